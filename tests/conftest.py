@@ -1,0 +1,38 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle_py
+    oracle_py.build()
+    return oracle_py
+
+
+@pytest.fixture(scope="session")
+def weights_blob():
+    from hobot_stereonet_amd import weights
+    return weights.synthetic(0)
+
+
+@pytest.fixture(scope="session")
+def golden_net():
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "network_golden.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_pre():
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "preprocess_golden.npz"))

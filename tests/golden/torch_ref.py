@@ -1,0 +1,84 @@
+"""SN-K4 expressed with torch.nn.functional on CPU (fp32) — an independent
+second implementation used to validate the C oracle.  This is not
+reference code: the reference has no network arithmetic.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from hobot_stereonet_amd import spec, weights as W
+
+
+def _t(blob, name):
+    return torch.from_numpy(W.tensor(blob, name).copy())
+
+
+def lrelu(x):
+    return F.leaky_relu(x, spec.LRELU_SLOPE)
+
+
+def res_block(blob, prefix, x, dil):
+    t = lrelu(F.conv2d(x, _t(blob, prefix + ".1.w"), _t(blob, prefix + ".1.b"), padding=dil, dilation=dil))
+    t = F.conv2d(t, _t(blob, prefix + ".2.w"), _t(blob, prefix + ".2.b"), padding=dil, dilation=dil)
+    return lrelu(x + t)
+
+
+def features(blob, planes):              # planes: (1,3,hp,wp)
+    x = planes
+    for i in range(spec.N_DOWN):
+        x = F.conv2d(x, _t(blob, f"feat.down{i}.w"), _t(blob, f"feat.down{i}.b"), stride=2, padding=2)
+    for i in range(spec.N_FEAT_RES):
+        x = res_block(blob, f"feat.res{i}", x, 1)
+    return F.conv2d(x, _t(blob, "feat.out.w"), _t(blob, "feat.out.b"), padding=1)
+
+
+def cost_volume(fl, fr, dl):             # (1,C,h,w) -> (1,C,dl,h,w)
+    _, c, h, w = fl.shape
+    cv = torch.zeros(1, c, dl, h, w)
+    for d in range(dl):
+        if d == 0:
+            cv[:, :, 0] = fl - fr
+        else:
+            cv[:, :, d, :, d:] = fl[..., d:] - fr[..., :-d]
+    return cv
+
+
+def aggregate(blob, fl, fr, dl):
+    x = cost_volume(fl, fr, dl)
+    for i in range(spec.N_AGG):
+        x = lrelu(F.conv3d(x, _t(blob, f"agg.conv{i}.w"), _t(blob, f"agg.conv{i}.b"), padding=1))
+    return F.conv3d(x, _t(blob, "agg.out.w"), _t(blob, "agg.out.b"), padding=1)[:, 0]   # (1,dl,h,w)
+
+
+def soft_argmin(cost):                   # (1,dl,h,w) -> (1,h,w)
+    p = torch.softmax(-cost, dim=1)
+    d = torch.arange(cost.shape[1], dtype=torch.float32).view(1, -1, 1, 1)
+    return (p * d).sum(1)
+
+
+def refine(blob, disp_up, img, dmax):    # (1,1,hp,wp), (1,3,hp,wp)
+    x = torch.cat([disp_up / dmax, img], 1)
+    x = lrelu(F.conv2d(x, _t(blob, "ref.in.w"), _t(blob, "ref.in.b"), padding=1))
+    for i, dil in enumerate(spec.REF_DILATIONS):
+        x = res_block(blob, f"ref.res{i}", x, dil)
+    r = F.conv2d(x, _t(blob, "ref.out.w"), _t(blob, "ref.out.b"), padding=1)
+    return F.relu(disp_up + dmax * r)
+
+
+def forward(blob, in6: np.ndarray, dmax: int):
+    """in6 int8 (6,h,w) -> dict(disp (h,w) f32, disp_low, cost)"""
+    _, h, w = in6.shape
+    hp, wp = spec.ceil16(h), spec.ceil16(w)
+    x = torch.zeros(1, 6, hp, wp)
+    x[0, :, :h, :w] = torch.from_numpy(in6.astype(np.float32) / 128.0)
+    with torch.no_grad():
+        fl = features(blob, x[:, :3])
+        fr = features(blob, x[:, 3:])
+        cost = aggregate(blob, fl, fr, dmax // 16)
+        low = soft_argmin(cost)
+        up = F.interpolate(low[:, None], scale_factor=16, mode="bilinear", align_corners=False) * 16.0
+        disp = refine(blob, up, x[:, :3], dmax)
+    return {"disp": disp[0, 0, :h, :w].numpy().copy(), "disp_low": low[0].numpy().copy(),
+            "cost": cost[0].numpy().copy(), "fl": fl[0].numpy().copy(), "fr": fr[0].numpy().copy()}

@@ -1,0 +1,97 @@
+"""Oracle network (C, fp32) vs the torch restatement: committed golden vectors and a
+live torch run.  The network itself is parity-UNPINNED w.r.t. the reference (no
+arithmetic, tests or vectors exist there — SURVEY.md §8(c)); these tests pin the
+oracle to the published algorithm as restated twice, independently."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from hobot_stereonet_amd import spec, synth, weights
+
+CASES = [("c96x64_d48", 96, 64, 48, 3), ("c160x96_d96", 160, 96, 96, 4), ("c100x52_d32", 100, 52, 32, 5)]
+TOL = 2e-4   # px; fp32 summation-order noise between the C loops and torch's kernels
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_weight_table_agrees_with_spec(oracle):
+    assert oracle.weight_count() == spec.param_count() == 423586
+    for name, (off, _) in spec.offsets().items():
+        if name != "__total__":
+            assert oracle.weight_offset(name) == off, name
+    assert oracle.weight_offset("nope.w") == -1
+
+
+def test_generators_have_not_drifted(golden_net, weights_blob):
+    assert sha(weights_blob) == str(golden_net["weights_sha256"])
+    for name, w, h, d, seed in CASES:
+        assert sha(synth.model_input_i8(w, h, d, seed)) == str(golden_net[name + ".input_sha256"])
+
+
+@pytest.mark.parametrize("name,w,h,d,seed", CASES)
+def test_forward_matches_golden(oracle, golden_net, weights_blob, name, w, h, d, seed):
+    x = synth.model_input_i8(w, h, d, seed)
+    disp, raw, low = oracle.forward(weights_blob, x, d)
+    assert np.abs(low - golden_net[name + ".disp_low"]).max() < 2e-5
+    epe = np.abs(disp - golden_net[name + ".disp"]).mean()
+    assert epe < TOL, epe
+    assert np.abs(disp - golden_net[name + ".disp"]).max() < 20 * TOL
+    # wire format: raw * scale * D reproduces disp to the int32 quantum (D * scale px)
+    q = d * spec.OUT_SCALE
+    assert np.abs(raw.astype(np.float64) * q - disp).max() <= 0.52 * q + 2e-6
+    assert raw.min() >= 0     # uint32 and int32 views agree (appendix B-5)
+
+
+def test_ops_match_golden(oracle, golden_net):
+    g = golden_net
+    x = g["op.conv2d.x"]
+    for tag, s, p, dil in [("k3", 1, 1, 1), ("k3d4", 1, 4, 4), ("k5s2", 2, 2, 1)]:
+        y = oracle.conv2d(x, g[f"op.conv2d.{tag}.w"], g[f"op.conv2d.{tag}.b"], s, p, dil)
+        np.testing.assert_allclose(y, g[f"op.conv2d.{tag}.y"], rtol=1e-5, atol=2e-5)
+    y3 = oracle.conv3d(g["op.conv3d.x"], g["op.conv3d.w"], g["op.conv3d.b"])
+    np.testing.assert_allclose(y3, g["op.conv3d.y"], rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(oracle.upsample_bilinear(g["op.up.x"], 16, 16.0), g["op.up.y"], rtol=1e-6, atol=1e-5)
+    np.testing.assert_allclose(oracle.soft_argmin(g["op.sam.x"]), g["op.sam.y"], rtol=1e-5, atol=1e-5)
+
+
+def test_live_torch_agrees(oracle, weights_blob):
+    import torch_ref
+    w, h, d = 112, 80, 64
+    x = synth.model_input_i8(w, h, d, 11)
+    disp, _, low = oracle.forward(weights_blob, x, d)
+    ref = torch_ref.forward(weights_blob, x, d)
+    assert np.abs(low - ref["disp_low"]).max() < 2e-5
+    assert np.abs(disp - ref["disp"]).mean() < TOL
+
+
+def test_identical_eyes_known_answer(oracle, weights_blob):
+    # the reference's only image fixtures are byte-identical L/R (config/image_left.jpg ==
+    # image_right.jpg) => plane d=0 of the cost volume is exactly 0 and both feature maps are equal.
+    w, h, d = 96, 64, 48
+    x = synth.model_input_i8(w, h, d, 5).copy()
+    x[3:] = x[:3]
+    planes = np.zeros((3, h, w), np.float32)
+    planes[:] = x[:3].astype(np.float32) / 128.0
+    fl = oracle.features(weights_blob, planes)
+    cv = oracle.cost_volume(fl, fl, d // 16)
+    assert (cv[:, 0] == 0).all()
+    assert (cv[:, 1, :, :1] == 0).all()
+
+
+def test_bad_args_are_rejected(oracle, weights_blob):
+    with pytest.raises(ValueError):
+        oracle.forward(weights_blob, np.zeros((6, 16, 16), np.int8), 40)   # D not a multiple of 16
+
+
+def test_snw_roundtrip(tmp_path, weights_blob):
+    p = str(tmp_path / "m.snw")
+    weights.save_snw(p, weights_blob, 1280, 720, 192)
+    blob, meta = weights.load_snw(p)
+    assert (blob == weights_blob).all() and meta == {"width": 1280, "height": 720, "dmax": 192}
+    with open(p, "r+b") as f:
+        f.write(b"XXXX")
+    with pytest.raises(ValueError):
+        weights.load_snw(p)
