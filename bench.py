@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Benchmark of the StereoNet hot path on MI355X — BASELINE.json metric: stereo pairs/s (+ ms/frame)
+at 1280x720, D=192.
+
+    python bench.py --gpus N --steps K --warmup W [--batch B] [--no-cpu-baseline]
+
+A step = one pass of the hot path (int8 model input -> int32 wire output + float disparity) over
+one batch of B synthetic pairs per GPU, inputs already resident in HBM.  N>1: one process per GPU
+(torch.distributed, backend nccl = RCCL), pairs sharded with no data-path collective; the step ends
+with the north-star's single exchange, an RCCL gather of the int32 disparity maps to rank 0.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+W, H, D = 1280, 720, 192
+MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: exact-fp32 MFMA peak
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(blob, x_one):
+    """The CPU-float oracle (oracle/, a 'port': the reference has no CPU implementation of the network)
+    timed on this box's host cores on a bounded sample: 3 passes of one 1280x720 D=192 pair."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py
+    oracle_py.forward(blob, x_one, D)            # warm-up (thread pool, page faults)
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        oracle_py.forward(blob, x_one, D)
+        ts.append(time.perf_counter() - t0)
+    med = sorted(ts)[1]
+    return {"value": 1.0 / med, "unit": "pairs/s", "cores": oracle_py.num_threads(), "kind": "port",
+            "sample": "3 passes of one 1280x720 D=192 pair through oracle/stereonet_oracle.c (median), 1 warm-up",
+            "ms_per_frame": med * 1e3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="pairs per GPU per step")
+    ap.add_argument("--refine-chunk", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from hobot_stereonet_amd import api, synth, weights
+
+    blob = weights.synthetic(0)
+    B = args.batch
+    tmp = tempfile.mkdtemp(prefix=f"snbench{rank}_")
+    model = os.path.join(tmp, "bench.snw")
+    weights.save_snw(model, blob, W, H, D)
+    eng = api.StereoNetHIP(model, device=local_rank, max_batch=B, refine_chunk=args.refine_chunk)
+
+    # synthetic shard for this rank: distinct seeds per pair; a few distinct pairs tiled to B
+    uniq = min(B, 4)
+    host = np.stack([synth.model_input_i8(W, H, D, rank * 1000 + i) for i in range(uniq)])
+    host = np.concatenate([host] * ((B + uniq - 1) // uniq))[:B]
+    dev = torch.device("cuda", local_rank)
+    x = torch.from_numpy(host).to(dev)
+    raw = torch.empty((B, H, W), dtype=torch.int32, device=dev)
+    disp = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    gathered = [torch.empty_like(raw) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    def step():
+        st = torch.cuda.current_stream().cuda_stream
+        eng.infer_device(B, x.data_ptr(), raw.data_ptr(), disp.data_ptr(), st)
+        if world > 1:
+            dist.gather(raw, gathered, dst=0)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-stage / dominant-kernel timing with HIP events on the launch stream (untimed extra pass)
+    roof = None
+    stage = None
+    if rank == 0:
+        eng.set_profiling(True)
+        reps = 3
+        acc = None
+        for _ in range(reps):
+            eng.infer_device(B, x.data_ptr(), raw.data_ptr(), disp.data_ptr(), 0)   # own stream, synchronous
+            ms = eng.stage_ms()
+            acc = ms if acc is None else {k: acc[k] + ms[k] for k in ms}
+        stage = {k: v / reps for k, v in acc.items()}
+        eng.set_profiling(False)
+        dk = eng.dominant_kernel()
+        launch_ms = stage["refine_conv"] / dk["launches"]
+        achieved = dk["flops_per_launch"] / (launch_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": dk["name"], "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                "avg_launch_ms": launch_ms, "launches_per_pair": dk["launches"],
+                "algorithmic_gbytes_per_s": dk["bytes_per_launch"] / (launch_ms * 1e-3) / 1e9,
+                "hbm_peak_gbytes_per_s": HBM_PEAK_GBS}
+
+    if rank == 0:
+        pairs = B * world * args.steps
+        value = pairs / elapsed
+        out = {
+            "metric": "stereo pairs/s at 1280x720 D=192 (ms/frame alongside)", "value": value, "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_frame": elapsed / (B * args.steps) * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (seeded stereo pairs, seeded random SN-K4 weights)",
+            "config": {"workload": f"BASELINE configs[1]: ZED-2i 1280x720 D=192 fp32, {B} pairs/GPU/step resident in HBM",
+                       "pairs_per_gpu_per_step": B, "width": W, "height": H, "dmax": D, "precision": "fp32-mfma",
+                       "refine_chunk": args.refine_chunk, "parallelism": f"shard{world}+rccl-gather" if world > 1 else "1gpu"},
+            "gflop_per_pair": eng.flops_per_pair / 1e9,
+            "model_tflops": value * eng.flops_per_pair / 1e12 / world,
+            "stage_ms_per_step": stage,
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(blob, host[0])
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,240 @@
+"""ctypes binding of libstereonet_hip.so (include/stereonet_hip.h) — the Python face of the
+drop-in boundary.  It mirrors the call sequence of the reference node:
+
+    Init()/GetModelInputSize  -> StereoNetHIP(model_file)          stereonet_node.cpp:44-45
+    Run(inputs, out, sync)    -> .infer(...) / .submit()+.wait()    stereonet_node.cpp:812,968
+    CvtNV12Data2Tensors       -> .preprocess_nv12(...)              preprocess.cpp:913-1059
+
+There is no CPU fallback: constructing StereoNetHIP without a gfx950 device raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from . import build as _build
+
+SN_MEM_HOST, SN_MEM_DEVICE = 0, 1
+PREC_FP32, PREC_F16X3, PREC_F16 = 0, 1, 2
+STAGES = ("features", "aggregate", "refine", "refine_conv", "total")
+
+
+class SnConfig(C.Structure):
+    _fields_ = [("device", C.c_int), ("max_batch", C.c_int), ("width", C.c_int), ("height", C.c_int),
+                ("dmax", C.c_int), ("precision", C.c_int), ("task_num", C.c_int), ("refine_chunk", C.c_int)]
+
+
+class SnIoInfo(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("dmax", C.c_int), ("in_channels", C.c_int),
+                ("max_batch", C.c_int), ("precision", C.c_int), ("task_num", C.c_int), ("device", C.c_int),
+                ("out_scale", C.c_float), ("in_bytes", C.c_size_t), ("out_bytes", C.c_size_t),
+                ("flops_per_pair", C.c_double)]
+
+
+class StereoNetError(RuntimeError):
+    def __init__(self, code: int, where: str, detail: str = ""):
+        self.code = code
+        super().__init__(f"{where}: {error_string(code)} (code {code}){': ' + detail if detail else ''}")
+
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None):
+    """Loads (building if stale and hipcc is present) libstereonet_hip.so."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or _build.LIB
+    if not os.path.exists(path) or (os.path.exists(_build.HIPCC) and _build.is_stale()):
+        _build.build()
+    lib = C.CDLL(path)
+    vp, ip, i8p, i32p, fp, u8p = C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
+    lib.sn_create.argtypes = [C.c_char_p, C.POINTER(SnConfig), C.POINTER(vp)]
+    lib.sn_destroy.argtypes = [vp]
+    lib.sn_get_io_info.argtypes = [vp, C.POINTER(SnIoInfo)]
+    lib.sn_strerror.restype = C.c_char_p
+    lib.sn_strerror.argtypes = [ip]
+    lib.sn_last_error.restype = C.c_char_p
+    lib.sn_last_error.argtypes = [vp]
+    lib.sn_infer_i8.argtypes = [vp, i8p, i32p, fp, ip, vp]
+    lib.sn_infer_batch.argtypes = [vp, ip, i8p, i32p, fp, ip, vp]
+    lib.sn_preprocess_nv12.argtypes = [vp, u8p, u8p, ip, ip, i8p, ip, vp]
+    lib.sn_infer_sbs_nv12.argtypes = [vp, u8p, ip, ip, i32p, fp, i8p, ip, vp]
+    lib.sn_submit.argtypes = [vp, i8p, i32p, fp, ip, C.POINTER(C.c_uint64)]
+    lib.sn_wait.argtypes = [vp, C.c_uint64, C.POINTER(C.c_float)]
+    lib.sn_synchronize.argtypes = [vp]
+    lib.sn_set_profiling.argtypes = [vp, ip]
+    lib.sn_get_stage_ms.argtypes = [vp, C.POINTER(C.c_float), ip]
+    lib.sn_get_dominant_kernel.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(ip), C.POINTER(C.c_double),
+                                           C.POINTER(C.c_double)]
+    lib.sn_dbg_conv2d.argtypes = [vp, fp, ip, ip, ip, fp, fp, ip, ip, ip, ip, fp, fp]
+    lib.sn_dbg_conv3d.argtypes = [vp, fp, ip, ip, ip, fp, fp, ip, fp]
+    lib.sn_dbg_read.argtypes = [vp, C.c_char_p, fp, C.c_size_t, C.POINTER(C.c_size_t)]
+    for name in ("sn_create", "sn_destroy", "sn_get_io_info", "sn_infer_i8", "sn_infer_batch", "sn_preprocess_nv12",
+                 "sn_infer_sbs_nv12", "sn_submit", "sn_wait", "sn_synchronize", "sn_set_profiling",
+                 "sn_get_stage_ms", "sn_get_dominant_kernel", "sn_dbg_conv2d", "sn_dbg_conv3d", "sn_dbg_read"):
+        getattr(lib, name).restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def error_string(code: int) -> str:
+    return load_library().sn_strerror(code).decode()
+
+
+def _np_ptr(a: Optional[np.ndarray]):
+    return a.ctypes.data if a is not None else None
+
+
+class StereoNetHIP:
+    """One GPU's StereoNet engine (sn_handle)."""
+
+    def __init__(self, model_file: str, device: int = -1, max_batch: int = 1, width: int = 0, height: int = 0,
+                 dmax: int = 0, precision: int = PREC_FP32, task_num: int = 4, refine_chunk: int = 0):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        cfg = SnConfig(device, max_batch, width, height, dmax, precision, task_num, refine_chunk)
+        rc = self._lib.sn_create(model_file.encode(), C.byref(cfg), C.byref(self._h))
+        if rc != 0:
+            self._h = C.c_void_p()
+            raise StereoNetError(rc, f"sn_create({model_file!r})")
+        info = SnIoInfo()
+        self._check(self._lib.sn_get_io_info(self._h, C.byref(info)), "sn_get_io_info")
+        self.info = info
+        self.width, self.height, self.dmax = info.width, info.height, info.dmax
+        self.max_batch = info.max_batch
+        self.out_scale = float(info.out_scale)
+        self.flops_per_pair = float(info.flops_per_pair)
+
+    # -- plumbing -----------------------------------------------------------------------------
+    def _check(self, rc: int, where: str):
+        if rc != 0:
+            detail = self._lib.sn_last_error(self._h).decode() if self._h else ""
+            raise StereoNetError(rc, where, detail)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.sn_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- Run (host numpy buffers) ---------------------------------------------------------------
+    def infer(self, in6: np.ndarray, want_disp: bool = True, want_raw: bool = True):
+        """in6: int8 (6,H,W) or (n,6,H,W) -> (disp float32, raw int32) with matching leading dims."""
+        x = np.ascontiguousarray(in6, dtype=np.int8)
+        single = x.ndim == 3
+        if single:
+            x = x[None]
+        n = x.shape[0]
+        if x.shape[1:] != (6, self.height, self.width):
+            raise StereoNetError(-1, "infer", f"input shape {x.shape} != (n,6,{self.height},{self.width})")
+        disp = np.empty((n, self.height, self.width), np.float32) if want_disp else None
+        raw = np.empty((n, self.height, self.width), np.int32) if want_raw else None
+        self._check(self._lib.sn_infer_batch(self._h, n, x.ctypes.data, _np_ptr(raw), _np_ptr(disp), SN_MEM_HOST, None),
+                    "sn_infer_batch")
+        if single:
+            return (disp[0] if disp is not None else None), (raw[0] if raw is not None else None)
+        return disp, raw
+
+    # -- Run (device pointers, e.g. torch tensors' data_ptr(); stream = hipStream_t as int) ------
+    def infer_device(self, n: int, in_ptr: int, raw_ptr: int, disp_ptr: int, stream: int = 0):
+        self._check(self._lib.sn_infer_batch(self._h, n, in_ptr, raw_ptr or None, disp_ptr or None, SN_MEM_DEVICE,
+                                             stream or None), "sn_infer_batch")
+
+    def preprocess_nv12(self, left: np.ndarray, right: np.ndarray, w: int, h: int) -> np.ndarray:
+        left = np.ascontiguousarray(left, dtype=np.uint8)
+        right = np.ascontiguousarray(right, dtype=np.uint8)
+        out = np.empty((6, h, w), np.int8)
+        self._check(self._lib.sn_preprocess_nv12(self._h, left.ctypes.data, right.ctypes.data, w, h, out.ctypes.data,
+                                                 SN_MEM_HOST, None), "sn_preprocess_nv12")
+        return out
+
+    def infer_sbs_nv12(self, sbs: np.ndarray, want_tensor: bool = False):
+        """sbs: uint8 side-by-side NV12 frame (H*3/2 rows of 2W bytes) -> (disp, raw[, tensor])"""
+        sbs = np.ascontiguousarray(sbs, dtype=np.uint8)
+        disp = np.empty((self.height, self.width), np.float32)
+        raw = np.empty((self.height, self.width), np.int32)
+        ten = np.empty((6, self.height, self.width), np.int8) if want_tensor else None
+        self._check(self._lib.sn_infer_sbs_nv12(self._h, sbs.ctypes.data, 2 * self.width, self.height, raw.ctypes.data,
+                                                disp.ctypes.data, _np_ptr(ten), SN_MEM_HOST, None), "sn_infer_sbs_nv12")
+        return (disp, raw, ten) if want_tensor else (disp, raw)
+
+    # -- async Run -------------------------------------------------------------------------------
+    def submit(self, in6: np.ndarray, raw_out: Optional[np.ndarray], disp_out: Optional[np.ndarray],
+               timeout_ms: int = -1) -> int:
+        x = np.ascontiguousarray(in6, dtype=np.int8)
+        t = C.c_uint64()
+        self._check(self._lib.sn_submit(self._h, x.ctypes.data, _np_ptr(raw_out), _np_ptr(disp_out), timeout_ms,
+                                        C.byref(t)), "sn_submit")
+        return t.value
+
+    def wait(self, ticket: int) -> float:
+        ms = C.c_float()
+        self._check(self._lib.sn_wait(self._h, ticket, C.byref(ms)), "sn_wait")
+        return ms.value
+
+    def synchronize(self):
+        self._check(self._lib.sn_synchronize(self._h), "sn_synchronize")
+
+    # -- measurement -------------------------------------------------------------------------------
+    def set_profiling(self, on: bool):
+        self._check(self._lib.sn_set_profiling(self._h, int(on)), "sn_set_profiling")
+
+    def stage_ms(self) -> dict:
+        arr = (C.c_float * len(STAGES))()
+        self._check(self._lib.sn_get_stage_ms(self._h, arr, len(STAGES)), "sn_get_stage_ms")
+        return dict(zip(STAGES, [float(v) for v in arr]))
+
+    def dominant_kernel(self) -> dict:
+        name = C.create_string_buffer(128)
+        launches = C.c_int()
+        fl, by = C.c_double(), C.c_double()
+        self._check(self._lib.sn_get_dominant_kernel(self._h, name, 128, C.byref(launches), C.byref(fl), C.byref(by)),
+                    "sn_get_dominant_kernel")
+        return {"name": name.value.decode(), "launches": launches.value, "flops_per_launch": fl.value,
+                "bytes_per_launch": by.value}
+
+    # -- parity hooks --------------------------------------------------------------------------------
+    def dbg_conv2d(self, x, wt, bias, k, stride=1, dil=1, lrelu=False, residual=None):
+        x = np.ascontiguousarray(x, np.float32)
+        wt = np.ascontiguousarray(wt, np.float32)
+        bias = np.ascontiguousarray(bias, np.float32)
+        cin, h, w = x.shape
+        ho, wo = (h, w) if stride == 1 else (h // 2, w // 2)
+        out = np.empty((32, ho, wo), np.float32)
+        res = np.ascontiguousarray(residual, np.float32) if residual is not None else None
+        self._check(self._lib.sn_dbg_conv2d(self._h, x.ctypes.data, cin, h, w, wt.ctypes.data, bias.ctypes.data, k,
+                                            stride, dil, int(lrelu), _np_ptr(res), out.ctypes.data), "sn_dbg_conv2d")
+        return out
+
+    def dbg_conv3d(self, x, wt, bias, lrelu=False):
+        x = np.ascontiguousarray(x, np.float32)
+        wt = np.ascontiguousarray(wt, np.float32)
+        bias = np.ascontiguousarray(bias, np.float32)
+        _, d, h, w = x.shape
+        out = np.empty_like(x)
+        self._check(self._lib.sn_dbg_conv3d(self._h, x.ctypes.data, d, h, w, wt.ctypes.data, bias.ctypes.data,
+                                            int(lrelu), out.ctypes.data), "sn_dbg_conv3d")
+        return out
+
+    def dbg_read(self, what: str) -> np.ndarray:
+        n = C.c_size_t()
+        self._check(self._lib.sn_dbg_read(self._h, what.encode(), None, 0, C.byref(n)), "sn_dbg_read")
+        out = np.empty(n.value, np.float32)
+        self._check(self._lib.sn_dbg_read(self._h, what.encode(), out.ctypes.data, n.value, C.byref(n)), "sn_dbg_read")
+        return out

@@ -1,0 +1,407 @@
+// sn_kernels.hpp — gfx950 (CDNA4) device kernels for the StereoNet path.
+//
+// Everything here replaces what the reference runs inside the opaque BPU blob behind
+// DnnNode::Run (stereonet_infer/src/stereonet_node.cpp:812) plus the byte shuffling of
+// PreProcess::CvtNV12Data2Tensors (stereonet_infer/src/preprocess.cpp:913-1059).
+// Layer semantics: DESIGN.md §2 (SN-K4).  wave = 64 lanes; MFMA = v_mfma_f32_32x32x2_f32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kC = 32;            // feature channels == MFMA N
+constexpr float kSlope = 0.2f;    // LeakyReLU
+
+// Bijective XCD-aware remap: hardware places block b on XCD b % 8; give each XCD a contiguous
+// run of logical tiles so neighbouring tiles (which share halos) hit the same L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+// ------------------------------------------------------------------------------------------
+// K0: NV12 pair -> int8 NCHW 6xHxW, bit-exact with preprocess.cpp:975-1056.
+// The reference indexes the chroma as planar I420 (preprocess.h:131-133): "U" = in + w*h,
+// "V" = U + w*h/4, sample (i/2)*w/2 + j/2; each byte then goes through Quantize(((b-128)/128))
+// which equals b ^ 0x80 for all 256 values (tests/golden/preprocess_golden.npz).
+// `src_pitch`/`eye_off` let the same kernel read the two eyes straight out of the 2W-wide
+// side-by-side message (stereonet_node.cpp:705-738) without the host-side split.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pre_nv12(const uint8_t* __restrict__ left,
+                                                  const uint8_t* __restrict__ right, int src_pitch,
+                                                  int w, int h, int8_t* __restrict__ out6) {
+  // one thread = 4 consecutive output bytes of one plane row
+  const int quads = w >> 2;
+  const long total = 6L * h * quads;
+  for (long t = blockIdx.x * 256L + threadIdx.x; t < total; t += (long)gridDim.x * 256L) {
+    const int q = (int)(t % quads);
+    const long rowid = t / quads;
+    const int i = (int)(rowid % h);
+    const int plane = (int)(rowid / h);   // 0..5
+    const uint8_t* src = plane < 3 ? left : right;
+    const int p = plane % 3;
+    const int j = q << 2;
+    uint32_t v;
+    if (p == 0) {
+      // w % 4 == 0 and 4-byte aligned eye pointers are checked on the host
+      v = *reinterpret_cast<const uint32_t*>(src + (size_t)i * src_pitch + j);
+    } else {
+      // linear index into the eye's contiguous w*h/2 chroma bytes, as the reference computes it
+      const int base = (p == 1 ? 0 : (w * h) / 4) + (i / 2) * w / 2 + j / 2;
+      // chroma byte k of the contiguous eye image lives at row h + k / w, col k % w of the source
+      const int k0 = base, k1 = base + 1;
+      const uint8_t c0 = src[(size_t)(h + k0 / w) * src_pitch + (k0 % w)];
+      const uint8_t c1 = src[(size_t)(h + k1 / w) * src_pitch + (k1 % w)];
+      v = (uint32_t)c0 * 0x0101u | ((uint32_t)c1 * 0x0101u << 16);
+    }
+    v ^= 0x80808080u;
+    *reinterpret_cast<uint32_t*>(out6 + ((size_t)plane * h + i) * w + j) = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Input loaders for the implicit-GEMM convolution.  A loader maps (image, virtual channel,
+// y, x) -> fp32 input value, returning 0 outside the tensor (zero padding) — this is where the
+// cost volume, the 3-D plane gathering, the int8 dequantisation and the bilinear upsample are
+// fused into the consuming convolution instead of being materialised in HBM.
+// ------------------------------------------------------------------------------------------
+struct LoadF32 {            // plain NCHW fp32 tensor [nimg][C][H][W]
+  const float* p;
+  int C, H, W;
+  __device__ __forceinline__ float operator()(int img, int c, int y, int x) const {
+    if ((unsigned)y >= (unsigned)H || (unsigned)x >= (unsigned)W || c >= C) return 0.f;
+    return p[(((size_t)img * C + c) * H + y) * W + x];
+  }
+};
+
+struct LoadI8Eye {          // model input int8 [n][6][H][W]; image = n*2 + eye; 3 real channels
+  const int8_t* p;
+  int H, W;
+  __device__ __forceinline__ float operator()(int img, int c, int y, int x) const {
+    if ((unsigned)y >= (unsigned)H || (unsigned)x >= (unsigned)W || c >= 3) return 0.f;
+    const int n = img >> 1, eye = img & 1;
+    return (float)p[(((size_t)n * 6 + eye * 3 + c) * H + y) * W + x] * (1.0f / 128.0f);
+  }
+};
+
+// 3-D conv as a 2-D conv over 96 virtual channels: c' = dz*32 + ci reads plane d+dz-1.
+// Volume layout [n][Dl][32][H][W] (plane-major: every (n,d) is an ordinary NCHW image).
+struct LoadVol3D {
+  const float* p;
+  int Dl, H, W;
+  __device__ __forceinline__ float operator()(int img, int c, int y, int x) const {
+    const int n = img / Dl, d = img - n * Dl;
+    const int dz = c >> 5, ci = c & 31;
+    const int dd = d + dz - 1;
+    if ((unsigned)dd >= (unsigned)Dl || (unsigned)y >= (unsigned)H || (unsigned)x >= (unsigned)W)
+      return 0.f;
+    return p[((((size_t)n * Dl + dd) * kC + ci) * H + y) * W + x];
+  }
+};
+
+// Same, but the volume is the cost volume computed on the fly from the two feature maps:
+// cv[ci][dd][y][x] = fL[ci][y][x] - fR[ci][y][x-dd], 0 where x-dd < 0.   feat: [n*2+eye][32][H][W]
+struct LoadCostVol {
+  const float* feat;
+  int Dl, H, W;
+  __device__ __forceinline__ float operator()(int img, int c, int y, int x) const {
+    const int n = img / Dl, d = img - n * Dl;
+    const int dz = c >> 5, ci = c & 31;
+    const int dd = d + dz - 1;
+    if ((unsigned)dd >= (unsigned)Dl || (unsigned)y >= (unsigned)H || (unsigned)x >= (unsigned)W ||
+        x < dd)
+      return 0.f;
+    const size_t plane = (size_t)H * W;
+    const float* l = feat + ((size_t)(2 * n) * kC + ci) * plane + (size_t)y * W;
+    const float* r = l + (size_t)kC * plane;
+    return l[x] - r[x - dd];
+  }
+};
+
+// bilinear x16, align_corners=False, values x16 (disparity in full-res px)
+__device__ __forceinline__ float upsample16(const float* low, int hl, int wl, int y, int x) {
+  float sy = ((float)y + 0.5f) * (1.0f / 16.0f) - 0.5f;
+  float sx = ((float)x + 0.5f) * (1.0f / 16.0f) - 0.5f;
+  sy = sy < 0.f ? 0.f : sy;
+  sx = sx < 0.f ? 0.f : sx;
+  const int y0 = (int)sy, x0 = (int)sx;
+  const int y1 = y0 < hl - 1 ? y0 + 1 : y0, x1 = x0 < wl - 1 ? x0 + 1 : x0;
+  const float ly = sy - (float)y0, lx = sx - (float)x0;
+  const float hy = 1.0f - ly, hx = 1.0f - lx;
+  const float v = hy * (hx * low[y0 * wl + x0] + lx * low[y0 * wl + x1]) +
+                  ly * (hx * low[y1 * wl + x0] + lx * low[y1 * wl + x1]);
+  return v * 16.0f;
+}
+
+// Refinement input: channel 0 = upsampled disparity / D, channels 1..3 = left image planes.
+struct LoadRefineIn {
+  const float* disp_low;    // [n][hl][wl]
+  const int8_t* in6;        // [n][6][H][W]
+  int hl, wl, H, W, Hp, Wp;
+  float inv_d;
+  __device__ __forceinline__ float operator()(int img, int c, int y, int x) const {
+    if ((unsigned)y >= (unsigned)Hp || (unsigned)x >= (unsigned)Wp || c >= 4) return 0.f;
+    if (c == 0) return upsample16(disp_low + (size_t)img * hl * wl, hl, wl, y, x) * inv_d;
+    if (y >= H || x >= W) return 0.f;
+    return (float)in6[(((size_t)img * 6 + (c - 1)) * H + y) * W + x] * (1.0f / 128.0f);
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// Implicit-GEMM convolution, C_out = 32, on the exact-fp32 matrix core.
+//   D[cout][pixel] += A[cout][k] * B[k][pixel],  k = (virtual channel, tap)
+//   v_mfma_f32_32x32x2_f32: lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31];
+//   lane l receives D[i = (r&3) + 8*(r>>2) + 4*(l>>5)][j = l&31], r = 0..15.
+// so one wave owns a 32-pixel row segment x all 32 output channels, and for a fixed register r the
+// two half-waves store two 128-byte runs of consecutive pixels (coalesced NCHW stores).
+// Block = 4 waves, tile = TR rows x TC cols of output; input halo tile and the weight slice of CH
+// input channels are staged through LDS per chunk.  For STRIDE 2 the staged columns are split by
+// parity so that the 32 lanes of a half-wave read consecutive LDS words (no bank conflicts).
+// ------------------------------------------------------------------------------------------
+struct ConvArgs {
+  const float* wpk;    // packed weights [cin_pad][taps][32]
+  const float* bias;   // [32]
+  float* out;          // [nimg][32][Ho][Wo]
+  const float* res;    // nullable residual, same layout as out (may alias out)
+  int nimg, cin_pad, Ho, Wo;
+  int dil, pad;
+  int lrelu;
+  int tiles_x, tiles_y;
+};
+
+template <int KS, int STRIDE, int CH, int TR, int TC, class Loader>
+__global__ __launch_bounds__(256) void k_conv_c32_mfma(ConvArgs a, Loader ld) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int TAPS = KS * KS;
+  constexpr int CSEG = TC / 32;
+  constexpr int NSEG = TR * CSEG;
+  static_assert(NSEG % 4 == 0, "tile must split evenly over 4 waves");
+  constexpr int SPW = NSEG / 4;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nwg = a.tiles_x * a.tiles_y * a.nimg;
+  const int b = xcd_remap(blockIdx.x, nwg);
+  const int tx = b % a.tiles_x;
+  const int t2 = b / a.tiles_x;
+  const int ty = t2 % a.tiles_y;
+  const int img = t2 / a.tiles_y;
+
+  const int rows_in = (TR - 1) * STRIDE + (KS - 1) * a.dil + 1;
+  const int cols_in = (TC - 1) * STRIDE + (KS - 1) * a.dil + 1;
+  const int half = (cols_in + 1) >> 1;
+  const int pitch = STRIDE == 1 ? cols_in : 2 * half;
+  float* s_w = smem;                       // [CH][TAPS][32]
+  float* s_in = smem + CH * TAPS * 32;     // [CH][rows_in][pitch]
+  const int iy0 = ty * TR * STRIDE - a.pad, ix0 = tx * TC * STRIDE - a.pad;
+
+  f32x16 acc[SPW];
+#pragma unroll
+  for (int s = 0; s < SPW; ++s)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+
+  const int kh = lane >> 5, j = lane & 31;
+
+  for (int c0 = 0; c0 < a.cin_pad; c0 += CH) {
+    __syncthreads();   // previous chunk fully consumed
+    {
+      const float4* wsrc = reinterpret_cast<const float4*>(a.wpk + (size_t)c0 * TAPS * 32);
+      float4* wdst = reinterpret_cast<float4*>(s_w);
+      for (int i = tid; i < CH * TAPS * 8; i += 256) wdst[i] = wsrc[i];
+    }
+    for (int rr = wave; rr < CH * rows_in; rr += 4) {
+      const int c = rr / rows_in;
+      const int r = rr - c * rows_in;
+      float* dst = s_in + (size_t)rr * pitch;
+      const int gy = iy0 + r;
+      for (int cc = lane; cc < cols_in; cc += 64) {
+        const float v = ld(img, c0 + c, gy, ix0 + cc);
+        const int di = STRIDE == 1 ? cc : (cc & 1) * half + (cc >> 1);
+        dst[di] = v;
+      }
+    }
+    __syncthreads();
+
+    for (int tap = 0; tap < TAPS; ++tap) {
+      const int ky = tap / KS, kx = tap - ky * KS;
+#pragma unroll
+      for (int kk = 0; kk < CH; kk += 2) {
+        const float wa = s_w[((kk + kh) * TAPS + tap) * 32 + j];
+        const float* plane = s_in + (size_t)(kk + kh) * rows_in * pitch;
+#pragma unroll
+        for (int s = 0; s < SPW; ++s) {
+          const int seg = wave * SPW + s;
+          const int srow = seg / CSEG, scol = (seg - srow * CSEG) * 32;
+          const int r = srow * STRIDE + ky * a.dil;
+          int di;
+          if (STRIDE == 1) {
+            di = scol + j + kx * a.dil;
+          } else {
+            di = (kx & 1) * half + scol + j + (kx >> 1);   // dil == 1 for strided convs
+          }
+          const float xb = plane[r * pitch + di];
+          acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa, xb, acc[s], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // epilogue: bias (+ residual) (+ LeakyReLU), coalesced NCHW stores
+  const size_t plane_o = (size_t)a.Ho * a.Wo;
+#pragma unroll
+  for (int s = 0; s < SPW; ++s) {
+    const int seg = wave * SPW + s;
+    const int srow = seg / CSEG, scol = (seg - srow * CSEG) * 32;
+    const int y = ty * TR + srow, x = tx * TC + scol + j;
+    if (y < a.Ho && x < a.Wo) {
+      const size_t base = (size_t)img * kC * plane_o + (size_t)y * a.Wo + x;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = (r & 3) + 8 * (r >> 2) + 4 * kh;
+        float v = acc[s][r] + a.bias[co];
+        const size_t idx = base + (size_t)co * plane_o;
+        if (a.res) v += a.res[idx];
+        if (a.lrelu) v = v > 0.f ? v : v * kSlope;
+        a.out[idx] = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K6: final 3x3x3 conv 32->1 fused with soft-argmin.
+//   cost[d] = b + sum_{ci,dz,ky,kx} w[ci][dz][ky][kx] * vol[n][d+dz-1][ci][y+ky-1][x+kx-1]
+//   disp    = sum_d d * softmax_d(-cost)
+// Lane layout inside a wave: 16 consecutive pixels x 4 channel groups (8 input channels each).
+// Every lane accumulates partial costs for all Dl planes over its 8 channels; the channel groups
+// are then combined with two wave shuffles (xor 16, xor 32) — no LDS, no cross-wave traffic — and
+// the softmax / expectation runs in registers.  Weights are wave-uniform -> scalar loads.
+// ------------------------------------------------------------------------------------------
+template <int DLMAX>
+__global__ __launch_bounds__(256) void k_head_softargmin(const float* __restrict__ vol,   // [n][Dl][32][H][W]
+                                                         const float* __restrict__ w,     // [32][27] (ci, dz*9+ky*3+kx)
+                                                         float bias, int Dl, int H, int W, int npix_total,
+                                                         float* __restrict__ disp_low,    // [n][H][W]
+                                                         float* __restrict__ cost_out) {  // nullable [n][Dl][H][W]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int grp = lane >> 4;                    // channel group 0..3
+  const int gp = (blockIdx.x * 4 + wave) * 16 + (lane & 15);   // global pixel index over n*H*W
+  const int plane = H * W;
+  const bool live = gp < npix_total;
+  const int n = live ? gp / plane : 0;
+  const int pix = live ? gp - n * plane : 0;
+  const int y = pix / W, x = pix - y * W;
+
+  float cost[DLMAX];
+#pragma unroll
+  for (int d = 0; d < DLMAX; ++d) cost[d] = 0.f;
+
+  for (int cg = 0; cg < 8; ++cg) {
+    const int ci = grp * 8 + cg;
+    const float* wc = w + ci * 27;
+#pragma unroll
+    for (int p = 0; p < DLMAX; ++p) {
+      if (p < Dl) {
+        const float* src = vol + (((size_t)n * Dl + p) * kC + ci) * plane;
+        float v[9];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const int yy = y + ky - 1, xx = x + kx - 1;
+            const bool ok = live && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+            v[ky * 3 + kx] = ok ? src[yy * W + xx] : 0.f;
+          }
+#pragma unroll
+        for (int dz = 0; dz < 3; ++dz) {
+          const int d = p - dz + 1;           // output plane fed by input plane p through tap dz
+          if (d >= 0 && d < DLMAX) {
+            float s = 0.f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) s = fmaf(wc[dz * 9 + t], v[t], s);
+            cost[d] += s;
+          }
+        }
+      }
+    }
+  }
+  // combine the 4 channel groups: wavefront shuffle reduction
+#pragma unroll
+  for (int d = 0; d < DLMAX; ++d) {
+    float c = cost[d];
+    c += __shfl_xor(c, 16, 64);
+    c += __shfl_xor(c, 32, 64);
+    cost[d] = c + bias;
+  }
+  // soft-argmin over the Dl planes (max-subtracted), in registers
+  float m = -cost[0];
+#pragma unroll
+  for (int d = 1; d < DLMAX; ++d)
+    if (d < Dl) m = fmaxf(m, -cost[d]);
+  float se = 0.f, sd = 0.f;
+#pragma unroll
+  for (int d = 0; d < DLMAX; ++d)
+    if (d < Dl) {
+      const float e = expf(-cost[d] - m);
+      se += e;
+      sd = fmaf((float)d, e, sd);
+    }
+  if (live && grp == 0) {
+    disp_low[gp] = sd / se;
+    if (cost_out) {
+#pragma unroll
+      for (int d = 0; d < DLMAX; ++d)
+        if (d < Dl) cost_out[((size_t)n * Dl + d) * plane + pix] = cost[d];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K8: refinement head 3x3 conv 32->1, disp = relu(up + D*r), float + wire int32 outputs.
+//   raw = rint(disp * inv_q), inv_q = 1/(D*scale)   (stereonet_node.cpp:282-288: the consumer
+//   multiplies raw by scale*16*12).  One thread per output pixel, lanes along x (coalesced).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_head_final(const float* __restrict__ xin,      // [n][32][Hp][Wp]
+                                                    const float* __restrict__ w,        // [32][9]
+                                                    float bias, const float* __restrict__ disp_low,
+                                                    int hl, int wl, int Hp, int Wp, int H, int W,
+                                                    float dmax, float inv_q,
+                                                    float* __restrict__ out_disp,       // nullable [n][H][W]
+                                                    int32_t* __restrict__ out_raw) {    // nullable [n][H][W]
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int n = blockIdx.z;
+  if (x >= W || y >= H) return;
+  const size_t plane = (size_t)Hp * Wp;
+  const float* src = xin + (size_t)n * kC * plane;
+  float acc = bias;
+  for (int ci = 0; ci < kC; ++ci) {
+    const float* p = src + (size_t)ci * plane;
+    const float* wc = w + ci * 9;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int yy = y + ky - 1;
+      if ((unsigned)yy >= (unsigned)Hp) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int xx = x + kx - 1;
+        const float v = (unsigned)xx < (unsigned)Wp ? p[(size_t)yy * Wp + xx] : 0.f;
+        acc = fmaf(wc[ky * 3 + kx], v, acc);
+      }
+    }
+  }
+  const float up = upsample16(disp_low + (size_t)n * hl * wl, hl, wl, y, x);
+  float d = up + dmax * acc;
+  d = d > 0.f ? d : 0.f;
+  const size_t o = ((size_t)n * H + y) * W + x;
+  if (out_disp) out_disp[o] = d;
+  if (out_raw) out_raw[o] = (int32_t)__float2int_rn(d * inv_q);
+}
+
+}  // namespace sn

@@ -1,0 +1,884 @@
+// stereonet_hip.hip — host engine + C ABI of libstereonet_hip.so (see include/stereonet_hip.h).
+//
+// Replaces, for the StereoNet hot path, what the reference obtains from the closed dnn_node /
+// libdnn runtime: model load (DnnNode::Init, stereonet_infer/src/stereonet_node.cpp:44), tensor
+// introspection (:57-103) and DnnNode::Run (:812 async, :968 sync).  No CPU fallback exists: if
+// there is no gfx950 device every entry point fails with SN_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/stereonet_hip.h"
+#include "sn_kernels.hpp"
+
+namespace {
+
+using namespace sn;
+
+constexpr int kNDown = 4, kNFeatRes = 6, kNAgg = 4, kNRefRes = 6;
+constexpr int kRefDil[kNRefRes] = {1, 2, 4, 8, 1, 1};
+constexpr float kOutScale = 2.60443857769133e-6f;   // stereonet_node.cpp:282
+
+#define HIP_TRY(h, expr)                                                              \
+  do {                                                                                \
+    hipError_t e_ = (expr);                                                           \
+    if (e_ != hipSuccess) {                                                           \
+      set_err(h, std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+      return SN_ERR_DEVICE;                                                           \
+    }                                                                                 \
+  } while (0)
+
+struct ConvLayer {
+  float* wpk = nullptr;    // device, packed [cin_pad][taps][32]
+  float* bias = nullptr;   // device [32]
+  int cin = 0, cin_pad = 0, taps = 0;
+};
+
+struct HeadLayer {          // C -> 1 layers (VALU kernels)
+  float* w = nullptr;       // device [32][taps]
+  float bias = 0.f;
+};
+
+struct Workspace {          // activations for up to `nb` pairs
+  int nb = 0, rb = 0;
+  int8_t* in6 = nullptr;
+  float* down[3] = {nullptr, nullptr, nullptr};
+  float* low[3] = {nullptr, nullptr, nullptr};
+  float* feat = nullptr;
+  float* vol[2] = {nullptr, nullptr};
+  float* cost = nullptr;     // [nb][Dl][hl][wl] (debug / parity)
+  float* disp_low = nullptr;
+  float* ref[2] = {nullptr, nullptr};
+  float* out_disp = nullptr;
+  int32_t* out_raw = nullptr;
+  uint8_t* nv12 = nullptr;   // staging for NV12 inputs (2 eyes or one side-by-side frame)
+};
+
+struct Slot {                // async request slot (sn_submit / sn_wait)
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  Workspace ws;
+  int8_t* pin_in = nullptr;
+  int32_t* pin_raw = nullptr;
+  float* pin_disp = nullptr;
+  int32_t* user_raw = nullptr;
+  float* user_disp = nullptr;
+  uint64_t ticket = 0;       // 0 = free
+};
+
+}  // namespace
+
+struct sn_handle {
+  int device = 0;
+  int W = 0, H = 0, D = 0, Wp = 0, Hp = 0, wl = 0, hl = 0, Dl = 0;
+  int max_batch = 1, precision = 0, task_num = 4, refine_chunk = 1;
+  hipStream_t stream = nullptr;
+  ConvLayer down[kNDown], fres[kNFeatRes][2], fout, agg[kNAgg], rin, rres[kNRefRes][2];
+  HeadLayer aout, rout;
+  Workspace ws;
+  std::vector<Slot> slots;
+  std::mutex mu;
+  std::condition_variable cv;
+  uint64_t next_ticket = 1;
+  // profiling
+  bool profiling = false;
+  hipEvent_t ev[8] = {};
+  float stage_ms[SN_STAGE_COUNT] = {};
+  int dom_launches = 0;
+  mutable std::string err;
+};
+
+namespace {
+
+void set_err(const sn_handle* h, const std::string& s) {
+  if (h) h->err = s;
+}
+void set_err(std::nullptr_t, const std::string&) {}
+
+template <class T>
+hipError_t dalloc(T** p, size_t count) {
+  return hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T) + 256);
+}
+
+// ---- weight file (hobot_stereonet_amd/weights.py documents the layout) -------------------------
+struct SnwHeader {
+  char magic[4];
+  uint32_t version, width, height, dmax, channels, n_down, n_fres, n_agg, n_rres;
+  uint32_t dil[6];
+  uint64_t n_params, reserved;
+};
+static_assert(sizeof(SnwHeader) == 80, "SNW1 header is 80 bytes");
+
+struct HostLayer {
+  const float* w;
+  const float* b;
+  int cout, cin, taps;
+};
+
+// Walks the canonical tensor order (spec.layers()).
+struct BlobWalker {
+  const float* base;
+  size_t off = 0;
+  HostLayer next(int cout, int cin, int taps) {
+    HostLayer l{base + off, nullptr, cout, cin, taps};
+    off += (size_t)cout * cin * taps;
+    l.b = base + off;
+    off += cout;
+    return l;
+  }
+};
+
+size_t param_count() {
+  size_t n = 0;
+  for (int i = 0; i < kNDown; ++i) n += (size_t)kC * (i == 0 ? 3 : kC) * 25 + kC;
+  n += (size_t)(2 * kNFeatRes + 1) * (kC * kC * 9 + kC);
+  n += (size_t)kNAgg * (kC * kC * 27 + kC) + kC * 27 + 1;
+  n += (size_t)kC * 4 * 9 + kC + (size_t)2 * kNRefRes * (kC * kC * 9 + kC) + kC * 9 + 1;
+  return n;
+}
+
+// 2-D conv weights [co][ci][ky][kx] -> packed [ci_pad][tap][co]
+int upload_conv2d(sn_handle* h, const HostLayer& l, int ch_multiple, ConvLayer* out) {
+  const int cin_pad = (l.cin + ch_multiple - 1) / ch_multiple * ch_multiple;
+  std::vector<float> pk((size_t)cin_pad * l.taps * kC, 0.f);
+  for (int co = 0; co < kC; ++co)
+    for (int ci = 0; ci < l.cin; ++ci)
+      for (int t = 0; t < l.taps; ++t)
+        pk[((size_t)ci * l.taps + t) * kC + co] = l.w[((size_t)co * l.cin + ci) * l.taps + t];
+  out->cin = l.cin;
+  out->cin_pad = cin_pad;
+  out->taps = l.taps;
+  HIP_TRY(h, dalloc(&out->wpk, pk.size()));
+  HIP_TRY(h, dalloc(&out->bias, kC));
+  HIP_TRY(h, hipMemcpy(out->wpk, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(h, hipMemcpy(out->bias, l.b, kC * sizeof(float), hipMemcpyHostToDevice));
+  return SN_OK;
+}
+
+// 3-D conv weights [co][ci][kz][ky][kx] -> packed [c' = kz*32+ci][tap = ky*3+kx][co]  (96 virtual channels)
+int upload_conv3d(sn_handle* h, const HostLayer& l, ConvLayer* out) {
+  std::vector<float> pk((size_t)96 * 9 * kC, 0.f);
+  for (int co = 0; co < kC; ++co)
+    for (int ci = 0; ci < kC; ++ci)
+      for (int kz = 0; kz < 3; ++kz)
+        for (int t = 0; t < 9; ++t)
+          pk[((size_t)(kz * kC + ci) * 9 + t) * kC + co] = l.w[(((size_t)co * kC + ci) * 3 + kz) * 9 + t];
+  out->cin = 96;
+  out->cin_pad = 96;
+  out->taps = 9;
+  HIP_TRY(h, dalloc(&out->wpk, pk.size()));
+  HIP_TRY(h, dalloc(&out->bias, kC));
+  HIP_TRY(h, hipMemcpy(out->wpk, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(h, hipMemcpy(out->bias, l.b, kC * sizeof(float), hipMemcpyHostToDevice));
+  return SN_OK;
+}
+
+int upload_head(sn_handle* h, const HostLayer& l, HeadLayer* out) {   // [1][32][taps] as-is
+  HIP_TRY(h, dalloc(&out->w, (size_t)kC * l.taps));
+  HIP_TRY(h, hipMemcpy(out->w, l.w, (size_t)kC * l.taps * sizeof(float), hipMemcpyHostToDevice));
+  out->bias = l.b[0];
+  return SN_OK;
+}
+
+// ---- convolution launcher ------------------------------------------------------------------------
+template <int KS, int STRIDE, int CH, int TR, int TC, class Loader>
+hipError_t launch_conv(hipStream_t st, const ConvLayer& L, const Loader& ld, int nimg, int Ho, int Wo,
+                       int dil, float* out, const float* res, bool lrelu) {
+  ConvArgs a;
+  a.wpk = L.wpk;
+  a.bias = L.bias;
+  a.out = out;
+  a.res = res;
+  a.nimg = nimg;
+  a.cin_pad = L.cin_pad;
+  a.Ho = Ho;
+  a.Wo = Wo;
+  a.dil = dil;
+  a.pad = (KS / 2) * dil;
+  a.lrelu = lrelu ? 1 : 0;
+  a.tiles_x = (Wo + TC - 1) / TC;
+  a.tiles_y = (Ho + TR - 1) / TR;
+  const int rows_in = (TR - 1) * STRIDE + (KS - 1) * dil + 1;
+  const int cols_in = (TC - 1) * STRIDE + (KS - 1) * dil + 1;
+  const int pitch = STRIDE == 1 ? cols_in : 2 * ((cols_in + 1) / 2);
+  const size_t lds = ((size_t)CH * KS * KS * 32 + (size_t)CH * rows_in * pitch) * sizeof(float);
+  auto kern = k_conv_c32_mfma<KS, STRIDE, CH, TR, TC, Loader>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  const int nwg = a.tiles_x * a.tiles_y * nimg;
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, st, a, ld);
+  return hipGetLastError();
+}
+
+// 3x3 C->C conv on a plain NCHW fp32 tensor; tile shape chosen from image size and dilation
+hipError_t conv3x3(hipStream_t st, const ConvLayer& L, const float* in, int nimg, int H, int W, int dil,
+                   float* out, const float* res, bool lrelu) {
+  LoadF32 ld{in, kC, H, W};
+  if (H * W <= 64 * 128) return launch_conv<3, 1, 8, 4, 32>(st, L, ld, nimg, H, W, dil, out, res, lrelu);
+  if (dil >= 4) return launch_conv<3, 1, 4, 16, 64>(st, L, ld, nimg, H, W, dil, out, res, lrelu);
+  return launch_conv<3, 1, 8, 8, 64>(st, L, ld, nimg, H, W, dil, out, res, lrelu);
+}
+
+hipError_t conv5x5s2(hipStream_t st, const ConvLayer& L, const float* in, int nimg, int Hin, int Win,
+                     float* out) {
+  LoadF32 ld{in, kC, Hin, Win};
+  const int Ho = Hin / 2, Wo = Win / 2;
+  if (Ho * Wo <= 64 * 128) return launch_conv<5, 2, 4, 4, 32>(st, L, ld, nimg, Ho, Wo, 1, out, nullptr, false);
+  return launch_conv<5, 2, 4, 8, 64>(st, L, ld, nimg, Ho, Wo, 1, out, nullptr, false);
+}
+
+// ---- workspace -----------------------------------------------------------------------------------
+int alloc_ws(sn_handle* h, Workspace* ws, int nb, int rb) {
+  ws->nb = nb;
+  ws->rb = rb;
+  const size_t HW = (size_t)h->H * h->W, HWp = (size_t)h->Hp * h->Wp, hw = (size_t)h->hl * h->wl;
+  HIP_TRY(h, dalloc(&ws->in6, (size_t)nb * 6 * HW));
+  for (int k = 0; k < 3; ++k)
+    HIP_TRY(h, dalloc(&ws->down[k], (size_t)2 * nb * kC * (HWp >> (2 * (k + 1)))));
+  for (int k = 0; k < 3; ++k) HIP_TRY(h, dalloc(&ws->low[k], (size_t)2 * nb * kC * hw));
+  HIP_TRY(h, dalloc(&ws->feat, (size_t)2 * nb * kC * hw));
+  for (int k = 0; k < 2; ++k) HIP_TRY(h, dalloc(&ws->vol[k], (size_t)nb * h->Dl * kC * hw));
+  HIP_TRY(h, dalloc(&ws->cost, (size_t)nb * h->Dl * hw));
+  HIP_TRY(h, dalloc(&ws->disp_low, (size_t)nb * hw));
+  for (int k = 0; k < 2; ++k) HIP_TRY(h, dalloc(&ws->ref[k], (size_t)rb * kC * HWp));
+  HIP_TRY(h, dalloc(&ws->out_disp, (size_t)nb * HW));
+  HIP_TRY(h, dalloc(&ws->out_raw, (size_t)nb * HW));
+  HIP_TRY(h, dalloc(&ws->nv12, (size_t)HW * 3));
+  return SN_OK;
+}
+
+void free_ws(Workspace* ws) {
+  hipFree(ws->in6);
+  for (auto p : ws->down) hipFree(p);
+  for (auto p : ws->low) hipFree(p);
+  hipFree(ws->feat);
+  for (auto p : ws->vol) hipFree(p);
+  hipFree(ws->cost);
+  hipFree(ws->disp_low);
+  for (auto p : ws->ref) hipFree(p);
+  hipFree(ws->out_disp);
+  hipFree(ws->out_raw);
+  hipFree(ws->nv12);
+  *ws = Workspace();
+}
+
+// ---- the forward pass on device buffers ------------------------------------------------------------
+// in6: device int8 [n][6][H][W]; out_disp / out_raw: device, nullable.
+int forward(sn_handle* h, Workspace& ws, hipStream_t st, int n, const int8_t* in6, float* out_disp,
+            int32_t* out_raw, bool want_cost) {
+  const int Hp = h->Hp, Wp = h->Wp, hl = h->hl, wl = h->wl, Dl = h->Dl;
+  const bool prof = h->profiling && (&ws == &h->ws);
+  if (prof) HIP_TRY(h, hipEventRecord(h->ev[0], st));
+
+  // --- Siamese feature tower: images = 2n (left, right interleaved), shared weights ---
+  {
+    LoadI8Eye ld{in6, h->H, h->W};
+    const int Ho = Hp / 2, Wo = Wp / 2;
+    if (Ho * Wo <= 64 * 128)
+      HIP_TRY(h, (launch_conv<5, 2, 4, 4, 32>(st, h->down[0], ld, 2 * n, Ho, Wo, 1, ws.down[0], nullptr, false)));
+    else
+      HIP_TRY(h, (launch_conv<5, 2, 4, 8, 64>(st, h->down[0], ld, 2 * n, Ho, Wo, 1, ws.down[0], nullptr, false)));
+  }
+  HIP_TRY(h, conv5x5s2(st, h->down[1], ws.down[0], 2 * n, Hp / 2, Wp / 2, ws.down[1]));
+  HIP_TRY(h, conv5x5s2(st, h->down[2], ws.down[1], 2 * n, Hp / 4, Wp / 4, ws.down[2]));
+  HIP_TRY(h, conv5x5s2(st, h->down[3], ws.down[2], 2 * n, Hp / 8, Wp / 8, ws.low[0]));
+  float* x = ws.low[0];
+  float* t = ws.low[1];
+  for (int i = 0; i < kNFeatRes; ++i) {
+    HIP_TRY(h, conv3x3(st, h->fres[i][0], x, 2 * n, hl, wl, 1, t, nullptr, true));
+    HIP_TRY(h, conv3x3(st, h->fres[i][1], t, 2 * n, hl, wl, 1, x, x, true));   // in-place residual
+  }
+  HIP_TRY(h, conv3x3(st, h->fout, x, 2 * n, hl, wl, 1, ws.feat, nullptr, false));
+  if (prof) HIP_TRY(h, hipEventRecord(h->ev[1], st));
+
+  // --- cost volume (fused into the first 3-D conv's loader) + 3-D aggregation + soft-argmin ---
+  {
+    LoadCostVol ld{ws.feat, Dl, hl, wl};
+    HIP_TRY(h, (launch_conv<3, 1, 8, 4, 32>(st, h->agg[0], ld, n * Dl, hl, wl, 1, ws.vol[0], nullptr, true)));
+    for (int i = 1; i < kNAgg; ++i) {
+      LoadVol3D lv{ws.vol[(i - 1) & 1], Dl, hl, wl};
+      HIP_TRY(h, (launch_conv<3, 1, 8, 4, 32>(st, h->agg[i], lv, n * Dl, hl, wl, 1, ws.vol[i & 1], nullptr, true)));
+    }
+    const float* v = ws.vol[(kNAgg - 1) & 1];
+    const int npix = n * hl * wl;
+    hipLaunchKernelGGL(k_head_softargmin<16>, dim3((npix + 63) / 64), dim3(256), 0, st, v, h->aout.w,
+                       h->aout.bias, Dl, hl, wl, npix, ws.disp_low, want_cost ? ws.cost : nullptr);
+    HIP_TRY(h, hipGetLastError());
+  }
+  if (prof) HIP_TRY(h, hipEventRecord(h->ev[2], st));
+
+  // --- refinement, `rb` pairs at a time so the two full-resolution activation buffers stay small ---
+  const float inv_q = (float)(1.0 / ((double)h->D * (double)kOutScale));
+  h->dom_launches = 0;
+  for (int p0 = 0; p0 < n; p0 += ws.rb) {
+    const int m = (n - p0) < ws.rb ? (n - p0) : ws.rb;
+    const size_t HW = (size_t)h->H * h->W;
+    LoadRefineIn ld{ws.disp_low + (size_t)p0 * hl * wl, in6 + (size_t)p0 * 6 * HW, hl, wl, h->H, h->W, Hp, Wp,
+                    1.0f / (float)h->D};
+    float* rx = ws.ref[0];
+    float* rt = ws.ref[1];
+    if (Hp * Wp <= 64 * 128)
+      HIP_TRY(h, (launch_conv<3, 1, 4, 4, 32>(st, h->rin, ld, m, Hp, Wp, 1, rx, nullptr, true)));
+    else
+      HIP_TRY(h, (launch_conv<3, 1, 4, 8, 64>(st, h->rin, ld, m, Hp, Wp, 1, rx, nullptr, true)));
+    if (prof && p0 == 0) HIP_TRY(h, hipEventRecord(h->ev[4], st));
+    for (int i = 0; i < kNRefRes; ++i) {
+      HIP_TRY(h, conv3x3(st, h->rres[i][0], rx, m, Hp, Wp, kRefDil[i], rt, nullptr, true));
+      HIP_TRY(h, conv3x3(st, h->rres[i][1], rt, m, Hp, Wp, kRefDil[i], rx, rx, true));
+      h->dom_launches += 2;
+    }
+    if (prof && p0 == 0) HIP_TRY(h, hipEventRecord(h->ev[5], st));
+    dim3 grid((h->W + 63) / 64, (h->H + 3) / 4, m);
+    hipLaunchKernelGGL(k_head_final, grid, dim3(256), 0, st, rx, h->rout.w, h->rout.bias,
+                       ws.disp_low + (size_t)p0 * hl * wl, hl, wl, Hp, Wp, h->H, h->W, (float)h->D, inv_q,
+                       out_disp ? out_disp + (size_t)p0 * HW : nullptr,
+                       out_raw ? out_raw + (size_t)p0 * HW : nullptr);
+    HIP_TRY(h, hipGetLastError());
+  }
+  if (prof) HIP_TRY(h, hipEventRecord(h->ev[3], st));
+  return SN_OK;
+}
+
+int collect_profile(sn_handle* h) {
+  if (!h->profiling) return SN_OK;
+  HIP_TRY(h, hipEventSynchronize(h->ev[3]));
+  float ms = 0.f;
+  HIP_TRY(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+  h->stage_ms[SN_STAGE_FEATURES] = ms;
+  HIP_TRY(h, hipEventElapsedTime(&ms, h->ev[1], h->ev[2]));
+  h->stage_ms[SN_STAGE_AGGREGATE] = ms;
+  HIP_TRY(h, hipEventElapsedTime(&ms, h->ev[2], h->ev[3]));
+  h->stage_ms[SN_STAGE_REFINE] = ms;
+  HIP_TRY(h, hipEventElapsedTime(&ms, h->ev[4], h->ev[5]));
+  h->stage_ms[SN_STAGE_REFINE_CONV] = ms;    // first refinement chunk only
+  HIP_TRY(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[3]));
+  h->stage_ms[SN_STAGE_TOTAL] = ms;
+  return SN_OK;
+}
+
+int check_device(sn_handle* h) {
+  HIP_TRY(h, hipSetDevice(h->device));
+  return SN_OK;
+}
+
+}  // namespace
+
+// =====================================================================================================
+// C ABI
+// =====================================================================================================
+extern "C" {
+
+const char* sn_strerror(int code) {
+  switch (code) {
+    case SN_OK: return "ok";
+    case SN_ERR_ARG: return "invalid argument";
+    case SN_ERR_FILE: return "model file missing or unreadable";
+    case SN_ERR_FORMAT: return "model file is not an SN-K4 SNW1 weight file";
+    case SN_ERR_DEVICE: return "HIP device error (a gfx950 GPU is required; there is no CPU path)";
+    case SN_ERR_NOMEM: return "out of memory";
+    case SN_ERR_BUSY: return "no free task slot";
+    case SN_ERR_TICKET: return "unknown ticket";
+    default: return "unknown error";
+  }
+}
+
+const char* sn_last_error(const sn_handle* h) { return h ? h->err.c_str() : ""; }
+
+int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
+  if (!model_file || !out) return SN_ERR_ARG;
+  *out = nullptr;
+  FILE* f = fopen(model_file, "rb");
+  if (!f) return SN_ERR_FILE;
+  SnwHeader hd;
+  if (fread(&hd, 1, sizeof hd, f) != sizeof hd || memcmp(hd.magic, "SNW1", 4) != 0) {
+    fclose(f);
+    return SN_ERR_FORMAT;
+  }
+  const uint32_t dil_ok[6] = {1, 2, 4, 8, 1, 1};
+  if (hd.version != 1 || hd.channels != kC || hd.n_down != kNDown || hd.n_fres != kNFeatRes ||
+      hd.n_agg != kNAgg || hd.n_rres != kNRefRes || memcmp(hd.dil, dil_ok, sizeof dil_ok) != 0 ||
+      hd.n_params != param_count()) {
+    fclose(f);
+    return SN_ERR_FORMAT;
+  }
+  std::vector<float> blob(hd.n_params);
+  const size_t got = fread(blob.data(), sizeof(float), blob.size(), f);
+  fclose(f);
+  if (got != blob.size()) return SN_ERR_FORMAT;
+
+  sn_config c{};
+  if (cfg) c = *cfg; else c.device = -1;
+  const int W = c.width > 0 ? c.width : (int)hd.width;
+  const int H = c.height > 0 ? c.height : (int)hd.height;
+  const int D = c.dmax > 0 ? c.dmax : (int)hd.dmax;
+  if (W <= 0 || H <= 0 || (W & 3) || (H & 1) || D < 16 || D % 16 || D > 256) return SN_ERR_ARG;
+  if (c.precision != SN_PREC_FP32) return SN_ERR_ARG;   // other precisions: not built yet
+
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SN_ERR_DEVICE;
+  int dev = c.device;
+  if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return SN_ERR_DEVICE;
+  if (dev >= ndev) return SN_ERR_ARG;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return SN_ERR_DEVICE;
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    fprintf(stderr, "stereonet_hip: device %d is %s, this library is built for gfx950 only\n", dev,
+            prop.gcnArchName);
+    return SN_ERR_DEVICE;
+  }
+
+  sn_handle* h = new sn_handle();
+  h->device = dev;
+  h->W = W;
+  h->H = H;
+  h->D = D;
+  h->Wp = (W + 15) / 16 * 16;
+  h->Hp = (H + 15) / 16 * 16;
+  h->wl = h->Wp / 16;
+  h->hl = h->Hp / 16;
+  h->Dl = D / 16;
+  h->max_batch = c.max_batch > 0 ? c.max_batch : 1;
+  h->precision = c.precision;
+  h->task_num = c.task_num > 0 ? c.task_num : 4;
+  h->refine_chunk = c.refine_chunk > 0 ? c.refine_chunk : 1;
+  if (h->refine_chunk > h->max_batch) h->refine_chunk = h->max_batch;
+
+  int rc = check_device(h);
+  auto fail = [&](int code) {
+    sn_destroy(h);
+    return code;
+  };
+  if (rc) return fail(rc);
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(SN_ERR_DEVICE);
+  for (auto& e : h->ev)
+    if (hipEventCreate(&e) != hipSuccess) return fail(SN_ERR_DEVICE);
+
+  BlobWalker bw{blob.data()};
+  for (int i = 0; i < kNDown; ++i)
+    if ((rc = upload_conv2d(h, bw.next(kC, i == 0 ? 3 : kC, 25), 4, &h->down[i]))) return fail(rc);
+  for (int i = 0; i < kNFeatRes; ++i)
+    for (int j = 0; j < 2; ++j)
+      if ((rc = upload_conv2d(h, bw.next(kC, kC, 9), 8, &h->fres[i][j]))) return fail(rc);
+  if ((rc = upload_conv2d(h, bw.next(kC, kC, 9), 8, &h->fout))) return fail(rc);
+  for (int i = 0; i < kNAgg; ++i)
+    if ((rc = upload_conv3d(h, bw.next(kC, kC, 27), &h->agg[i]))) return fail(rc);
+  if ((rc = upload_head(h, bw.next(1, kC, 27), &h->aout))) return fail(rc);
+  if ((rc = upload_conv2d(h, bw.next(kC, 4, 9), 4, &h->rin))) return fail(rc);
+  for (int i = 0; i < kNRefRes; ++i)
+    for (int j = 0; j < 2; ++j)
+      if ((rc = upload_conv2d(h, bw.next(kC, kC, 9), 8, &h->rres[i][j]))) return fail(rc);
+  if ((rc = upload_head(h, bw.next(1, kC, 9), &h->rout))) return fail(rc);
+  if (bw.off != blob.size()) return fail(SN_ERR_FORMAT);
+
+  if ((rc = alloc_ws(h, &h->ws, h->max_batch, h->refine_chunk))) return fail(rc == SN_ERR_DEVICE ? SN_ERR_NOMEM : rc);
+  *out = h;
+  return SN_OK;
+}
+
+int sn_destroy(sn_handle* h) {
+  if (!h) return SN_ERR_ARG;
+  hipSetDevice(h->device);
+  hipDeviceSynchronize();
+  auto free_conv = [](ConvLayer& l) {
+    hipFree(l.wpk);
+    hipFree(l.bias);
+  };
+  for (auto& l : h->down) free_conv(l);
+  for (auto& b : h->fres)
+    for (auto& l : b) free_conv(l);
+  free_conv(h->fout);
+  for (auto& l : h->agg) free_conv(l);
+  free_conv(h->rin);
+  for (auto& b : h->rres)
+    for (auto& l : b) free_conv(l);
+  hipFree(h->aout.w);
+  hipFree(h->rout.w);
+  free_ws(&h->ws);
+  for (auto& s : h->slots) {
+    free_ws(&s.ws);
+    if (s.pin_in) hipHostFree(s.pin_in);
+    if (s.pin_raw) hipHostFree(s.pin_raw);
+    if (s.pin_disp) hipHostFree(s.pin_disp);
+    if (s.ev0) hipEventDestroy(s.ev0);
+    if (s.ev1) hipEventDestroy(s.ev1);
+    if (s.stream) hipStreamDestroy(s.stream);
+  }
+  for (auto& e : h->ev)
+    if (e) hipEventDestroy(e);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+  return SN_OK;
+}
+
+int sn_get_io_info(const sn_handle* h, sn_io_info* info) {
+  if (!h || !info) return SN_ERR_ARG;
+  memset(info, 0, sizeof *info);
+  info->width = h->W;
+  info->height = h->H;
+  info->dmax = h->D;
+  info->in_channels = 6;
+  info->max_batch = h->max_batch;
+  info->precision = h->precision;
+  info->task_num = h->task_num;
+  info->device = h->device;
+  info->out_scale = kOutScale;
+  info->in_bytes = (size_t)6 * h->H * h->W;
+  info->out_bytes = (size_t)4 * h->H * h->W;
+  double mac = 0;
+  const double wp = h->Wp, hp = h->Hp, wl = h->wl, hl = h->hl, dl = h->Dl;
+  for (int k = 1; k <= kNDown; ++k) mac += 2.0 * (wp * hp / (double)(1 << (2 * k))) * kC * (k == 1 ? 3 : kC) * 25;
+  mac += 2.0 * (2 * kNFeatRes + 1) * wl * hl * kC * kC * 9;
+  mac += kNAgg * dl * hl * wl * kC * kC * 27 + dl * hl * wl * kC * 27;
+  mac += wp * hp * (4.0 * kC * 9 + 2.0 * kNRefRes * kC * kC * 9 + kC * 9);
+  info->flops_per_pair = 2.0 * mac;
+  return SN_OK;
+}
+
+int sn_infer_batch(sn_handle* h, int n, const int8_t* in, int32_t* out_i32, float* out_disp, int mem,
+                   void* stream) {
+  if (!h) return SN_ERR_ARG;
+  if (!in || (!out_i32 && !out_disp) || n <= 0 || n > h->max_batch || (mem != SN_MEM_HOST && mem != SN_MEM_DEVICE)) {
+    set_err(h, "sn_infer_batch: bad arguments");
+    return SN_ERR_ARG;
+  }
+  int rc = check_device(h);
+  if (rc) return rc;
+  hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+  const size_t HW = (size_t)h->H * h->W;
+  const int8_t* din = in;
+  int32_t* draw = out_i32;
+  float* ddisp = out_disp;
+  if (mem == SN_MEM_HOST) {
+    HIP_TRY(h, hipMemcpyAsync(h->ws.in6, in, (size_t)n * 6 * HW, hipMemcpyHostToDevice, st));
+    din = h->ws.in6;
+    draw = out_i32 ? h->ws.out_raw : nullptr;
+    ddisp = out_disp ? h->ws.out_disp : nullptr;
+  }
+  if ((rc = forward(h, h->ws, st, n, din, ddisp, draw, n == 1))) return rc;
+  if (mem == SN_MEM_HOST) {
+    if (out_i32) HIP_TRY(h, hipMemcpyAsync(out_i32, draw, (size_t)n * HW * 4, hipMemcpyDeviceToHost, st));
+    if (out_disp) HIP_TRY(h, hipMemcpyAsync(out_disp, ddisp, (size_t)n * HW * 4, hipMemcpyDeviceToHost, st));
+  }
+  if (mem == SN_MEM_HOST || !stream) {
+    HIP_TRY(h, hipStreamSynchronize(st));
+    if ((rc = collect_profile(h))) return rc;
+  }
+  return SN_OK;
+}
+
+int sn_infer_i8(sn_handle* h, const int8_t* in, int32_t* out_i32, float* out_disp, int mem, void* stream) {
+  return sn_infer_batch(h, 1, in, out_i32, out_disp, mem, stream);
+}
+
+static int pre_args_ok(sn_handle* h, int w, int hp) { return w == h->W && hp == h->H; }
+
+int sn_preprocess_nv12(sn_handle* h, const uint8_t* left, const uint8_t* right, int w, int h_px,
+                       int8_t* out6, int mem, void* stream) {
+  if (!h) return SN_ERR_ARG;
+  if (!left || !right || !out6 || w <= 0 || h_px <= 0 || (w & 3) || (h_px & 1) ||
+      (size_t)w * h_px > (size_t)h->W * h->H || (mem != SN_MEM_HOST && mem != SN_MEM_DEVICE)) {
+    set_err(h, "sn_preprocess_nv12: bad arguments");
+    return SN_ERR_ARG;
+  }
+  int rc = check_device(h);
+  if (rc) return rc;
+  hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+  const size_t eye = (size_t)w * h_px * 3 / 2;
+  const uint8_t *dl = left, *dr = right;
+  int8_t* dout = out6;
+  if (mem == SN_MEM_HOST) {
+    HIP_TRY(h, hipMemcpyAsync(h->ws.nv12, left, eye, hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(h->ws.nv12 + eye, right, eye, hipMemcpyHostToDevice, st));
+    dl = h->ws.nv12;
+    dr = h->ws.nv12 + eye;
+    dout = h->ws.in6;
+  } else if (((uintptr_t)left | (uintptr_t)right | (uintptr_t)out6) & 3) {
+    return SN_ERR_ARG;
+  }
+  const long total = 6L * h_px * (w >> 2);
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(k_pre_nv12, dim3(blocks), dim3(256), 0, st, dl, dr, w, w, h_px, dout);
+  HIP_TRY(h, hipGetLastError());
+  if (mem == SN_MEM_HOST)
+    HIP_TRY(h, hipMemcpyAsync(out6, dout, (size_t)6 * w * h_px, hipMemcpyDeviceToHost, st));
+  if (mem == SN_MEM_HOST || !stream) HIP_TRY(h, hipStreamSynchronize(st));
+  return SN_OK;
+}
+
+int sn_infer_sbs_nv12(sn_handle* h, const uint8_t* sbs, int w2, int h_px, int32_t* out_i32, float* out_disp,
+                      int8_t* out_tensor, int mem, void* stream) {
+  if (!h) return SN_ERR_ARG;
+  // geometry check of FeedImg (stereonet_node.cpp:682-690): height == model h, width == 2 * model w
+  if (!sbs || (!out_i32 && !out_disp) || !pre_args_ok(h, w2 / 2, h_px) || (w2 & 1) ||
+      (mem != SN_MEM_HOST && mem != SN_MEM_DEVICE)) {
+    set_err(h, "sn_infer_sbs_nv12: image size does not match the model input");
+    return SN_ERR_ARG;
+  }
+  int rc = check_device(h);
+  if (rc) return rc;
+  hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+  const int w = w2 / 2;
+  const size_t HW = (size_t)h->H * h->W;
+  const uint8_t* dsrc = sbs;
+  if (mem == SN_MEM_HOST) {
+    HIP_TRY(h, hipMemcpyAsync(h->ws.nv12, sbs, HW * 3, hipMemcpyHostToDevice, st));
+    dsrc = h->ws.nv12;
+  } else if ((uintptr_t)sbs & 3) {
+    return SN_ERR_ARG;
+  }
+  int8_t* din = (mem == SN_MEM_DEVICE && out_tensor) ? out_tensor : h->ws.in6;
+  const long total = 6L * h_px * (w >> 2);
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(k_pre_nv12, dim3(blocks), dim3(256), 0, st, dsrc, dsrc + w, w2, w, h_px, din);
+  HIP_TRY(h, hipGetLastError());
+  int32_t* draw = out_i32;
+  float* ddisp = out_disp;
+  if (mem == SN_MEM_HOST) {
+    draw = out_i32 ? h->ws.out_raw : nullptr;
+    ddisp = out_disp ? h->ws.out_disp : nullptr;
+  }
+  if ((rc = forward(h, h->ws, st, 1, din, ddisp, draw, true))) return rc;
+  if (mem == SN_MEM_HOST) {
+    if (out_i32) HIP_TRY(h, hipMemcpyAsync(out_i32, draw, HW * 4, hipMemcpyDeviceToHost, st));
+    if (out_disp) HIP_TRY(h, hipMemcpyAsync(out_disp, ddisp, HW * 4, hipMemcpyDeviceToHost, st));
+    if (out_tensor) HIP_TRY(h, hipMemcpyAsync(out_tensor, din, HW * 6, hipMemcpyDeviceToHost, st));
+  }
+  if (mem == SN_MEM_HOST || !stream) {
+    HIP_TRY(h, hipStreamSynchronize(st));
+    if ((rc = collect_profile(h))) return rc;
+  }
+  return SN_OK;
+}
+
+// ---- async task slots (DnnNode::Run with is_sync_mode = false) ---------------------------------------
+static int ensure_slots(sn_handle* h) {
+  if (!h->slots.empty()) return SN_OK;
+  const size_t HW = (size_t)h->H * h->W;
+  h->slots.resize(h->task_num);
+  for (auto& s : h->slots) {
+    HIP_TRY(h, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    HIP_TRY(h, hipEventCreate(&s.ev0));
+    HIP_TRY(h, hipEventCreate(&s.ev1));
+    int rc = alloc_ws(h, &s.ws, 1, 1);
+    if (rc) return rc;
+    HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&s.pin_in), 6 * HW, hipHostMallocDefault));
+    HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&s.pin_raw), 4 * HW, hipHostMallocDefault));
+    HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&s.pin_disp), 4 * HW, hipHostMallocDefault));
+  }
+  return SN_OK;
+}
+
+int sn_submit(sn_handle* h, const int8_t* in, int32_t* out_i32, float* out_disp, int timeout_ms,
+              uint64_t* ticket) {
+  if (!h || !in || (!out_i32 && !out_disp) || !ticket) return SN_ERR_ARG;
+  std::unique_lock<std::mutex> lk(h->mu);
+  int rc = check_device(h);
+  if (rc) return rc;
+  if ((rc = ensure_slots(h))) return rc;
+  Slot* s = nullptr;
+  auto find_free = [&]() {
+    for (auto& c : h->slots)
+      if (c.ticket == 0) {
+        s = &c;
+        return true;
+      }
+    return false;
+  };
+  if (timeout_ms < 0) {
+    h->cv.wait(lk, find_free);
+  } else if (!h->cv.wait_for(lk, std::chrono::milliseconds(timeout_ms), find_free)) {
+    return SN_ERR_BUSY;
+  }
+  const size_t HW = (size_t)h->H * h->W;
+  s->ticket = h->next_ticket++;
+  s->user_raw = out_i32;
+  s->user_disp = out_disp;
+  *ticket = s->ticket;
+  memcpy(s->pin_in, in, 6 * HW);   // the caller may release its tensor as soon as we return
+  HIP_TRY(h, hipEventRecord(s->ev0, s->stream));
+  HIP_TRY(h, hipMemcpyAsync(s->ws.in6, s->pin_in, 6 * HW, hipMemcpyHostToDevice, s->stream));
+  const bool prof = h->profiling;
+  h->profiling = false;   // stage events belong to the synchronous path
+  rc = forward(h, s->ws, s->stream, 1, s->ws.in6, out_disp ? s->ws.out_disp : nullptr,
+               out_i32 ? s->ws.out_raw : nullptr, false);
+  h->profiling = prof;
+  if (rc) {
+    s->ticket = 0;
+    return rc;
+  }
+  if (out_i32) HIP_TRY(h, hipMemcpyAsync(s->pin_raw, s->ws.out_raw, 4 * HW, hipMemcpyDeviceToHost, s->stream));
+  if (out_disp) HIP_TRY(h, hipMemcpyAsync(s->pin_disp, s->ws.out_disp, 4 * HW, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(h, hipEventRecord(s->ev1, s->stream));
+  return SN_OK;
+}
+
+int sn_wait(sn_handle* h, uint64_t ticket, float* infer_ms) {
+  if (!h || ticket == 0) return SN_ERR_ARG;
+  Slot* s = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(h->mu);
+    for (auto& c : h->slots)
+      if (c.ticket == ticket) s = &c;
+  }
+  if (!s) return SN_ERR_TICKET;
+  hipSetDevice(h->device);
+  HIP_TRY(h, hipEventSynchronize(s->ev1));
+  const size_t HW = (size_t)h->H * h->W;
+  if (s->user_raw) memcpy(s->user_raw, s->pin_raw, 4 * HW);
+  if (s->user_disp) memcpy(s->user_disp, s->pin_disp, 4 * HW);
+  if (infer_ms) {
+    float ms = 0.f;
+    HIP_TRY(h, hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    *infer_ms = ms;
+  }
+  {
+    std::lock_guard<std::mutex> lk(h->mu);
+    s->ticket = 0;
+  }
+  h->cv.notify_one();
+  return SN_OK;
+}
+
+int sn_synchronize(sn_handle* h) {
+  if (!h) return SN_ERR_ARG;
+  int rc = check_device(h);
+  if (rc) return rc;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  for (auto& s : h->slots) HIP_TRY(h, hipStreamSynchronize(s.stream));
+  return SN_OK;
+}
+
+// ---- measurement hooks ---------------------------------------------------------------------------------
+int sn_set_profiling(sn_handle* h, int enable) {
+  if (!h) return SN_ERR_ARG;
+  h->profiling = enable != 0;
+  return SN_OK;
+}
+
+int sn_get_stage_ms(sn_handle* h, float* ms, int count) {
+  if (!h || !ms || count <= 0) return SN_ERR_ARG;
+  for (int i = 0; i < count && i < SN_STAGE_COUNT; ++i) ms[i] = h->stage_ms[i];
+  return SN_OK;
+}
+
+int sn_get_dominant_kernel(sn_handle* h, char* name, size_t cap, int* launches, double* flops, double* bytes) {
+  if (!h) return SN_ERR_ARG;
+  if (name && cap) snprintf(name, cap, "k_conv_c32_mfma<3,1,*> (refinement 3x3 C->C, fp32 MFMA)");
+  const double px = (double)h->Hp * h->Wp * h->ws.rb;
+  if (launches) *launches = 2 * kNRefRes;   // per refinement chunk
+  if (flops) *flops = 2.0 * px * kC * kC * 9;
+  // algorithmic HBM bytes per launch: read the C-channel fp32 input once, write the output once
+  // (the in-place residual read of the second conv of a block hits the same lines it writes)
+  if (bytes) *bytes = px * kC * 4.0 * 2.0;
+  return SN_OK;
+}
+
+// ---- parity hooks ----------------------------------------------------------------------------------------
+int sn_dbg_conv2d(sn_handle* h, const float* in, int cin, int h_px, int w, const float* wt, const float* bias,
+                  int k, int stride, int dil, int lrelu, const float* residual, float* out) {
+  if (!h || !in || !wt || !bias || !out || cin <= 0 || cin > kC) return SN_ERR_ARG;
+  if (!((k == 3 && stride == 1) || (k == 5 && stride == 2 && dil == 1))) return SN_ERR_ARG;
+  int rc = check_device(h);
+  if (rc) return rc;
+  const int taps = k * k;
+  const int Ho = stride == 1 ? h_px : h_px / 2, Wo = stride == 1 ? w : w / 2;
+  if (stride == 2 && ((h_px & 1) || (w & 1))) return SN_ERR_ARG;
+  ConvLayer L;
+  HostLayer hl{wt, bias, kC, cin, taps};
+  if ((rc = upload_conv2d(h, hl, (k == 5 || cin <= 4) ? 4 : 8, &L))) return rc;
+  float *din = nullptr, *dout = nullptr;
+  const size_t nin = (size_t)cin * h_px * w, nout = (size_t)kC * Ho * Wo;
+  HIP_TRY(h, dalloc(&din, nin));
+  HIP_TRY(h, dalloc(&dout, nout));
+  HIP_TRY(h, hipMemcpy(din, in, nin * 4, hipMemcpyHostToDevice));
+  const float* dres = nullptr;
+  if (residual) {   // in-place form, as the pipeline uses it
+    HIP_TRY(h, hipMemcpy(dout, residual, nout * 4, hipMemcpyHostToDevice));
+    dres = dout;
+  }
+  hipStream_t st = h->stream;
+  LoadF32 ld{din, cin, h_px, w};
+  hipError_t e;
+  if (k == 5) {
+    e = (Ho * Wo <= 64 * 128) ? launch_conv<5, 2, 4, 4, 32>(st, L, ld, 1, Ho, Wo, 1, dout, dres, lrelu != 0)
+                              : launch_conv<5, 2, 4, 8, 64>(st, L, ld, 1, Ho, Wo, 1, dout, dres, lrelu != 0);
+  } else if (cin <= 4) {
+    e = (Ho * Wo <= 64 * 128) ? launch_conv<3, 1, 4, 4, 32>(st, L, ld, 1, Ho, Wo, dil, dout, dres, lrelu != 0)
+                              : launch_conv<3, 1, 4, 8, 64>(st, L, ld, 1, Ho, Wo, dil, dout, dres, lrelu != 0);
+  } else {
+    e = conv3x3(st, L, din, 1, h_px, w, dil, dout, dres, lrelu != 0);
+  }
+  HIP_TRY(h, e);
+  HIP_TRY(h, hipStreamSynchronize(st));
+  HIP_TRY(h, hipMemcpy(out, dout, nout * 4, hipMemcpyDeviceToHost));
+  hipFree(din);
+  hipFree(dout);
+  hipFree(L.wpk);
+  hipFree(L.bias);
+  return SN_OK;
+}
+
+int sn_dbg_conv3d(sn_handle* h, const float* in, int d, int h_px, int w, const float* wt, const float* bias,
+                  int lrelu, float* out) {
+  if (!h || !in || !wt || !bias || !out || d <= 0) return SN_ERR_ARG;
+  int rc = check_device(h);
+  if (rc) return rc;
+  ConvLayer L;
+  HostLayer hl{wt, bias, kC, kC, 27};
+  if ((rc = upload_conv3d(h, hl, &L))) return rc;
+  const size_t plane = (size_t)h_px * w, n = (size_t)kC * d * plane;
+  // caller layout [ci][d][h][w] (PyTorch) <-> device layout [d][ci][h][w]
+  std::vector<float> tmp(n);
+  for (int ci = 0; ci < kC; ++ci)
+    for (int z = 0; z < d; ++z)
+      memcpy(&tmp[((size_t)z * kC + ci) * plane], &in[((size_t)ci * d + z) * plane], plane * 4);
+  float *din = nullptr, *dout = nullptr;
+  HIP_TRY(h, dalloc(&din, n));
+  HIP_TRY(h, dalloc(&dout, n));
+  HIP_TRY(h, hipMemcpy(din, tmp.data(), n * 4, hipMemcpyHostToDevice));
+  LoadVol3D lv{din, d, h_px, w};
+  HIP_TRY(h, (launch_conv<3, 1, 8, 4, 32>(h->stream, L, lv, d, h_px, w, 1, dout, nullptr, lrelu != 0)));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, hipMemcpy(tmp.data(), dout, n * 4, hipMemcpyDeviceToHost));
+  for (int co = 0; co < kC; ++co)
+    for (int z = 0; z < d; ++z)
+      memcpy(&out[((size_t)co * d + z) * plane], &tmp[((size_t)z * kC + co) * plane], plane * 4);
+  hipFree(din);
+  hipFree(dout);
+  hipFree(L.wpk);
+  hipFree(L.bias);
+  return SN_OK;
+}
+
+int sn_dbg_read(sn_handle* h, const char* what, float* dst, size_t cap, size_t* n) {
+  if (!h || !what || !n) return SN_ERR_ARG;
+  int rc = check_device(h);
+  if (rc) return rc;
+  const size_t hw = (size_t)h->hl * h->wl;
+  const float* src = nullptr;
+  size_t cnt = 0;
+  if (!strcmp(what, "feat_l")) { src = h->ws.feat; cnt = kC * hw; }
+  else if (!strcmp(what, "feat_r")) { src = h->ws.feat + kC * hw; cnt = kC * hw; }
+  else if (!strcmp(what, "cost")) { src = h->ws.cost; cnt = h->Dl * hw; }
+  else if (!strcmp(what, "disp_low")) { src = h->ws.disp_low; cnt = hw; }
+  else if (!strcmp(what, "refine_x")) { src = h->ws.ref[0]; cnt = (size_t)kC * h->Hp * h->Wp; }
+  else return SN_ERR_ARG;
+  *n = cnt;
+  if (!dst) return SN_OK;
+  if (cap < cnt) return SN_ERR_ARG;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, hipMemcpy(dst, src, cnt * 4, hipMemcpyDeviceToHost));
+  return SN_OK;
+}
+
+}  // extern "C"

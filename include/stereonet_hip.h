@@ -1,0 +1,153 @@
+/*
+ * stereonet_hip.h — C ABI of libstereonet_hip.so, the MI355X (gfx950) replacement
+ * for the Horizon BPU execution behind hobot_stereonet's StereonetNode.
+ *
+ * What this boundary replaces in the reference (paths under /root/reference):
+ *   - hobot::dnn_node::DnnNode::Init()  -> model load     stereonet_infer/src/stereonet_node.cpp:44
+ *   - DnnNode::GetModelInputSize / Model::Get*TensorProperties
+ *                                                          stereonet_node.cpp:45,57-103
+ *   - DnnNode::Run(inputs, output, is_sync, -1, -1)        stereonet_node.cpp:812 (async),
+ *                                                          :177,:584,:968 (sync)
+ *   - PreProcess::CvtNV12Data2Tensors (optional fused)     stereonet_infer/src/preprocess.cpp:913-1059
+ *   - the NV12 side-by-side split in FeedImg (optional)    stereonet_node.cpp:705-738
+ * The reference reaches all of these through the closed `dnn_node`/`libdnn`
+ * (hbDNN*, hbSys*) API; hobot_stereonet_amd/csrc/compat/ re-implements exactly
+ * the members the reference touches on top of the functions below (see
+ * INTEGRATION.md for the binding a maintainer adds).
+ *
+ * Conventions: plain C types only; every function returns int, 0 = ok, <0 =
+ * error (the reference's -1 convention, stereonet_infer/include/parser.h:37-39);
+ * no exceptions cross the boundary.  Buffers are caller-owned.  `mem` says
+ * whether data pointers are host (SN_MEM_HOST) or HIP device (SN_MEM_DEVICE)
+ * memory.  `stream` is a hipStream_t passed as void* (NULL = the handle's own
+ * stream, and the call returns after completion; non-NULL with SN_MEM_DEVICE =
+ * work is only enqueued on that stream).  A handle is bound to one GPU; calls on
+ * one handle must not overlap in time except sn_submit/sn_wait, which are
+ * thread-safe (task_num requests in flight, stereonet_node.cpp:144).
+ *
+ * Tensor contract (unchanged from the reference):
+ *   input  int8  NCHW [n][6][H][W]: L-Y, L-"U", L-"V", R-Y, R-"U", R-"V"; value = byte ^ 0x80
+ *          (preprocess.cpp:999-1003,1033-1040)
+ *   output int32 NCHW [n][1][H][W]: raw; disparity_px = raw * out_scale * dmax
+ *          (stereonet_node.cpp:282-288, parser.cpp:84-86, publisher_member_function.py:73-75)
+ *   optional float output [n][H][W]: disparity in px before int32 quantisation.
+ */
+#ifndef STEREONET_HIP_H_
+#define STEREONET_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sn_handle sn_handle;
+
+enum {
+  SN_OK = 0,
+  SN_ERR_ARG = -1,       /* null / out-of-range argument, geometry mismatch          */
+  SN_ERR_FILE = -2,      /* model_file missing or unreadable (stereonet_node.cpp:131) */
+  SN_ERR_FORMAT = -3,    /* not an SNW1 weight file / wrong architecture header       */
+  SN_ERR_DEVICE = -4,    /* HIP runtime error or no gfx950 device                     */
+  SN_ERR_NOMEM = -5,
+  SN_ERR_BUSY = -6,      /* sn_submit: no free task slot within the timeout           */
+  SN_ERR_TICKET = -7     /* sn_wait: unknown or already-consumed ticket               */
+};
+
+enum { SN_MEM_HOST = 0, SN_MEM_DEVICE = 1 };
+
+/* Arithmetic of the convolution contractions.  All variants accumulate in fp32. */
+enum {
+  SN_PREC_FP32 = 0,      /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere                  */
+  SN_PREC_F16X3 = 1,     /* refinement tower on fp16 MFMA with hi/lo operand split (3 MFMAs per   */
+                         /* product, ~2^-22 relative): fp32-class accuracy at the fp16 MFMA rate  */
+  SN_PREC_F16 = 2        /* refinement tower on plain fp16 MFMA operands                          */
+};
+
+typedef struct sn_config {
+  int device;        /* HIP device ordinal, -1 = current device                                 */
+  int max_batch;     /* largest n for sn_infer_batch; <=0 -> 1                                   */
+  int width;         /* 0 = take from the model file header                                      */
+  int height;        /* 0 = take from the model file header                                      */
+  int dmax;          /* max disparity D (multiple of 16, <= 256); 0 = from the model file        */
+  int precision;     /* SN_PREC_*                                                                 */
+  int task_num;      /* async slots for sn_submit; <=0 -> 4 (stereonet_node.cpp:144)              */
+  int refine_chunk;  /* pairs refined together (activation residency); <=0 -> auto                */
+} sn_config;
+
+typedef struct sn_io_info {
+  int width, height, dmax;
+  int in_channels;        /* 6 */
+  int max_batch, precision, task_num, device;
+  float out_scale;        /* 2.60443857769133e-6 (stereonet_node.cpp:282) */
+  size_t in_bytes;        /* per pair: 6*H*W  (int8)  */
+  size_t out_bytes;       /* per pair: 4*H*W  (int32) */
+  double flops_per_pair;  /* algorithmic conv FLOPs (2*MAC), DESIGN.md §5 */
+} sn_io_info;
+
+/* DnnNode::Init + Model introspection ------------------------------------------------------- */
+int sn_create(const char *model_file, const sn_config *cfg, sn_handle **out);
+int sn_destroy(sn_handle *h);
+int sn_get_io_info(const sn_handle *h, sn_io_info *info);
+const char *sn_strerror(int code);
+const char *sn_last_error(const sn_handle *h);   /* detail of the last failure on this handle */
+
+/* DnnNode::Run, synchronous form (stereonet_node.cpp:968) ----------------------------------- */
+/* out_i32 and out_disp may each be NULL (but not both). */
+int sn_infer_i8(sn_handle *h, const int8_t *in_nchw6, int32_t *out_i32, float *out_disp,
+                int mem, void *stream);
+int sn_infer_batch(sn_handle *h, int n, const int8_t *in_nchw6, int32_t *out_i32, float *out_disp,
+                   int mem, void *stream);
+
+/* PreProcess::CvtNV12Data2Tensors on the GPU (preprocess.cpp:913-1059), bit-exact, including the
+ * reference's planar-I420 reading of the NV12 chroma (preprocess.h:131-133). */
+int sn_preprocess_nv12(sn_handle *h, const uint8_t *left_nv12, const uint8_t *right_nv12,
+                       int w, int h_px, int8_t *out_nchw6, int mem, void *stream);
+/* FeedImg's split (stereonet_node.cpp:705-738) + CvtNV12Data2Tensors + Run in one call: takes the
+ * raw 2W x H side-by-side NV12 message payload.  out_tensor (nullable) receives the int8 model
+ * input the reference would have built. */
+int sn_infer_sbs_nv12(sn_handle *h, const uint8_t *sbs_nv12, int w2, int h_px, int32_t *out_i32,
+                      float *out_disp, int8_t *out_tensor, int mem, void *stream);
+
+/* DnnNode::Run, asynchronous form (stereonet_node.cpp:812): host buffers only.  sn_submit copies
+ * the input and returns at once with a ticket; up to task_num tickets are in flight;
+ * timeout_ms < 0 waits for a free slot forever (the reference passes -1).  sn_wait blocks until the
+ * ticket's pair is done, fills the host outputs given at submit, and reports the device time. */
+int sn_submit(sn_handle *h, const int8_t *in_nchw6_host, int32_t *out_i32_host, float *out_disp_host,
+              int timeout_ms, uint64_t *ticket);
+int sn_wait(sn_handle *h, uint64_t ticket, float *infer_ms);
+int sn_synchronize(sn_handle *h);
+
+/* Measurement hooks (bench.py): per-stage device time of the most recent sn_infer_batch, taken
+ * with hipEvents on the stream the kernels ran on.  Stage ids: */
+enum {
+  SN_STAGE_FEATURES = 0,   /* Siamese tower, both eyes            */
+  SN_STAGE_AGGREGATE = 1,  /* cost volume + 3-D convs + soft-argmin */
+  SN_STAGE_REFINE = 2,     /* upsample + refinement tower + output epilogue */
+  SN_STAGE_REFINE_CONV = 3,/* the 12 C->C 3x3 convs inside REFINE (dominant kernel) */
+  SN_STAGE_TOTAL = 4,
+  SN_STAGE_COUNT = 5
+};
+int sn_set_profiling(sn_handle *h, int enable);
+int sn_get_stage_ms(sn_handle *h, float *ms, int count);
+/* launches of the dominant kernel in the last call and its algorithmic FLOPs / HBM bytes per launch */
+int sn_get_dominant_kernel(sn_handle *h, char *name, size_t name_cap, int *launches,
+                           double *flops_per_launch, double *bytes_per_launch);
+
+/* Parity hooks (tests only; they run the product kernels on caller data, host memory) -------- */
+/* one C->32 convolution through the MFMA kernel: in [cin][h][w] fp32, wt [32][cin][k][k], out [32][ho][wo] */
+int sn_dbg_conv2d(sn_handle *h, const float *in, int cin, int h_px, int w, const float *wt,
+                  const float *bias, int k, int stride, int dil, int lrelu, const float *residual,
+                  float *out);
+/* one 3x3x3 32->32 conv3d (+bias, optional LeakyReLU): in [32][d][h][w] -> out [32][d][h][w] */
+int sn_dbg_conv3d(sn_handle *h, const float *in, int d, int h_px, int w, const float *wt,
+                  const float *bias, int lrelu, float *out);
+/* intermediates of the most recent batch-1 inference: "feat_l" / "feat_r" [32][hl][wl],
+ * "cost"... see DESIGN.md §6; returns the element count in *n (dst may be NULL to query). */
+int sn_dbg_read(sn_handle *h, const char *what, float *dst, size_t cap, size_t *n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STEREONET_HIP_H_ */

@@ -36,3 +36,20 @@ def golden_net():
 def golden_pre():
     import numpy as np
     return np.load(os.path.join(ROOT, "tests", "golden", "preprocess_golden.npz"))
+
+
+@pytest.fixture(scope="session")
+def model_factory(tmp_path_factory, weights_blob):
+    """-> f(w, h, d) -> path of an SNW1 model file with seed-0 synthetic weights."""
+    from hobot_stereonet_amd import weights
+    made = {}
+
+    def make(w, h, d):
+        key = (w, h, d)
+        if key not in made:
+            p = str(tmp_path_factory.mktemp("models") / f"sn_{w}x{h}_d{d}.snw")
+            weights.save_snw(p, weights_blob, w, h, d)
+            made[key] = p
+        return made[key]
+
+    return make

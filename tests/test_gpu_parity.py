@@ -1,0 +1,200 @@
+"""HIP path vs the CPU oracle, through the C ABI (include/stereonet_hip.h).  Needs an MI355X.
+
+Tolerances: byte/integer work (pre-processing, wire format) is bit-exact; the network is fp32
+arithmetic in a different summation order, bounded by EPE <= 1e-3 px (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+from hobot_stereonet_amd import api, spec, synth
+
+pytestmark = pytest.mark.gpu
+EPE_TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def small_engine(model_factory):
+    eng = api.StereoNetHIP(model_factory(96, 64, 48), max_batch=2)
+    yield eng
+    eng.close()
+
+
+def rel_err(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+# ---- per-kernel parity ------------------------------------------------------------------------
+@pytest.mark.parametrize("h,w,dil", [(45, 80, 1), (64, 96, 1), (33, 70, 2), (72, 200, 4), (130, 300, 8),
+                                     (64, 128, 1), (20, 20, 8), (128, 257, 1), (190, 130, 2)])
+def test_conv3x3_c32(small_engine, oracle, h, w, dil):
+    rng = np.random.default_rng(h * 1000 + w + dil)
+    x = rng.standard_normal((32, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((32, 32, 3, 3)) / 17.0).astype(np.float32)
+    b = rng.standard_normal(32).astype(np.float32)
+    ref = oracle.conv2d(x, wt, b, 1, dil, dil)
+    got = small_engine.dbg_conv2d(x, wt, b, 3, 1, dil)
+    assert rel_err(got, ref) < 2e-5
+    # residual + LeakyReLU epilogue (the in-place res-block form)
+    res = rng.standard_normal((32, h, w)).astype(np.float32)
+    v = ref + res
+    ref2 = np.where(v > 0, v, v * np.float32(0.2))
+    got2 = small_engine.dbg_conv2d(x, wt, b, 3, 1, dil, lrelu=True, residual=res)
+    assert rel_err(got2, ref2) < 2e-5
+
+
+@pytest.mark.parametrize("cin,h,w", [(3, 64, 96), (3, 360, 640), (32, 90, 160), (32, 46, 82), (32, 180, 320)])
+def test_conv5x5_stride2(small_engine, oracle, cin, h, w):
+    rng = np.random.default_rng(cin * 7 + h + w)
+    x = rng.standard_normal((cin, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((32, cin, 5, 5)) / np.sqrt(cin * 25)).astype(np.float32)
+    b = rng.standard_normal(32).astype(np.float32)
+    ref = oracle.conv2d(x, wt, b, 2, 2, 1)
+    got = small_engine.dbg_conv2d(x, wt, b, 5, 2, 1)
+    assert got.shape == ref.shape
+    assert rel_err(got, ref) < 2e-5
+
+
+def test_conv3x3_few_channels(small_engine, oracle):
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((4, 70, 150)).astype(np.float32)
+    wt = rng.standard_normal((32, 4, 3, 3)).astype(np.float32)
+    b = rng.standard_normal(32).astype(np.float32)
+    assert rel_err(small_engine.dbg_conv2d(x, wt, b, 3, 1, 1), oracle.conv2d(x, wt, b, 1, 1, 1)) < 2e-5
+
+
+@pytest.mark.parametrize("d,h,w", [(3, 4, 6), (12, 45, 80), (6, 17, 33)])
+def test_conv3d(small_engine, oracle, d, h, w):
+    rng = np.random.default_rng(d + h + w)
+    x = rng.standard_normal((32, d, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((32, 32, 3, 3, 3)) / 30.0).astype(np.float32)
+    b = rng.standard_normal(32).astype(np.float32)
+    ref = oracle.conv3d(x, wt, b)
+    got = small_engine.dbg_conv3d(x, wt, b)
+    assert rel_err(got, ref) < 2e-5
+
+
+# ---- pre-processing: bit-exact ---------------------------------------------------------------------
+def test_preprocess_nv12_bit_exact(small_engine, oracle, golden_pre):
+    for c in ("rand32x16", "rand64x36", "rand48x20", "ramp8x4"):
+        w, h = map(int, golden_pre[c + ".wh"])
+        left = golden_pre[c + ".nv12"]
+        right = synth.random_nv12(w, h, 17)
+        got = small_engine.preprocess_nv12(left, right, w, h)
+        exp_l = (golden_pre[c + ".yuv444"].reshape(3, h, w) ^ np.uint8(0x80)).view(np.int8)
+        assert (got[:3] == exp_l).all(), c                      # vs the reference's own output
+        assert (got == oracle.preprocess_nv12(left, right, w, h)).all(), c
+
+
+# ---- end to end --------------------------------------------------------------------------------------
+CASES = [("c96x64_d48", 96, 64, 48, 3), ("c160x96_d96", 160, 96, 96, 4), ("c100x52_d32", 100, 52, 32, 5)]
+
+
+@pytest.mark.parametrize("name,w,h,d,seed", CASES)
+def test_forward_small_vs_golden_and_oracle(model_factory, oracle, golden_net, weights_blob, name, w, h, d, seed):
+    x = synth.model_input_i8(w, h, d, seed)
+    with api.StereoNetHIP(model_factory(w, h, d)) as eng:
+        disp, raw = eng.infer(x)
+        low = eng.dbg_read("disp_low").reshape((h + 15) // 16, (w + 15) // 16)
+        cost = eng.dbg_read("cost").reshape(d // 16, (h + 15) // 16, (w + 15) // 16)
+    odisp, oraw, olow = oracle.forward(weights_blob, x, d)
+    assert np.abs(cost - golden_net[name + ".cost"]).max() < 2e-4 * max(1.0, np.abs(golden_net[name + ".cost"]).max())
+    assert np.abs(low - olow).max() < 1e-4
+    assert np.abs(disp - golden_net[name + ".disp"]).mean() < EPE_TOL
+    assert np.abs(disp - odisp).mean() < EPE_TOL
+    assert np.abs(disp - odisp).max() < 20 * EPE_TOL
+    # wire format is the same integer map of the float disparity as the oracle's
+    inv_q = np.float32(1.0 / (float(d) * float(np.float32(spec.OUT_SCALE))))
+    assert (raw == np.rint(disp * inv_q).astype(np.int32)).all()
+    assert raw.min() >= 0
+
+
+def test_features_identical_eyes(model_factory, oracle, weights_blob):
+    # reference fixture config/image_left.jpg == image_right.jpg: equal eyes -> equal feature maps
+    w, h, d = 96, 64, 48
+    x = synth.model_input_i8(w, h, d, 5).copy()
+    x[3:] = x[:3]
+    with api.StereoNetHIP(model_factory(w, h, d)) as eng:
+        eng.infer(x)
+        fl, fr = eng.dbg_read("feat_l"), eng.dbg_read("feat_r")
+    assert (fl == fr).all()
+    planes = x[:3].astype(np.float32) / 128.0
+    assert rel_err(fl.reshape(32, 4, 6), oracle.features(weights_blob, planes)) < 5e-5
+
+
+def test_full_size_epe(model_factory, oracle, weights_blob):
+    """BASELINE.json configs[1]: 1280x720, D=192, one pair, fp32."""
+    w, h, d = 1280, 720, 192
+    x = synth.model_input_i8(w, h, d, 0)
+    with api.StereoNetHIP(model_factory(w, h, d)) as eng:
+        disp, raw = eng.infer(x)
+        disp2, raw2 = eng.infer(x)
+    odisp, oraw, _ = oracle.forward(weights_blob, x, d)
+    epe = float(np.abs(disp - odisp).mean())
+    print(f"EPE vs oracle at 1280x720 D=192: {epe:.3e} px, max {np.abs(disp - odisp).max():.3e}")
+    assert epe < EPE_TOL
+    assert (disp == disp2).all() and (raw == raw2).all()          # deterministic
+    assert np.abs(raw.astype(np.int64) - oraw).max() <= 1 + int(20 * EPE_TOL / (d * spec.OUT_SCALE))
+    # the render node's dequantisation (publisher_member_function.py:65-75) recovers the disparity
+    back = raw.view(np.uint32).astype(np.float64) * spec.OUT_SCALE * 16 * 12
+    assert np.abs(back - disp).max() < 0.51 * d * spec.OUT_SCALE + 1e-5
+
+
+def test_padded_geometry(model_factory, oracle, weights_blob):
+    # sizes that are not multiples of 16 are zero-padded right/bottom and cropped (C1 960x540, C5 1242x375 shapes)
+    w, h, d = 124, 38, 32
+    x = synth.model_input_i8(w, h, d, 9)
+    with api.StereoNetHIP(model_factory(w, h, d)) as eng:
+        disp, _ = eng.infer(x)
+    odisp, _, _ = oracle.forward(weights_blob, x, d)
+    assert disp.shape == (h, w)
+    assert np.abs(disp - odisp).mean() < EPE_TOL
+
+
+def test_batch_equals_single_and_async(small_engine):
+    w, h, d = 96, 64, 48
+    xs = np.stack([synth.model_input_i8(w, h, d, s) for s in (1, 2)])
+    disp_b, raw_b = small_engine.infer(xs)
+    for i in range(2):
+        dsp, rw = small_engine.infer(xs[i])
+        assert (dsp == disp_b[i]).all() and (rw == raw_b[i]).all()     # bit-identical: no cross-pair math
+    # async Run (is_sync_mode=false, stereonet_node.cpp:812): task_num=4 in flight
+    outs = [(np.empty((h, w), np.int32), np.empty((h, w), np.float32)) for _ in range(6)]
+    tickets = []
+    for i in range(6):
+        if len(tickets) == 4:
+            small_engine.wait(tickets.pop(0))
+        tickets.append(small_engine.submit(xs[i % 2], outs[i][0], outs[i][1]))
+    for t in tickets:
+        assert small_engine.wait(t) > 0.0
+    for i in range(6):
+        assert (outs[i][0] == raw_b[i % 2]).all() and (outs[i][1] == disp_b[i % 2]).all()
+    with pytest.raises(api.StereoNetError):
+        small_engine.wait(12345)
+
+
+def test_side_by_side_nv12_path(model_factory, oracle):
+    # FeedImg split + CvtNV12Data2Tensors + Run fused on the device == the reference's three host steps
+    w, h, d = 96, 64, 48
+    sbs = np.random.default_rng(4).integers(0, 256, (h * 3 // 2) * 2 * w, dtype=np.uint8)
+    left, right = oracle.split_sbs_nv12(sbs, w, h)
+    ten_ref = oracle.preprocess_nv12(left, right, w, h)
+    with api.StereoNetHIP(model_factory(w, h, d)) as eng:
+        disp, raw, ten = eng.infer_sbs_nv12(sbs, want_tensor=True)
+        disp2, raw2 = eng.infer(ten_ref)
+    assert (ten == ten_ref).all()
+    assert (disp == disp2).all() and (raw == raw2).all()
+
+
+def test_error_behaviour(model_factory, tmp_path):
+    with pytest.raises(api.StereoNetError) as e:
+        api.StereoNetHIP(str(tmp_path / "missing.snw"))
+    assert e.value.code == -2          # reference: access() check fails -> Init returns -1 (stereonet_node.cpp:131-134)
+    bad = tmp_path / "bad.snw"
+    bad.write_bytes(b"not a model" * 10)
+    with pytest.raises(api.StereoNetError) as e:
+        api.StereoNetHIP(str(bad))
+    assert e.value.code == -3
+    with api.StereoNetHIP(model_factory(96, 64, 48)) as eng:
+        with pytest.raises(api.StereoNetError):
+            eng.infer(np.zeros((6, 32, 32), np.int8))           # geometry mismatch (stereonet_node.cpp:682-690)
+        with pytest.raises(api.StereoNetError):
+            eng.infer(np.zeros((3, 6, 64, 96), np.int8))        # n > max_batch
