@@ -25,6 +25,7 @@ import torch  # noqa: E402
 
 W, H, D = 1280, 720, 192
 MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: exact-fp32 MFMA peak
+MFMA_F16_PEAK_TFLOPS = 2500.0     # dense fp16 MFMA peak
 HBM_PEAK_GBS = 8000.0
 
 
@@ -52,6 +53,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8, help="pairs per GPU per step")
     ap.add_argument("--refine-chunk", type=int, default=1)
+    ap.add_argument("--precision", choices=["fp32", "f16"], default="f16",
+                    help="arithmetic of the refinement-tower contractions (the low-res branch is always fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -76,7 +79,8 @@ def main():
     tmp = tempfile.mkdtemp(prefix=f"snbench{rank}_")
     model = os.path.join(tmp, "bench.snw")
     weights.save_snw(model, blob, W, H, D)
-    eng = api.StereoNetHIP(model, device=local_rank, max_batch=B, refine_chunk=args.refine_chunk)
+    prec = api.PREC_F16 if args.precision == "f16" else api.PREC_FP32
+    eng = api.StereoNetHIP(model, device=local_rank, max_batch=B, refine_chunk=args.refine_chunk, precision=prec)
 
     # synthetic shard for this rank: distinct seeds per pair; a few distinct pairs tiled to B
     uniq = min(B, 4)
@@ -128,12 +132,17 @@ def main():
         eng.set_profiling(False)
         dk = eng.dominant_kernel()
         launch_ms = stage["refine_conv"] / dk["launches"]
-        achieved = dk["flops_per_launch"] / (launch_ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": dk["name"], "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
-                "avg_launch_ms": launch_ms, "launches_per_pair": dk["launches"],
-                "algorithmic_gbytes_per_s": dk["bytes_per_launch"] / (launch_ms * 1e-3) / 1e9,
-                "hbm_peak_gbytes_per_s": HBM_PEAK_GBS}
+        tflops = dk["flops_per_launch"] / (launch_ms * 1e-3) / 1e12
+        gbs = dk["bytes_per_launch"] / (launch_ms * 1e-3) / 1e9
+        if args.precision == "fp32":     # exact-fp32 MFMA: compute-bound
+            roof = {"bound": "mfma", "achieved": tflops, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": tflops / MFMA_F32_PEAK_TFLOPS}
+        else:                            # fp16 MFMA at AI ~ 125 FLOP/B: HBM-bound
+            roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
+        roof.update({"traffic": None, "kernel": dk["name"], "avg_launch_ms": launch_ms,
+                     "launches_per_refine_chunk": dk["launches"], "algorithmic_bytes_per_launch": dk["bytes_per_launch"],
+                     "algorithmic_flops_per_launch": dk["flops_per_launch"], "tflops": tflops, "gbytes_per_s": gbs,
+                     "mfma_peak_tflops": MFMA_F16_PEAK_TFLOPS if args.precision == "f16" else MFMA_F32_PEAK_TFLOPS})
 
     if rank == 0:
         pairs = B * world * args.steps
@@ -142,10 +151,11 @@ def main():
             "metric": "stereo pairs/s at 1280x720 D=192 (ms/frame alongside)", "value": value, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "ms_per_frame": elapsed / (B * args.steps) * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.precision == "fp32" else "f16 (refinement MFMA operands; fp32 accumulate; low-res branch f32)",
             "data": "synthetic (seeded stereo pairs, seeded random SN-K4 weights)",
-            "config": {"workload": f"BASELINE configs[1]: ZED-2i 1280x720 D=192 fp32, {B} pairs/GPU/step resident in HBM",
-                       "pairs_per_gpu_per_step": B, "width": W, "height": H, "dmax": D, "precision": "fp32-mfma",
+            "config": {"workload": f"BASELINE configs[1]/[2] shape: 1280x720 D=192, {B} synthetic pairs/GPU/step resident in HBM",
+                       "pairs_per_gpu_per_step": B, "width": W, "height": H, "dmax": D, "precision": args.precision,
                        "refine_chunk": args.refine_chunk, "parallelism": f"shard{world}+rccl-gather" if world > 1 else "1gpu"},
             "gflop_per_pair": eng.flops_per_pair / 1e9,
             "model_tflops": value * eng.flops_per_pair / 1e12 / world,

@@ -13,7 +13,11 @@ namespace sn {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
 constexpr int kC = 32;            // feature channels == MFMA N
+constexpr int kRefPad = 8;        // zero border (px) of the fp16 refinement tensors = max dilation
 constexpr float kSlope = 0.2f;    // LeakyReLU
 
 // Bijective XCD-aware remap: hardware places block b on XCD b % 8; give each XCD a contiguous
@@ -173,9 +177,10 @@ struct ConvArgs {
   int dil, pad;
   int lrelu;
   int tiles_x, tiles_y;
+  int f16_Hs, f16_Ws;  // OUTF == 1 only: padded plane dims of the fp16 NCHW8c output
 };
 
-template <int KS, int STRIDE, int CH, int TR, int TC, class Loader>
+template <int KS, int STRIDE, int CH, int TR, int TC, class Loader, int OUTF = 0>
 __global__ __launch_bounds__(256) void k_conv_c32_mfma(ConvArgs a, Loader ld) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int TAPS = KS * KS;
@@ -259,7 +264,24 @@ __global__ __launch_bounds__(256) void k_conv_c32_mfma(ConvArgs a, Loader ld) {
     const int seg = wave * SPW + s;
     const int srow = seg / CSEG, scol = (seg - srow * CSEG) * 32;
     const int y = ty * TR + srow, x = tx * TC + scol + j;
-    if (y < a.Ho && x < a.Wo) {
+    if (OUTF == 1) {
+      // fp16 NCHW8c with zero border (RefGeom, below): channel block q = r>>2 holds couts 8q..8q+7,
+      // this lane owns 4 of them (4*kh + (r&3)) -> one 8-byte store per block, 512 B per wave-store.
+      if (y < a.Ho && x < a.Wo) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          half4 hv;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = acc[s][4 * q + e] + a.bias[8 * q + 4 * kh + e];
+            if (a.lrelu) v = v > 0.f ? v : v * kSlope;
+            hv[e] = (_Float16)v;
+          }
+          const size_t slot = (((size_t)img * 4 + q) * a.f16_Hs + (y + kRefPad)) * a.f16_Ws + (x + kRefPad);
+          *reinterpret_cast<half4*>(reinterpret_cast<char*>(a.out) + slot * 16 + kh * 8) = hv;
+        }
+      }
+    } else if (y < a.Ho && x < a.Wo) {
       const size_t base = (size_t)img * kC * plane_o + (size_t)y * a.Wo + x;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -393,6 +415,209 @@ __global__ __launch_bounds__(256) void k_head_final(const float* __restrict__ xi
         const int xx = x + kx - 1;
         const float v = (unsigned)xx < (unsigned)Wp ? p[(size_t)yy * Wp + xx] : 0.f;
         acc = fmaf(wc[ky * 3 + kx], v, acc);
+      }
+    }
+  }
+  const float up = upsample16(disp_low + (size_t)n * hl * wl, hl, wl, y, x);
+  float d = up + dmax * acc;
+  d = d > 0.f ? d : 0.f;
+  const size_t o = ((size_t)n * H + y) * W + x;
+  if (out_disp) out_disp[o] = d;
+  if (out_raw) out_raw[o] = (int32_t)__float2int_rn(d * inv_q);
+}
+
+
+// ==========================================================================================
+// fp16 refinement tower (SN_PREC_F16): the 12 C->C 3x3 (dilated) convolutions at full resolution.
+//
+// Tensor layout "NCHW8c" with a zero border: [n][4 channel blocks][Hs][Ws] of 16-byte slots, one
+// slot = 8 consecutive fp16 channels of one pixel.  Hs = Ht + 2*kRefPad, Ws = Wt + 2*kRefPad where
+// Ht x Wt is the image rounded up to whole 8x64 tiles.  The border and the tile overhang are zeroed
+// once and never written, so the kernel has no bounds checks: zero padding is real memory.
+//   * loads: a tile row is a contiguous run of slots -> LDS-DMA (global_load_lds_dwordx4, 1 KiB per
+//     wave instruction, lane-linear destination) straight into the [block][row][col] LDS image;
+//   * MFMA  v_mfma_f32_32x32x16_f16:  D[cout][pixel] += W[cout][k] * X[k][pixel], k = 16 input
+//     channels of one tap.  The X fragment of lane (pixel j, k-half g) is ONE 16-byte slot of block
+//     2*kk+g -> ds_read_b128 of consecutive slots (conflict-free, immediate offsets, no swizzle);
+//     all 18 W fragments (9 taps x 2 k-steps) live in 72 VGPRs for the life of the persistent block;
+//   * stores: lane (pixel j, half g) owns couts 8q+4g..+3 of block q -> 8-byte store; the two halves
+//     of a wave fill whole 16-byte slots of 32 consecutive pixels = one contiguous 512-byte run.
+// K is split in two phases of 16 channels (2 channel blocks each) that ping-pong through two LDS
+// buffers: while phase p computes, the DMA for phase p+1 (same tile, or the next tile of this
+// persistent block) is in flight; one barrier per phase.
+// ==========================================================================================
+struct RefGeom {
+  int Hs, Ws;          // padded plane dims (pixels)
+  int H, W;            // valid image area (the network's Hp x Wp)
+  int tiles_x, tiles_y;
+};
+
+template <int DIL>
+struct RefTile {
+  static constexpr int TH = 8, TW = 64;
+  static constexpr int ROWS = TH + 2 * DIL, COLS = TW + 2 * DIL;
+  static constexpr int PLANE = ROWS * COLS;             // slots per channel block
+  static constexpr int HALF = 2 * PLANE;                // slots per phase (2 channel blocks)
+  static constexpr int NINST = (HALF + 63) / 64;        // DMA wave-instructions per phase
+  static constexpr int BUF = NINST * 64;                // slots per LDS buffer (padded)
+  static constexpr int LDS_BYTES = 2 * BUF * 16;
+};
+
+template <int DIL>
+__device__ __forceinline__ void ref_issue_dma(const uint4* __restrict__ in, uint4* lds_buf, const RefGeom& g,
+                                              int img, int y0, int x0, int kk, int wave, int lane) {
+  using T = RefTile<DIL>;
+  for (int i = wave; i < T::NINST; i += 4) {
+    int s = i * 64 + lane;
+    s = s < T::HALF ? s : T::HALF - 1;                   // tail lanes re-fetch the last slot into the pad
+    const int pc = s / T::PLANE;
+    const int rem = s - pc * T::PLANE;
+    const int r = rem / T::COLS;
+    const int c = rem - r * T::COLS;
+    const size_t slot = (((size_t)img * 4 + (2 * kk + pc)) * g.Hs + (y0 + r - DIL + kRefPad)) * g.Ws +
+                        (x0 + c - DIL + kRefPad);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(in + slot),
+                                     (__attribute__((address_space(3))) void*)(lds_buf + i * 64), 16, 0, 0);
+  }
+}
+
+template <int DIL, int KK>
+__device__ __forceinline__ void ref_compute(const uint4* lds_lane, const half8 (&wf)[18], f32x16 (&acc)[4]) {
+  using T = RefTile<DIL>;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int off = ((s >> 1) + ky * DIL) * T::COLS + (s & 1) * 32 + kx * DIL;
+      const half8 xb = *reinterpret_cast<const half8*>(lds_lane + off);
+      acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[tap * 2 + KK], xb, acc[s], 0, 0, 0);
+    }
+  }
+}
+
+template <int DIL>
+__global__ __launch_bounds__(256, 2) void k_ref_conv_f16(const uint4* __restrict__ in, uint4* out,
+                                                         const uint4* res,                   // nullable (may alias out)
+                                                         const uint4* __restrict__ wfrag,    // [9][2][64] slots
+                                                         const float* __restrict__ bias, RefGeom g, int nimg,
+                                                         int lrelu) {
+  using T = RefTile<DIL>;
+  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, gh = lane >> 5;
+
+  // weights: 18 MFMA A-fragments, resident in registers
+  half8 wf[18];
+#pragma unroll
+  for (int i = 0; i < 18; ++i) {
+    const uint4 v = wfrag[i * 64 + lane];
+    wf[i] = *reinterpret_cast<const half8*>(&v);
+  }
+  float bv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bv[r] = bias[(r & 3) + 8 * (r >> 2) + 4 * gh];
+
+  // persistent tile loop; XCD x (= blockIdx % 8) walks a contiguous band of tiles
+  const int per_img = g.tiles_x * g.tiles_y;
+  const int total = per_img * nimg;
+  const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, nlb = gridDim.x >> 3;
+  const int t_begin = (int)((long)xcd * total / 8), t_end = (int)((long)(xcd + 1) * total / 8);
+
+  uint4* buf0 = lds;
+  uint4* buf1 = lds + T::BUF;
+  // this lane's read base inside a buffer: channel block gh, pixel j, first row of this wave
+  const int lane_off = gh * T::PLANE + (2 * wave) * T::COLS + j;
+
+  int t = t_begin + lb;
+  if (t >= t_end) return;
+  int img = t / per_img, rem = t - img * per_img;
+  int ty = rem / g.tiles_x, tx = rem - ty * g.tiles_x;
+  ref_issue_dma<DIL>(in, buf0, g, img, ty * T::TH, tx * T::TW, 0, wave, lane);
+  __syncthreads();
+
+  while (true) {
+    const int y0 = ty * T::TH, x0 = tx * T::TW;
+    ref_issue_dma<DIL>(in, buf1, g, img, y0, x0, 1, wave, lane);
+    f32x16 acc[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+    ref_compute<DIL, 0>(buf0 + lane_off, wf, acc);
+    __syncthreads();                         // phase-1 data landed; everyone is done with buf0
+
+    const int tn = t + nlb;
+    int nimg_i = 0, nty = 0, ntx = 0;
+    const bool more = tn < t_end;
+    if (more) {
+      nimg_i = tn / per_img;
+      const int r2 = tn - nimg_i * per_img;
+      nty = r2 / g.tiles_x;
+      ntx = r2 - nty * g.tiles_x;
+      ref_issue_dma<DIL>(in, buf0, g, nimg_i, nty * T::TH, ntx * T::TW, 0, wave, lane);
+    }
+    ref_compute<DIL, 1>(buf1 + lane_off, wf, acc);
+
+    // epilogue: bias (+ residual) (+ LeakyReLU) -> fp16, 8-byte stores
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int y = y0 + 2 * wave + (s >> 1), x = x0 + (s & 1) * 32 + j;
+      if (y < g.H && x < g.W) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const size_t slot = (((size_t)img * 4 + q) * g.Hs + (y + kRefPad)) * g.Ws + (x + kRefPad);
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[s][4 * q + e] + bv[4 * q + e];
+          if (res) {
+            const half4 rv = *reinterpret_cast<const half4*>(reinterpret_cast<const char*>(res) + slot * 16 + gh * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+          }
+          half4 hv;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float u = v[e];
+            if (lrelu) u = u > 0.f ? u : u * kSlope;
+            hv[e] = (_Float16)u;
+          }
+          *reinterpret_cast<half4*>(reinterpret_cast<char*>(out) + slot * 16 + gh * 8) = hv;
+        }
+      }
+    }
+    __syncthreads();                         // next tile's phase-0 data landed; everyone is done with buf1
+    if (!more) break;
+    t = tn;
+    img = nimg_i;
+    ty = nty;
+    tx = ntx;
+  }
+}
+
+// K8 for the fp16 tower: 3x3 conv 32->1 on the NCHW8c tensor, disp = relu(up + D*r), outputs as k_head_final.
+__global__ __launch_bounds__(256) void k_head_final_f16(const uint4* __restrict__ xin, RefGeom g,
+                                                        const float* __restrict__ w,      // [32][9]
+                                                        float bias, const float* __restrict__ disp_low, int hl,
+                                                        int wl, int H, int W, float dmax, float inv_q,
+                                                        float* __restrict__ out_disp, int32_t* __restrict__ out_raw) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int n = blockIdx.z;
+  if (x >= W || y >= H) return;
+  float acc = bias;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const uint4* row = xin + (((size_t)n * 4 + q) * g.Hs + (y + ky - 1 + kRefPad)) * g.Ws + (x - 1 + kRefPad);
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const uint4 raw = row[kx];
+        const half8 hv = *reinterpret_cast<const half8*>(&raw);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc = fmaf(w[(8 * q + e) * 9 + ky * 3 + kx], (float)hv[e], acc);
       }
     }
   }

@@ -41,6 +41,11 @@ struct ConvLayer {
   int cin = 0, cin_pad = 0, taps = 0;
 };
 
+struct RefLayerF16 {        // fp16 tower layer: 18 MFMA A-fragments + fp32 bias
+  uint4* wfrag = nullptr;   // device [9][2][64] slots
+  float* bias = nullptr;
+};
+
 struct HeadLayer {          // C -> 1 layers (VALU kernels)
   float* w = nullptr;       // device [32][taps]
   float bias = 0.f;
@@ -56,6 +61,7 @@ struct Workspace {          // activations for up to `nb` pairs
   float* cost = nullptr;     // [nb][Dl][hl][wl] (debug / parity)
   float* disp_low = nullptr;
   float* ref[2] = {nullptr, nullptr};
+  uint4* ref16[2] = {nullptr, nullptr};   // fp16 NCHW8c padded (SN_PREC_F16)
   float* out_disp = nullptr;
   int32_t* out_raw = nullptr;
   uint8_t* nv12 = nullptr;   // staging for NV12 inputs (2 eyes or one side-by-side frame)
@@ -82,6 +88,9 @@ struct sn_handle {
   hipStream_t stream = nullptr;
   ConvLayer down[kNDown], fres[kNFeatRes][2], fout, agg[kNAgg], rin, rres[kNRefRes][2];
   HeadLayer aout, rout;
+  RefLayerF16 rres16[kNRefRes][2];
+  RefGeom rg{};
+  int num_cu = 256;
   Workspace ws;
   std::vector<Slot> slots;
   std::mutex mu;
@@ -188,10 +197,12 @@ int upload_head(sn_handle* h, const HostLayer& l, HeadLayer* out) {   // [1][32]
 }
 
 // ---- convolution launcher ------------------------------------------------------------------------
-template <int KS, int STRIDE, int CH, int TR, int TC, class Loader>
+template <int KS, int STRIDE, int CH, int TR, int TC, class Loader, int OUTF = 0>
 hipError_t launch_conv(hipStream_t st, const ConvLayer& L, const Loader& ld, int nimg, int Ho, int Wo,
-                       int dil, float* out, const float* res, bool lrelu) {
+                       int dil, float* out, const float* res, bool lrelu, int f16_Hs = 0, int f16_Ws = 0) {
   ConvArgs a;
+  a.f16_Hs = f16_Hs;
+  a.f16_Ws = f16_Ws;
   a.wpk = L.wpk;
   a.bias = L.bias;
   a.out = out;
@@ -209,7 +220,7 @@ hipError_t launch_conv(hipStream_t st, const ConvLayer& L, const Loader& ld, int
   const int cols_in = (TC - 1) * STRIDE + (KS - 1) * dil + 1;
   const int pitch = STRIDE == 1 ? cols_in : 2 * ((cols_in + 1) / 2);
   const size_t lds = ((size_t)CH * KS * KS * 32 + (size_t)CH * rows_in * pitch) * sizeof(float);
-  auto kern = k_conv_c32_mfma<KS, STRIDE, CH, TR, TC, Loader>;
+  auto kern = k_conv_c32_mfma<KS, STRIDE, CH, TR, TC, Loader, OUTF>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -237,6 +248,70 @@ hipError_t conv5x5s2(hipStream_t st, const ConvLayer& L, const float* in, int ni
   return launch_conv<5, 2, 4, 8, 64>(st, L, ld, nimg, Ho, Wo, 1, out, nullptr, false);
 }
 
+// ---- fp16 refinement tower -------------------------------------------------------------------------
+RefGeom make_ref_geom(int Hp, int Wp) {
+  RefGeom g;
+  g.tiles_x = (Wp + 63) / 64;
+  g.tiles_y = (Hp + 7) / 8;
+  g.H = Hp;
+  g.W = Wp;
+  g.Hs = g.tiles_y * 8 + 2 * kRefPad;
+  g.Ws = g.tiles_x * 64 + 2 * kRefPad;
+  return g;
+}
+
+size_t ref16_slots(const RefGeom& g, int nimg) { return (size_t)nimg * 4 * g.Hs * g.Ws; }
+
+// [co][ci][ky][kx] fp32 -> wfrag[tap][kk][lane][e] fp16 = w[co = lane&31][ci = 16kk + 8(lane>>5) + e][tap]
+int upload_ref_f16(sn_handle* h, const HostLayer& l, RefLayerF16* out) {
+  std::vector<_Float16> pk((size_t)18 * 64 * 8);
+  for (int tap = 0; tap < 9; ++tap)
+    for (int kk = 0; kk < 2; ++kk)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int e = 0; e < 8; ++e) {
+          const int co = lane & 31, ci = 16 * kk + 8 * (lane >> 5) + e;
+          pk[(((size_t)tap * 2 + kk) * 64 + lane) * 8 + e] = (_Float16)l.w[((size_t)co * kC + ci) * 9 + tap];
+        }
+  HIP_TRY(h, dalloc(&out->wfrag, (size_t)18 * 64));
+  HIP_TRY(h, dalloc(&out->bias, kC));
+  HIP_TRY(h, hipMemcpy(out->wfrag, pk.data(), pk.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+  HIP_TRY(h, hipMemcpy(out->bias, l.b, kC * sizeof(float), hipMemcpyHostToDevice));
+  return SN_OK;
+}
+
+template <int DIL>
+hipError_t launch_ref_f16(hipStream_t st, const RefLayerF16& L, const RefGeom& g, int num_cu, const uint4* in,
+                          uint4* out, const uint4* res, int nimg, bool lrelu) {
+  using T = RefTile<DIL>;
+  auto kern = k_ref_conv_f16<DIL>;
+  static bool attr_done = false;
+  if (!attr_done && T::LDS_BYTES > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  const int total = g.tiles_x * g.tiles_y * nimg;
+  const int per_cu = T::LDS_BYTES * 2 <= 160 * 1024 ? 2 : 1;
+  int blocks = num_cu * per_cu;
+  if (blocks > total) blocks = total;
+  blocks = (blocks + 7) / 8 * 8;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), T::LDS_BYTES, st, in, out, res, L.wfrag, L.bias, g, nimg,
+                     lrelu ? 1 : 0);
+  return hipGetLastError();
+}
+
+hipError_t ref_conv_f16(hipStream_t st, const RefLayerF16& L, const RefGeom& g, int num_cu, int dil, const uint4* in,
+                        uint4* out, const uint4* res, int nimg, bool lrelu) {
+  switch (dil) {
+    case 1: return launch_ref_f16<1>(st, L, g, num_cu, in, out, res, nimg, lrelu);
+    case 2: return launch_ref_f16<2>(st, L, g, num_cu, in, out, res, nimg, lrelu);
+    case 4: return launch_ref_f16<4>(st, L, g, num_cu, in, out, res, nimg, lrelu);
+    case 8: return launch_ref_f16<8>(st, L, g, num_cu, in, out, res, nimg, lrelu);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 // ---- workspace -----------------------------------------------------------------------------------
 int alloc_ws(sn_handle* h, Workspace* ws, int nb, int rb) {
   ws->nb = nb;
@@ -250,7 +325,15 @@ int alloc_ws(sn_handle* h, Workspace* ws, int nb, int rb) {
   for (int k = 0; k < 2; ++k) HIP_TRY(h, dalloc(&ws->vol[k], (size_t)nb * h->Dl * kC * hw));
   HIP_TRY(h, dalloc(&ws->cost, (size_t)nb * h->Dl * hw));
   HIP_TRY(h, dalloc(&ws->disp_low, (size_t)nb * hw));
-  for (int k = 0; k < 2; ++k) HIP_TRY(h, dalloc(&ws->ref[k], (size_t)rb * kC * HWp));
+  if (h->precision == SN_PREC_FP32) {
+    for (int k = 0; k < 2; ++k) HIP_TRY(h, dalloc(&ws->ref[k], (size_t)rb * kC * HWp));
+  } else {
+    for (int k = 0; k < 2; ++k) {
+      const size_t slots = ref16_slots(h->rg, rb);
+      HIP_TRY(h, dalloc(&ws->ref16[k], slots));
+      HIP_TRY(h, hipMemset(ws->ref16[k], 0, slots * sizeof(uint4)));   // the zero border is never written again
+    }
+  }
   HIP_TRY(h, dalloc(&ws->out_disp, (size_t)nb * HW));
   HIP_TRY(h, dalloc(&ws->out_raw, (size_t)nb * HW));
   HIP_TRY(h, dalloc(&ws->nv12, (size_t)HW * 3));
@@ -266,6 +349,7 @@ void free_ws(Workspace* ws) {
   hipFree(ws->cost);
   hipFree(ws->disp_low);
   for (auto p : ws->ref) hipFree(p);
+  for (auto p : ws->ref16) hipFree(p);
   hipFree(ws->out_disp);
   hipFree(ws->out_raw);
   hipFree(ws->nv12);
@@ -325,24 +409,50 @@ int forward(sn_handle* h, Workspace& ws, hipStream_t st, int n, const int8_t* in
     const size_t HW = (size_t)h->H * h->W;
     LoadRefineIn ld{ws.disp_low + (size_t)p0 * hl * wl, in6 + (size_t)p0 * 6 * HW, hl, wl, h->H, h->W, Hp, Wp,
                     1.0f / (float)h->D};
-    float* rx = ws.ref[0];
-    float* rt = ws.ref[1];
-    if (Hp * Wp <= 64 * 128)
-      HIP_TRY(h, (launch_conv<3, 1, 4, 4, 32>(st, h->rin, ld, m, Hp, Wp, 1, rx, nullptr, true)));
-    else
-      HIP_TRY(h, (launch_conv<3, 1, 4, 8, 64>(st, h->rin, ld, m, Hp, Wp, 1, rx, nullptr, true)));
-    if (prof && p0 == 0) HIP_TRY(h, hipEventRecord(h->ev[4], st));
-    for (int i = 0; i < kNRefRes; ++i) {
-      HIP_TRY(h, conv3x3(st, h->rres[i][0], rx, m, Hp, Wp, kRefDil[i], rt, nullptr, true));
-      HIP_TRY(h, conv3x3(st, h->rres[i][1], rt, m, Hp, Wp, kRefDil[i], rx, rx, true));
-      h->dom_launches += 2;
+    if (h->precision == SN_PREC_FP32) {
+      float* rx = ws.ref[0];
+      float* rt = ws.ref[1];
+      if (Hp * Wp <= 64 * 128)
+        HIP_TRY(h, (launch_conv<3, 1, 4, 4, 32>(st, h->rin, ld, m, Hp, Wp, 1, rx, nullptr, true)));
+      else
+        HIP_TRY(h, (launch_conv<3, 1, 4, 8, 64>(st, h->rin, ld, m, Hp, Wp, 1, rx, nullptr, true)));
+      if (prof && p0 == 0) HIP_TRY(h, hipEventRecord(h->ev[4], st));
+      for (int i = 0; i < kNRefRes; ++i) {
+        HIP_TRY(h, conv3x3(st, h->rres[i][0], rx, m, Hp, Wp, kRefDil[i], rt, nullptr, true));
+        HIP_TRY(h, conv3x3(st, h->rres[i][1], rt, m, Hp, Wp, kRefDil[i], rx, rx, true));
+        h->dom_launches += 2;
+      }
+      if (prof && p0 == 0) HIP_TRY(h, hipEventRecord(h->ev[5], st));
+      dim3 grid((h->W + 63) / 64, (h->H + 3) / 4, m);
+      hipLaunchKernelGGL(k_head_final, grid, dim3(256), 0, st, rx, h->rout.w, h->rout.bias,
+                         ws.disp_low + (size_t)p0 * hl * wl, hl, wl, Hp, Wp, h->H, h->W, (float)h->D, inv_q,
+                         out_disp ? out_disp + (size_t)p0 * HW : nullptr,
+                         out_raw ? out_raw + (size_t)p0 * HW : nullptr);
+    } else {
+      // fp16 tower: ref.in (K=36, fp32 MFMA) writes the NCHW8c fp16 tensor, the 12 C->C convs run on
+      // v_mfma_f32_32x32x16_f16, the head reads fp16 and finishes in fp32
+      uint4* rx = ws.ref16[0];
+      uint4* rt = ws.ref16[1];
+      const RefGeom& g = h->rg;
+      if (Hp * Wp <= 64 * 128)
+        HIP_TRY(h, (launch_conv<3, 1, 4, 4, 32, LoadRefineIn, 1>(st, h->rin, ld, m, Hp, Wp, 1, reinterpret_cast<float*>(rx),
+                                                                  nullptr, true, g.Hs, g.Ws)));
+      else
+        HIP_TRY(h, (launch_conv<3, 1, 4, 8, 64, LoadRefineIn, 1>(st, h->rin, ld, m, Hp, Wp, 1, reinterpret_cast<float*>(rx),
+                                                                  nullptr, true, g.Hs, g.Ws)));
+      if (prof && p0 == 0) HIP_TRY(h, hipEventRecord(h->ev[4], st));
+      for (int i = 0; i < kNRefRes; ++i) {
+        HIP_TRY(h, ref_conv_f16(st, h->rres16[i][0], g, h->num_cu, kRefDil[i], rx, rt, nullptr, m, true));
+        HIP_TRY(h, ref_conv_f16(st, h->rres16[i][1], g, h->num_cu, kRefDil[i], rt, rx, rx, m, true));
+        h->dom_launches += 2;
+      }
+      if (prof && p0 == 0) HIP_TRY(h, hipEventRecord(h->ev[5], st));
+      dim3 grid((h->W + 63) / 64, (h->H + 3) / 4, m);
+      hipLaunchKernelGGL(k_head_final_f16, grid, dim3(256), 0, st, rx, g, h->rout.w, h->rout.bias,
+                         ws.disp_low + (size_t)p0 * hl * wl, hl, wl, h->H, h->W, (float)h->D, inv_q,
+                         out_disp ? out_disp + (size_t)p0 * HW : nullptr,
+                         out_raw ? out_raw + (size_t)p0 * HW : nullptr);
     }
-    if (prof && p0 == 0) HIP_TRY(h, hipEventRecord(h->ev[5], st));
-    dim3 grid((h->W + 63) / 64, (h->H + 3) / 4, m);
-    hipLaunchKernelGGL(k_head_final, grid, dim3(256), 0, st, rx, h->rout.w, h->rout.bias,
-                       ws.disp_low + (size_t)p0 * hl * wl, hl, wl, Hp, Wp, h->H, h->W, (float)h->D, inv_q,
-                       out_disp ? out_disp + (size_t)p0 * HW : nullptr,
-                       out_raw ? out_raw + (size_t)p0 * HW : nullptr);
     HIP_TRY(h, hipGetLastError());
   }
   if (prof) HIP_TRY(h, hipEventRecord(h->ev[3], st));
@@ -422,7 +532,7 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
   const int H = c.height > 0 ? c.height : (int)hd.height;
   const int D = c.dmax > 0 ? c.dmax : (int)hd.dmax;
   if (W <= 0 || H <= 0 || (W & 3) || (H & 1) || D < 16 || D % 16 || D > 256) return SN_ERR_ARG;
-  if (c.precision != SN_PREC_FP32) return SN_ERR_ARG;   // other precisions: not built yet
+  if (c.precision != SN_PREC_FP32 && c.precision != SN_PREC_F16) return SN_ERR_ARG;   // F16X3: not built yet
 
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SN_ERR_DEVICE;
@@ -451,6 +561,8 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
   h->precision = c.precision;
   h->task_num = c.task_num > 0 ? c.task_num : 4;
   h->refine_chunk = c.refine_chunk > 0 ? c.refine_chunk : 1;
+  h->rg = make_ref_geom(h->Hp, h->Wp);
+  h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (h->refine_chunk > h->max_batch) h->refine_chunk = h->max_batch;
 
   int rc = check_device(h);
@@ -475,8 +587,14 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
   if ((rc = upload_head(h, bw.next(1, kC, 27), &h->aout))) return fail(rc);
   if ((rc = upload_conv2d(h, bw.next(kC, 4, 9), 4, &h->rin))) return fail(rc);
   for (int i = 0; i < kNRefRes; ++i)
-    for (int j = 0; j < 2; ++j)
-      if ((rc = upload_conv2d(h, bw.next(kC, kC, 9), 8, &h->rres[i][j]))) return fail(rc);
+    for (int j = 0; j < 2; ++j) {
+      const HostLayer hl_ = bw.next(kC, kC, 9);
+      if (h->precision == SN_PREC_FP32) {
+        if ((rc = upload_conv2d(h, hl_, 8, &h->rres[i][j]))) return fail(rc);
+      } else {
+        if ((rc = upload_ref_f16(h, hl_, &h->rres16[i][j]))) return fail(rc);
+      }
+    }
   if ((rc = upload_head(h, bw.next(1, kC, 9), &h->rout))) return fail(rc);
   if (bw.off != blob.size()) return fail(SN_ERR_FORMAT);
 
@@ -501,6 +619,11 @@ int sn_destroy(sn_handle* h) {
   free_conv(h->rin);
   for (auto& b : h->rres)
     for (auto& l : b) free_conv(l);
+  for (auto& b : h->rres16)
+    for (auto& l : b) {
+      hipFree(l.wfrag);
+      hipFree(l.bias);
+    }
   hipFree(h->aout.w);
   hipFree(h->rout.w);
   free_ws(&h->ws);
@@ -773,13 +896,16 @@ int sn_get_stage_ms(sn_handle* h, float* ms, int count) {
 
 int sn_get_dominant_kernel(sn_handle* h, char* name, size_t cap, int* launches, double* flops, double* bytes) {
   if (!h) return SN_ERR_ARG;
-  if (name && cap) snprintf(name, cap, "k_conv_c32_mfma<3,1,*> (refinement 3x3 C->C, fp32 MFMA)");
+  const bool f16 = h->precision != SN_PREC_FP32;
+  if (name && cap)
+    snprintf(name, cap, "%s", f16 ? "k_ref_conv_f16<DIL> (refinement 3x3 C->C, fp16 MFMA 32x32x16)"
+                                  : "k_conv_c32_mfma<3,1,*> (refinement 3x3 C->C, fp32 MFMA 32x32x2)");
   const double px = (double)h->Hp * h->Wp * h->ws.rb;
   if (launches) *launches = 2 * kNRefRes;   // per refinement chunk
   if (flops) *flops = 2.0 * px * kC * kC * 9;
-  // algorithmic HBM bytes per launch: read the C-channel fp32 input once, write the output once
-  // (the in-place residual read of the second conv of a block hits the same lines it writes)
-  if (bytes) *bytes = px * kC * 4.0 * 2.0;
+  // algorithmic HBM bytes per launch: read the 32-channel input once + write the output once, plus the
+  // residual read on every second launch (averaged: 2.5 tensors); element = 2 B (fp16) or 4 B (fp32)
+  if (bytes) *bytes = px * kC * (f16 ? 2.0 : 4.0) * 2.5;
   return SN_OK;
 }
 
@@ -860,6 +986,67 @@ int sn_dbg_conv3d(sn_handle* h, const float* in, int d, int h_px, int w, const f
   return SN_OK;
 }
 
+int sn_dbg_ref_conv_f16(sn_handle* h, const float* in, int h_px, int w, const float* wt, const float* bias, int dil,
+                        int lrelu, const float* residual, float* out) {
+  if (!h || !in || !wt || !bias || !out || h_px <= 0 || w <= 0) return SN_ERR_ARG;
+  if (dil != 1 && dil != 2 && dil != 4 && dil != 8) return SN_ERR_ARG;
+  int rc = check_device(h);
+  if (rc) return rc;
+  const RefGeom g = make_ref_geom(h_px, w);
+  const size_t slots = ref16_slots(g, 1);
+  auto to_dev_layout = [&](const float* src, std::vector<_Float16>& dst) {
+    dst.assign(slots * 8, (_Float16)0.f);
+    for (int c = 0; c < kC; ++c)
+      for (int y = 0; y < h_px; ++y)
+        for (int x = 0; x < w; ++x)
+          dst[((((size_t)(c >> 3)) * g.Hs + y + kRefPad) * g.Ws + x + kRefPad) * 8 + (c & 7)] =
+              (_Float16)src[((size_t)c * h_px + y) * w + x];
+  };
+  std::vector<_Float16> hin, hres;
+  to_dev_layout(in, hin);
+  RefLayerF16 L;
+  HostLayer hl{wt, bias, kC, kC, 9};
+  if ((rc = upload_ref_f16(h, hl, &L))) return rc;
+  uint4 *din = nullptr, *dout = nullptr;
+  HIP_TRY(h, dalloc(&din, slots));
+  HIP_TRY(h, dalloc(&dout, slots));
+  HIP_TRY(h, hipMemcpy(din, hin.data(), slots * 16, hipMemcpyHostToDevice));
+  const uint4* dres = nullptr;
+  if (residual) {
+    to_dev_layout(residual, hres);
+    HIP_TRY(h, hipMemcpy(dout, hres.data(), slots * 16, hipMemcpyHostToDevice));
+    dres = dout;
+  } else {
+    HIP_TRY(h, hipMemset(dout, 0, slots * 16));
+  }
+  HIP_TRY(h, ref_conv_f16(h->stream, L, g, h->num_cu, dil, din, dout, dres, 1, lrelu != 0));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  std::vector<_Float16> hout(slots * 8);
+  HIP_TRY(h, hipMemcpy(hout.data(), dout, slots * 16, hipMemcpyDeviceToHost));
+  for (int c = 0; c < kC; ++c)
+    for (int y = 0; y < h_px; ++y)
+      for (int x = 0; x < w; ++x)
+        out[((size_t)c * h_px + y) * w + x] =
+            (float)hout[((((size_t)(c >> 3)) * g.Hs + y + kRefPad) * g.Ws + x + kRefPad) * 8 + (c & 7)];
+  // the zero border must have survived (the kernel never writes outside the valid area)
+  for (int c = 0; c < 4; ++c)
+    for (int y = 0; y < g.Hs; ++y)
+      for (int x = 0; x < g.Ws; ++x) {
+        const bool inside = y >= kRefPad && y < kRefPad + h_px && x >= kRefPad && x < kRefPad + w;
+        if (inside) continue;
+        for (int e = 0; e < 8; ++e)
+          if ((float)hout[(((size_t)c * g.Hs + y) * g.Ws + x) * 8 + e] != 0.f) {
+            set_err(h, "fp16 conv wrote into the zero border");
+            return SN_ERR_DEVICE;
+          }
+      }
+  hipFree(din);
+  hipFree(dout);
+  hipFree(L.wfrag);
+  hipFree(L.bias);
+  return SN_OK;
+}
+
 int sn_dbg_read(sn_handle* h, const char* what, float* dst, size_t cap, size_t* n) {
   if (!h || !what || !n) return SN_ERR_ARG;
   int rc = check_device(h);
@@ -871,7 +1058,7 @@ int sn_dbg_read(sn_handle* h, const char* what, float* dst, size_t cap, size_t* 
   else if (!strcmp(what, "feat_r")) { src = h->ws.feat + kC * hw; cnt = kC * hw; }
   else if (!strcmp(what, "cost")) { src = h->ws.cost; cnt = h->Dl * hw; }
   else if (!strcmp(what, "disp_low")) { src = h->ws.disp_low; cnt = hw; }
-  else if (!strcmp(what, "refine_x")) { src = h->ws.ref[0]; cnt = (size_t)kC * h->Hp * h->Wp; }
+  else if (!strcmp(what, "refine_x") && h->precision == SN_PREC_FP32) { src = h->ws.ref[0]; cnt = (size_t)kC * h->Hp * h->Wp; }
   else return SN_ERR_ARG;
   *n = cnt;
   if (!dst) return SN_OK;

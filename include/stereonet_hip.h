@@ -143,6 +143,10 @@ int sn_dbg_conv2d(sn_handle *h, const float *in, int cin, int h_px, int w, const
 /* one 3x3x3 32->32 conv3d (+bias, optional LeakyReLU): in [32][d][h][w] -> out [32][d][h][w] */
 int sn_dbg_conv3d(sn_handle *h, const float *in, int d, int h_px, int w, const float *wt,
                   const float *bias, int lrelu, float *out);
+/* one 32->32 3x3 conv (dilation 1/2/4/8) through the fp16 refinement-tower kernel: in / residual / out are
+ * fp32 [32][h][w] on the host; the hook converts to the kernel's fp16 NCHW8c layout and back. */
+int sn_dbg_ref_conv_f16(sn_handle *h, const float *in, int h_px, int w, const float *wt, const float *bias,
+                        int dil, int lrelu, const float *residual, float *out);
 /* intermediates of the most recent batch-1 inference: "feat_l" / "feat_r" [32][hl][wl],
  * "cost"... see DESIGN.md §6; returns the element count in *n (dst may be NULL to query). */
 int sn_dbg_read(sn_handle *h, const char *what, float *dst, size_t cap, size_t *n);

@@ -1,0 +1,84 @@
+"""fp16 refinement tower (SN_PREC_F16) vs the CPU oracle.  Operands are rounded to fp16, products are
+exact and accumulation is fp32, so a single layer must match the oracle run on fp16-rounded operands to
+fp32 round-off + one output rounding; end to end the bound is the north-star's EPE <= 1e-3 px."""
+import numpy as np
+import pytest
+
+from hobot_stereonet_amd import api, spec, synth
+
+pytestmark = pytest.mark.gpu
+EPE_TOL = 1e-3
+
+
+def q16(a):
+    return np.asarray(a, np.float32).astype(np.float16).astype(np.float32)
+
+
+@pytest.fixture(scope="module")
+def eng16(model_factory):
+    eng = api.StereoNetHIP(model_factory(96, 64, 48), max_batch=2, precision=api.PREC_F16)
+    yield eng
+    eng.close()
+
+
+@pytest.mark.parametrize("h,w,dil", [(16, 64, 1), (64, 96, 1), (45, 80, 2), (72, 200, 4), (130, 300, 8),
+                                     (8, 64, 8), (100, 129, 1), (24, 70, 4), (720, 1280, 1)])
+def test_ref_conv_f16_layer(eng16, oracle, h, w, dil):
+    rng = np.random.default_rng(h * 31 + w + dil)
+    x = q16(rng.standard_normal((32, h, w)))
+    wt = q16(rng.standard_normal((32, 32, 3, 3)) / 17.0)
+    b = rng.standard_normal(32).astype(np.float32)
+    ref = oracle.conv2d(x, wt, b, 1, dil, dil)
+    got = eng16.dbg_ref_conv_f16(x, wt, b, dil)
+    scale = np.abs(ref).max()
+    assert np.abs(got - q16(ref)).max() <= 2e-3 * scale / 2 + 1e-6      # <= 1 fp16 ulp of the largest value
+    assert np.abs(got - ref).mean() < 3e-4 * scale
+    res = q16(rng.standard_normal((32, h, w)))
+    v = ref + res
+    ref2 = np.where(v > 0, v, v * np.float32(0.2))
+    got2 = eng16.dbg_ref_conv_f16(x, wt, b, dil, lrelu=True, residual=res)
+    assert np.abs(got2 - ref2).max() <= 1.2e-3 * np.abs(ref2).max() + 1e-6
+
+
+CASES = [("c96x64_d48", 96, 64, 48, 3), ("c160x96_d96", 160, 96, 96, 4), ("c100x52_d32", 100, 52, 32, 5)]
+
+
+@pytest.mark.parametrize("name,w,h,d,seed", CASES)
+def test_forward_small_f16(model_factory, oracle, golden_net, weights_blob, name, w, h, d, seed):
+    x = synth.model_input_i8(w, h, d, seed)
+    with api.StereoNetHIP(model_factory(w, h, d), precision=api.PREC_F16) as eng:
+        disp, raw = eng.infer(x)
+        low = eng.dbg_read("disp_low").reshape((h + 15) // 16, (w + 15) // 16)
+    odisp, _, olow = oracle.forward(weights_blob, x, d)
+    assert np.abs(low - olow).max() < 1e-4            # the low-resolution branch stays fp32
+    epe = float(np.abs(disp - odisp).mean())
+    assert epe < EPE_TOL, epe
+    assert np.abs(disp - golden_net[name + ".disp"]).mean() < EPE_TOL
+    inv_q = np.float32(1.0 / (float(d) * float(np.float32(spec.OUT_SCALE))))
+    assert (raw == np.rint(disp * inv_q).astype(np.int32)).all()
+
+
+def test_full_size_epe_f16(model_factory, oracle, weights_blob):
+    """BASELINE.json configs[2] shape: 1280x720 D=192 on the fp16 MFMA path, batch 2, refine_chunk 2."""
+    w, h, d = 1280, 720, 192
+    xs = np.stack([synth.model_input_i8(w, h, d, s) for s in (0, 1)])
+    with api.StereoNetHIP(model_factory(w, h, d), precision=api.PREC_F16, max_batch=2, refine_chunk=2) as eng:
+        disp, raw = eng.infer(xs)
+        disp_again, _ = eng.infer(xs)
+        d0, _ = eng.infer(xs[0])
+    assert (disp == disp_again).all()                  # deterministic, border untouched between calls
+    assert (d0 == disp[0]).all()                       # batch == single
+    for i in range(2):
+        odisp, _, _ = oracle.forward(weights_blob, xs[i], d)
+        epe = float(np.abs(disp[i] - odisp).mean())
+        print(f"fp16 tower EPE vs oracle, pair {i}: {epe:.3e} px (max {np.abs(disp[i] - odisp).max():.3e})")
+        assert epe < EPE_TOL
+
+
+def test_padded_geometry_f16(model_factory, oracle, weights_blob):
+    w, h, d = 124, 38, 32
+    x = synth.model_input_i8(w, h, d, 9)
+    with api.StereoNetHIP(model_factory(w, h, d), precision=api.PREC_F16) as eng:
+        disp, _ = eng.infer(x)
+    odisp, _, _ = oracle.forward(weights_blob, x, d)
+    assert np.abs(disp - odisp).mean() < EPE_TOL
