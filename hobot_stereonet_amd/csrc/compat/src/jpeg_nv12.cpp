@@ -1,0 +1,245 @@
+// jpeg_nv12.cpp — see include/jpeg_nv12.h.  Straightforward baseline encoder: 16x16 MCUs (4 Y + Cb + Cr
+// blocks), float separable DCT, standard quantisation tables scaled by the libjpeg quality rule, standard
+// Huffman tables.
+#include "jpeg_nv12.h"
+
+#include <cmath>
+#include <cstring>
+
+namespace hobot {
+namespace stereonet {
+namespace {
+
+const uint8_t kZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                             41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                             30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+const uint8_t kQLum[64] = {16, 11, 10, 16, 24,  40,  51,  61,  12, 12, 14, 19, 26,  58,  60,  55,
+                           14, 13, 16, 24, 40,  57,  69,  56,  14, 17, 22, 29, 51,  87,  80,  62,
+                           18, 22, 37, 56, 68,  109, 103, 77,  24, 35, 55, 64, 81,  104, 113, 92,
+                           49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99};
+const uint8_t kQChr[64] = {17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99,
+                           99, 99, 47, 66, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99,
+                           99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99};
+const uint8_t kDcLumBits[16] = {0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0};
+const uint8_t kDcChrBits[16] = {0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0};
+const uint8_t kDcVals[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+const uint8_t kAcLumBits[16] = {0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 0x7d};
+const uint8_t kAcLumVals[162] = {
+    0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51, 0x61, 0x07, 0x22, 0x71,
+    0x14, 0x32, 0x81, 0x91, 0xa1, 0x08, 0x23, 0x42, 0xb1, 0xc1, 0x15, 0x52, 0xd1, 0xf0, 0x24, 0x33, 0x62, 0x72,
+    0x82, 0x09, 0x0a, 0x16, 0x17, 0x18, 0x19, 0x1a, 0x25, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x34, 0x35, 0x36, 0x37,
+    0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59,
+    0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x83,
+    0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3,
+    0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3,
+    0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe1, 0xe2,
+    0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf1, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa};
+const uint8_t kAcChrBits[16] = {0, 2, 1, 2, 4, 4, 3, 4, 7, 5, 4, 4, 0, 1, 2, 0x77};
+const uint8_t kAcChrVals[162] = {
+    0x00, 0x01, 0x02, 0x03, 0x11, 0x04, 0x05, 0x21, 0x31, 0x06, 0x12, 0x41, 0x51, 0x07, 0x61, 0x71, 0x13, 0x22,
+    0x32, 0x81, 0x08, 0x14, 0x42, 0x91, 0xa1, 0xb1, 0xc1, 0x09, 0x23, 0x33, 0x52, 0xf0, 0x15, 0x62, 0x72, 0xd1,
+    0x0a, 0x16, 0x24, 0x34, 0xe1, 0x25, 0xf1, 0x17, 0x18, 0x19, 0x1a, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x35, 0x36,
+    0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58,
+    0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a,
+    0x82, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a,
+    0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba,
+    0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda,
+    0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa};
+
+struct Huff {
+  uint16_t code[256];
+  uint8_t len[256];
+};
+
+void build_huff(const uint8_t* bits, const uint8_t* vals, Huff* h) {
+  memset(h, 0, sizeof *h);
+  int code = 0, k = 0;
+  for (int l = 1; l <= 16; ++l) {
+    for (int i = 0; i < bits[l - 1]; ++i) {
+      h->code[vals[k]] = (uint16_t)code++;
+      h->len[vals[k]] = (uint8_t)l;
+      ++k;
+    }
+    code <<= 1;
+  }
+}
+
+struct BitWriter {
+  std::vector<uint8_t>& out;
+  uint32_t acc = 0;
+  int nbits = 0;
+  explicit BitWriter(std::vector<uint8_t>& o) : out(o) {}
+  void put(uint32_t code, int len) {
+    acc = (acc << len) | (code & ((1u << len) - 1));
+    nbits += len;
+    while (nbits >= 8) {
+      const uint8_t b = (uint8_t)(acc >> (nbits - 8));
+      out.push_back(b);
+      if (b == 0xFF) out.push_back(0x00);
+      nbits -= 8;
+    }
+  }
+  void flush() {
+    if (nbits > 0) put((1u << (8 - nbits)) - 1, 8 - nbits);
+  }
+};
+
+void fdct8x8(const float* in, float* out) {
+  static float c[8][8];
+  static bool init = false;
+  if (!init) {
+    for (int u = 0; u < 8; ++u)
+      for (int x = 0; x < 8; ++x)
+        c[u][x] = (u == 0 ? std::sqrt(0.125f) : 0.5f) * std::cos((2 * x + 1) * u * 3.14159265358979323846f / 16.0f);
+    init = true;
+  }
+  float tmp[64];
+  for (int y = 0; y < 8; ++y)
+    for (int u = 0; u < 8; ++u) {
+      float s = 0.f;
+      for (int x = 0; x < 8; ++x) s += c[u][x] * in[y * 8 + x];
+      tmp[y * 8 + u] = s;
+    }
+  for (int v = 0; v < 8; ++v)
+    for (int u = 0; u < 8; ++u) {
+      float s = 0.f;
+      for (int y = 0; y < 8; ++y) s += c[v][y] * tmp[y * 8 + u];
+      out[v * 8 + u] = s;
+    }
+}
+
+void encode_block(const float* px, const uint8_t* q, const Huff& dc, const Huff& ac, int* last_dc, BitWriter* bw) {
+  float coef[64];
+  fdct8x8(px, coef);
+  int zz[64];
+  for (int i = 0; i < 64; ++i) zz[i] = (int)std::lrintf(coef[kZigzag[i]] / (float)q[kZigzag[i]]);
+  auto magnitude = [](int v, int* nb, uint32_t* bits) {
+    int a = v < 0 ? -v : v, n = 0;
+    while (a) {
+      ++n;
+      a >>= 1;
+    }
+    *nb = n;
+    *bits = (uint32_t)(v < 0 ? v + (1 << n) - 1 : v);
+  };
+  int nb;
+  uint32_t bits;
+  const int diff = zz[0] - *last_dc;
+  *last_dc = zz[0];
+  magnitude(diff, &nb, &bits);
+  bw->put(dc.code[nb], dc.len[nb]);
+  if (nb) bw->put(bits, nb);
+  int run = 0;
+  for (int i = 1; i < 64; ++i) {
+    if (zz[i] == 0) {
+      ++run;
+      continue;
+    }
+    while (run > 15) {
+      bw->put(ac.code[0xF0], ac.len[0xF0]);
+      run -= 16;
+    }
+    magnitude(zz[i], &nb, &bits);
+    const int sym = (run << 4) | nb;
+    bw->put(ac.code[sym], ac.len[sym]);
+    bw->put(bits, nb);
+    run = 0;
+  }
+  if (run) bw->put(ac.code[0x00], ac.len[0x00]);
+}
+
+void put16(std::vector<uint8_t>& o, int v) {
+  o.push_back((uint8_t)(v >> 8));
+  o.push_back((uint8_t)v);
+}
+
+}  // namespace
+
+bool EncodeNv12ToJpeg(const uint8_t* nv12, int w, int h, int pitch, int quality, std::vector<uint8_t>& out) {
+  if (!nv12 || w <= 0 || h <= 0 || (w & 1) || (h & 1) || pitch < w) return false;
+  quality = quality < 1 ? 1 : (quality > 100 ? 100 : quality);
+  const int sf = quality < 50 ? 5000 / quality : 200 - quality * 2;
+  uint8_t ql[64], qc[64];
+  for (int i = 0; i < 64; ++i) {
+    int a = (kQLum[i] * sf + 50) / 100, b = (kQChr[i] * sf + 50) / 100;
+    ql[i] = (uint8_t)(a < 1 ? 1 : (a > 255 ? 255 : a));
+    qc[i] = (uint8_t)(b < 1 ? 1 : (b > 255 ? 255 : b));
+  }
+  Huff dcl, dcc, acl, acc;
+  build_huff(kDcLumBits, kDcVals, &dcl);
+  build_huff(kDcChrBits, kDcVals, &dcc);
+  build_huff(kAcLumBits, kAcLumVals, &acl);
+  build_huff(kAcChrBits, kAcChrVals, &acc);
+
+  out.clear();
+  out.reserve((size_t)w * h / 4);
+  const uint8_t soi_app0[] = {0xFF, 0xD8, 0xFF, 0xE0, 0, 16, 'J', 'F', 'I', 'F', 0, 1, 1, 0, 0, 1, 0, 1, 0, 0};
+  out.insert(out.end(), soi_app0, soi_app0 + sizeof soi_app0);
+  for (int t = 0; t < 2; ++t) {   // DQT
+    out.push_back(0xFF);
+    out.push_back(0xDB);
+    put16(out, 67);
+    out.push_back((uint8_t)t);
+    for (int i = 0; i < 64; ++i) out.push_back((t ? qc : ql)[kZigzag[i]]);
+  }
+  out.push_back(0xFF);   // SOF0: 8 bit, 3 components, Y 2x2, Cb/Cr 1x1
+  out.push_back(0xC0);
+  put16(out, 17);
+  out.push_back(8);
+  put16(out, h);
+  put16(out, w);
+  out.push_back(3);
+  const uint8_t comps[9] = {1, 0x22, 0, 2, 0x11, 1, 3, 0x11, 1};
+  out.insert(out.end(), comps, comps + 9);
+  auto dht = [&](int cls_id, const uint8_t* bits, const uint8_t* vals, int nvals) {
+    out.push_back(0xFF);
+    out.push_back(0xC4);
+    put16(out, 3 + 16 + nvals);
+    out.push_back((uint8_t)cls_id);
+    out.insert(out.end(), bits, bits + 16);
+    out.insert(out.end(), vals, vals + nvals);
+  };
+  dht(0x00, kDcLumBits, kDcVals, 12);
+  dht(0x10, kAcLumBits, kAcLumVals, 162);
+  dht(0x01, kDcChrBits, kDcVals, 12);
+  dht(0x11, kAcChrBits, kAcChrVals, 162);
+  const uint8_t sos[] = {0xFF, 0xDA, 0, 12, 3, 1, 0x00, 2, 0x11, 3, 0x11, 0, 63, 0};
+  out.insert(out.end(), sos, sos + sizeof sos);
+
+  BitWriter bw(out);
+  int dc_y = 0, dc_cb = 0, dc_cr = 0;
+  const uint8_t* uv = nv12 + (size_t)h * pitch;
+  const int cw = w / 2, chh = h / 2;
+  float blk[64];
+  for (int my = 0; my < h; my += 16)
+    for (int mx = 0; mx < w; mx += 16) {
+      for (int b = 0; b < 4; ++b) {
+        const int by = my + (b >> 1) * 8, bx = mx + (b & 1) * 8;
+        for (int y = 0; y < 8; ++y) {
+          const int sy = by + y < h ? by + y : h - 1;
+          for (int x = 0; x < 8; ++x) {
+            const int sx = bx + x < w ? bx + x : w - 1;
+            blk[y * 8 + x] = (float)nv12[(size_t)sy * pitch + sx] - 128.0f;
+          }
+        }
+        encode_block(blk, ql, dcl, acl, &dc_y, &bw);
+      }
+      for (int comp = 0; comp < 2; ++comp) {
+        for (int y = 0; y < 8; ++y) {
+          const int sy = my / 2 + y < chh ? my / 2 + y : chh - 1;
+          for (int x = 0; x < 8; ++x) {
+            const int sx = mx / 2 + x < cw ? mx / 2 + x : cw - 1;
+            blk[y * 8 + x] = (float)uv[(size_t)sy * pitch + 2 * sx + comp] - 128.0f;
+          }
+        }
+        encode_block(blk, qc, dcc, acc, comp ? &dc_cr : &dc_cb, &bw);
+      }
+    }
+  bw.flush();
+  out.push_back(0xFF);
+  out.push_back(0xD9);
+  return true;
+}
+
+}  // namespace stereonet
+}  // namespace hobot

@@ -1,0 +1,49 @@
+// test_hooks.cpp — extern "C" entry points so the CPU test-suite can exercise the host mirror's pure
+// functions through ctypes without a GPU or ROS (tests/test_host_mirror.py).
+#include <cstring>
+
+#include "jpeg_nv12.h"
+#include "parser.h"
+#include "preprocess.h"
+
+extern "C" {
+
+void snhost_yuv420_to_yuv444(const unsigned char* in, unsigned char* out, int w, int h) {
+  hobot::stereonet::Tools::YUV420TOYUV444(in, out, w, h);
+}
+
+int snhost_quantize_byte(int b) {
+  return hobot::stereonet::PreProcess::Quantize(((float)b - 128.0) / 128.0);   // preprocess.cpp:1038 call-site form
+}
+
+// returns the JPEG size (<= cap) or -1
+long snhost_jpeg_nv12(const unsigned char* nv12, int w, int h, int pitch, int quality, unsigned char* out, long cap) {
+  std::vector<uint8_t> j;
+  if (!hobot::stereonet::EncodeNv12ToJpeg(nv12, w, h, pitch, quality, j) || (long)j.size() > cap) return -1;
+  memcpy(out, j.data(), j.size());
+  return (long)j.size();
+}
+
+// Parse() on a caller-provided int32 NCHW 1x1xhxw tensor
+int snhost_parse(const int32_t* raw, int w, int h, float scale, float* depth_m, float* disp_px) {
+  using namespace hobot::dnn_node;
+  auto out = std::make_shared<DnnNodeOutput>();
+  auto t = std::make_shared<DNNTensor>();
+  t->sysMem[0].virAddr = const_cast<int32_t*>(raw);
+  t->sysMem[0].memSize = (uint32_t)(4 * w * h);
+  const int32_t dims[4] = {1, 1, h, w};
+  for (int i = 0; i < 4; ++i) t->properties.validShape.dimensionSize[i] = dims[i];
+  t->properties.validShape.numDimensions = 4;
+  t->properties.tensorLayout = HB_DNN_LAYOUT_NCHW;
+  t->properties.tensorType = HB_DNN_TENSOR_TYPE_S32;
+  t->properties.scale.scaleLen = 1;
+  t->properties.scale.scaleData = &scale;
+  out->output_tensors.push_back(t);
+  std::vector<std::shared_ptr<hobot::stereonet::StereonetResult>> res;
+  if (hobot::stereonet::Parse(out, res) != 0 || res.empty()) return -1;
+  memcpy(depth_m, res[0]->results.data(), sizeof(float) * w * h);
+  memcpy(disp_px, res[0]->disparity.data(), sizeof(float) * w * h);
+  return 0;
+}
+
+}  // extern "C"

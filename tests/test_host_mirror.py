@@ -1,0 +1,133 @@
+"""Host C++ mirror of the reference node (hobot_stereonet_amd/csrc/compat): PreProcess / Parse / JPEG pure
+functions through ctypes on CPU; StereonetNode end to end through the in-process rclcpp stand-in on the GPU."""
+import ctypes as C
+import io
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from hobot_stereonet_amd import spec, synth, weights
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+COMPAT = os.path.join(ROOT, "hobot_stereonet_amd", "csrc", "compat")
+
+
+@pytest.fixture(scope="module")
+def hostlib():
+    from hobot_stereonet_amd import build
+    build.build()
+    subprocess.check_call(["make", "-C", COMPAT, "-s"])
+    lib = C.CDLL(os.path.join(COMPAT, "build", "libhobot_stereonet_node.so"))
+    vp, ci = C.c_void_p, C.c_int
+    lib.snhost_yuv420_to_yuv444.argtypes = [vp, vp, ci, ci]
+    lib.snhost_quantize_byte.argtypes = [ci]
+    lib.snhost_jpeg_nv12.restype = C.c_long
+    lib.snhost_jpeg_nv12.argtypes = [vp, ci, ci, ci, ci, vp, C.c_long]
+    lib.snhost_parse.argtypes = [vp, ci, ci, C.c_float, vp, vp]
+    return lib
+
+
+def test_host_yuv444_and_quantize_match_reference_vectors(hostlib, golden_pre):
+    for c in ("ramp8x4", "rand32x16", "rand64x36", "rand48x20"):
+        w, h = map(int, golden_pre[c + ".wh"])
+        src = np.ascontiguousarray(golden_pre[c + ".nv12"])
+        out = np.empty(3 * w * h, np.uint8)
+        hostlib.snhost_yuv420_to_yuv444(src.ctypes.data, out.ctypes.data, w, h)
+        assert (out == golden_pre[c + ".yuv444"]).all(), c
+    table = np.array([hostlib.snhost_quantize_byte(b) for b in range(256)], np.int8)
+    assert (table == golden_pre["quant_table"]).all()
+
+
+def test_host_parse_matches_oracle_and_reference_formula(hostlib, oracle):
+    w, h = 16, 4
+    raw = np.arange(1, w * h + 1, dtype=np.int32) * 3000
+    depth = np.empty(w * h, np.float32)
+    disp = np.empty(w * h, np.float32)
+    scale = C.c_float(spec.OUT_SCALE)
+    assert hostlib.snhost_parse(raw.ctypes.data, w, h, scale, depth.ctypes.data, disp.ctypes.data) == 0
+    odisp, odepth = oracle.dequant_depth(raw, spec.OUT_SCALE, 192.0)
+    np.testing.assert_allclose(disp, odisp, rtol=1e-6)
+    np.testing.assert_allclose(depth, odepth, rtol=1e-5)
+    # parser.cpp:84-86 by hand: int32 200000 -> 0.632 m
+    one = np.array([200000], np.int32)
+    assert hostlib.snhost_parse(one.ctypes.data, 1, 1, scale, depth.ctypes.data, disp.ctypes.data) == 0
+    assert abs(depth[0] - 0.632) < 1e-3 and abs(disp[0] - 100.01) < 1e-2
+
+
+def test_host_jpeg_decodes_to_the_source_image(hostlib):
+    from PIL import Image
+    w, h = 96, 64
+    left, _ = synth.stereo_pair_u8(w, h, 48, 2)
+    y = np.clip(left[0], 48, 208)          # keep RGB in gamut so the PIL round trip does not clip
+    uv = np.full((h // 2, w), 128, np.uint8)      # neutral chroma
+    uv[:, 0::2] = 90
+    uv[:, 1::2] = 170
+    nv12 = np.concatenate([y.ravel(), uv.ravel()])
+    buf = np.empty(w * h * 3, np.uint8)
+    n = hostlib.snhost_jpeg_nv12(nv12.ctypes.data, w, h, w, 95, buf.ctypes.data, buf.size)
+    assert n > 100
+    img = Image.open(io.BytesIO(buf[:n].tobytes()))
+    assert img.size == (w, h) and img.mode == "RGB"
+    ycc = np.asarray(img.convert("YCbCr"), np.float32)
+    assert np.abs(ycc[..., 0] - y).mean() < 2.0            # luma survives quality-95 quantisation
+    assert abs(ycc[..., 1].mean() - 90) < 3 and abs(ycc[..., 2].mean() - 170) < 3
+    # side-by-side source (pitch = 2w): the left half only
+    sbs = np.zeros((h * 3 // 2, 2 * w), np.uint8)
+    sbs[:h, :w] = y
+    sbs[h:, :w] = uv
+    n2 = hostlib.snhost_jpeg_nv12(sbs.ctypes.data, w, h, 2 * w, 95, buf.ctypes.data, buf.size)
+    img2 = np.asarray(Image.open(io.BytesIO(buf[:n2].tobytes())).convert("YCbCr"), np.float32)
+    assert np.abs(img2[..., 0] - y).mean() < 2.0
+
+
+def test_node_init_fails_loudly_without_gpu(hostlib, tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    m = str(tmp_path / "m.snw")
+    weights.save_snw(m, weights.synthetic(0), 96, 64, 48)
+    sbs = np.zeros((64 * 3 // 2) * 192, np.uint8)
+    sbs.tofile(str(tmp_path / "s.bin"))
+    r = subprocess.run([os.path.join(COMPAT, "build", "node_harness"), m, str(tmp_path / "s.bin"), "96", "64", "1",
+                        str(tmp_path / "o")], capture_output=True, text=True)
+    assert r.returncode == 3 and "Node init fail!" in r.stderr       # stereonet_node.cpp:44-48
+    # missing model file: SetNodePara's access() check (stereonet_node.cpp:131-134)
+    r = subprocess.run([os.path.join(COMPAT, "build", "node_harness"), str(tmp_path / "nope.snw"),
+                        str(tmp_path / "s.bin"), "96", "64", "1", str(tmp_path / "o")], capture_output=True, text=True)
+    assert r.returncode == 3 and "File is not exist" in r.stderr
+
+
+@pytest.mark.gpu
+def test_stereonet_node_end_to_end(hostlib, oracle, weights_blob, tmp_path):
+    """hbmem NV12 frame in -> /stereonet_node_output message out, payload = int32 tensor || JPEG(left)."""
+    from PIL import Image
+    w, h, d = 96, 64, 48
+    m = str(tmp_path / "m.snw")
+    weights.save_snw(m, weights_blob, w, h, d)
+    sbs = np.random.default_rng(8).integers(0, 256, (h * 3 // 2) * 2 * w, dtype=np.uint8)
+    sbs.tofile(str(tmp_path / "s.bin"))
+    nframes = 6          # > task_num: exercises the 4 in-flight slots
+    env = dict(os.environ, STEREONET_PRECISION="fp32")
+    r = subprocess.run([os.path.join(COMPAT, "build", "node_harness"), m, str(tmp_path / "s.bin"), str(w), str(h),
+                        str(nframes), str(tmp_path / "o")], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("frame_id=")]
+    assert len(lines) == nframes and f"received={nframes}" in r.stdout
+    assert [l.split()[0] for l in lines] == [f"frame_id={100 + i}" for i in range(nframes)]     # in order
+    assert all("encoding=jpeg" in l and f"height={h} width={w}" in l and "stamp=7." in l for l in lines)
+    # bad-encoding / bad-geometry frames were dropped, not published (stereonet_node.cpp:672-690)
+    left, right = oracle.split_sbs_nv12(sbs, w, h)
+    ten = oracle.preprocess_nv12(left, right, w, h)
+    odisp, oraw, _ = oracle.forward(weights_blob, ten, d)
+    for i in range(nframes):
+        payload = np.fromfile(str(tmp_path / f"o.{i}.msg"), dtype=np.uint8)
+        raw = payload[:w * h * 4].view(np.uint32).reshape(h, w)        # the render node's view (uint32)
+        disp = raw.astype(np.float64) * spec.OUT_SCALE * 16 * 12 * (d / 192.0)
+        assert np.abs(disp - odisp).mean() < 1e-3
+        assert np.abs(raw.astype(np.int64) - oraw).max() <= 170          # 170 quanta = 1e-3 px... scaled below
+        jpg = Image.open(io.BytesIO(payload[w * h * 4:].tobytes()))
+        assert jpg.size == (w, h)
+        y = np.asarray(jpg.convert("YCbCr"), np.float32)[..., 0]
+        assert np.abs(y - left[:w * h].reshape(h, w)).mean() < 6.0
