@@ -90,13 +90,13 @@ def main():
     x = torch.from_numpy(host).to(dev)
     raw = torch.empty((B, H, W), dtype=torch.int32, device=dev)
     disp = torch.empty((B, H, W), dtype=torch.float32, device=dev)
-    gathered = [torch.empty_like(raw) for _ in range(world)] if (world > 1 and rank == 0) else None
+    from hobot_stereonet_amd import dist as sdist
 
     def step():
         st = torch.cuda.current_stream().cuda_stream
         eng.infer_device(B, x.data_ptr(), raw.data_ptr(), disp.data_ptr(), st)
-        if world > 1:
-            dist.gather(raw, gathered, dst=0)
+        if world > 1:      # the path's one exchange: int32 disparity maps -> rank 0 (RCCL over xGMI)
+            sdist.gather_to_root(raw, [B] * world, dst=0)
 
     def sync_all():
         torch.cuda.synchronize()

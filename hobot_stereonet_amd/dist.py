@@ -1,0 +1,54 @@
+"""Multi-GPU data-parallel execution of the hot path: independent stereo pairs are sharded across ranks
+(one process per GPU), there is NO collective on the data path, and the only exchange is the final gather
+of the int32 disparity maps to rank 0 (RCCL over xGMI with backend "nccl", gloo on CPU in the tests).
+
+The reference has no multi-device path; the unit of work here is what it already treats
+as independent: one frame = one Run() (stereonet_infer/src/stereonet_node.cpp:144,812).
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous shard [begin, end) of n pairs for `rank`; the first n % world ranks get one extra pair."""
+    if n < 0 or world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad shard arguments")
+    q, r = divmod(n, world)
+    begin = rank * q + min(rank, r)
+    return begin, begin + q + (1 if rank < r else 0)
+
+
+def shard_counts(n: int, world: int) -> List[int]:
+    return [shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world)]
+
+
+def gather_to_root(local: torch.Tensor, counts: List[int], dst: int = 0) -> Optional[torch.Tensor]:
+    """Gathers per-rank [count_r, ...] tensors to `dst`, returning the [sum(counts), ...] tensor there
+    (None elsewhere).  Ragged shards are padded to the largest shard for the collective and trimmed."""
+    world = dist.get_world_size()
+    rank = dist.get_rank()
+    if len(counts) != world or local.shape[0] != counts[rank]:
+        raise ValueError("counts do not match the local shard")
+    cmax = max(counts)
+    send = local
+    if local.shape[0] != cmax:
+        send = torch.zeros((cmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        send[:local.shape[0]] = local
+    send = send.contiguous()
+    bufs = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+    dist.gather(send, bufs, dst=dst)
+    if rank != dst:
+        return None
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+
+
+def run_sharded(n: int, infer_shard: Callable[[int, int], torch.Tensor], dst: int = 0) -> Optional[torch.Tensor]:
+    """infer_shard(begin, end) -> tensor [end-begin, H, W] for this rank's pairs; returns all n maps on dst."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    begin, end = shard_range(n, rank, world)
+    local = infer_shard(begin, end)
+    return gather_to_root(local, shard_counts(n, world), dst)
