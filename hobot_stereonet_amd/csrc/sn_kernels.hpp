@@ -180,16 +180,26 @@ struct ConvArgs {
   int f16_Hs, f16_Ws;  // OUTF == 1 only: padded plane dims of the fp16 NCHW8c output
 };
 
-template <int KS, int STRIDE, int CH, int TR, int TC, class Loader, int OUTF = 0>
+template <int KS, int STRIDE, int DIL, int CH, int TR, int TC, class Loader, int OUTF = 0>
 __global__ __launch_bounds__(256) void k_conv_c32_mfma(ConvArgs a, Loader ld) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int TAPS = KS * KS;
   constexpr int CSEG = TC / 32;
   constexpr int NSEG = TR * CSEG;
   static_assert(NSEG % 4 == 0, "tile must split evenly over 4 waves");
+  static_assert(STRIDE == 1 || DIL == 1, "strided convs are not dilated");
   constexpr int SPW = NSEG / 4;
+  constexpr int ROWS_IN = (TR - 1) * STRIDE + (KS - 1) * DIL + 1;
+  constexpr int COLS_IN = (TC - 1) * STRIDE + (KS - 1) * DIL + 1;
+  constexpr int HALF = (COLS_IN + 1) / 2;
+  constexpr int PITCH = STRIDE == 1 ? COLS_IN : 2 * HALF;
+  constexpr int NELEM = CH * ROWS_IN * COLS_IN;          // input elements staged per chunk
+  constexpr int EPT = (NELEM + 255) / 256;               // ... per thread
+  constexpr int NW4 = CH * TAPS * 8;                     // float4s of weights per chunk
+  constexpr int WPT = (NW4 + 255) / 256;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nwg = a.tiles_x * a.tiles_y * a.nimg;
   const int b = xcd_remap(blockIdx.x, nwg);
   const int tx = b % a.tiles_x;
@@ -197,12 +207,8 @@ __global__ __launch_bounds__(256) void k_conv_c32_mfma(ConvArgs a, Loader ld) {
   const int ty = t2 % a.tiles_y;
   const int img = t2 / a.tiles_y;
 
-  const int rows_in = (TR - 1) * STRIDE + (KS - 1) * a.dil + 1;
-  const int cols_in = (TC - 1) * STRIDE + (KS - 1) * a.dil + 1;
-  const int half = (cols_in + 1) >> 1;
-  const int pitch = STRIDE == 1 ? cols_in : 2 * half;
   float* s_w = smem;                       // [CH][TAPS][32]
-  float* s_in = smem + CH * TAPS * 32;     // [CH][rows_in][pitch]
+  float* s_in = smem + CH * TAPS * 32;     // [CH][ROWS_IN][PITCH]
   const int iy0 = ty * TR * STRIDE - a.pad, ix0 = tx * TC * STRIDE - a.pad;
 
   f32x16 acc[SPW];
@@ -213,47 +219,81 @@ __global__ __launch_bounds__(256) void k_conv_c32_mfma(ConvArgs a, Loader ld) {
 
   const int kh = lane >> 5, j = lane & 31;
 
-  for (int c0 = 0; c0 < a.cin_pad; c0 += CH) {
-    __syncthreads();   // previous chunk fully consumed
-    {
-      const float4* wsrc = reinterpret_cast<const float4*>(a.wpk + (size_t)c0 * TAPS * 32);
-      float4* wdst = reinterpret_cast<float4*>(s_w);
-      for (int i = tid; i < CH * TAPS * 8; i += 256) wdst[i] = wsrc[i];
+  // Register staging (issue early / write late): all global loads of the NEXT chunk are issued
+  // back-to-back before the MFMAs of the current chunk and written to LDS after them, so HBM/L2
+  // latency is paid once per chunk and hidden under the matrix work.
+  float pre[EPT];
+  float4 wpre[WPT];
+  auto fetch = [&](int c0) {
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int idx = e * 256 + tid;
+      const int c = idx / (ROWS_IN * COLS_IN);
+      const int rem = idx - c * (ROWS_IN * COLS_IN);
+      const int r = rem / COLS_IN;
+      const int cc = rem - r * COLS_IN;
+      pre[e] = idx < NELEM ? ld(img, c0 + c, iy0 + r, ix0 + cc) : 0.f;
     }
-    for (int rr = wave; rr < CH * rows_in; rr += 4) {
-      const int c = rr / rows_in;
-      const int r = rr - c * rows_in;
-      float* dst = s_in + (size_t)rr * pitch;
-      const int gy = iy0 + r;
-      for (int cc = lane; cc < cols_in; cc += 64) {
-        const float v = ld(img, c0 + c, gy, ix0 + cc);
-        const int di = STRIDE == 1 ? cc : (cc & 1) * half + (cc >> 1);
-        dst[di] = v;
-      }
+    const float4* wsrc = reinterpret_cast<const float4*>(a.wpk + (size_t)c0 * TAPS * 32);
+#pragma unroll
+    for (int e = 0; e < WPT; ++e) {
+      const int idx = e * 256 + tid;
+      wpre[e] = idx < NW4 ? wsrc[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    __syncthreads();
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int idx = e * 256 + tid;
+      const int c = idx / (ROWS_IN * COLS_IN);
+      const int rem = idx - c * (ROWS_IN * COLS_IN);
+      const int r = rem / COLS_IN;
+      const int cc = rem - r * COLS_IN;
+      const int di = STRIDE == 1 ? cc : (cc & 1) * HALF + (cc >> 1);
+      if (idx < NELEM) s_in[(c * ROWS_IN + r) * PITCH + di] = pre[e];
+    }
+#pragma unroll
+    for (int e = 0; e < WPT; ++e) {
+      const int idx = e * 256 + tid;
+      if (idx < NW4) reinterpret_cast<float4*>(s_w)[idx] = wpre[e];
+    }
+  };
 
+  fetch(0);
+  commit();
+  __syncthreads();
+
+  for (int c0 = 0; c0 < a.cin_pad; c0 += CH) {
+    const bool more = c0 + CH < a.cin_pad;
+    if (more) fetch(c0 + CH);
+
+#pragma unroll 1
     for (int tap = 0; tap < TAPS; ++tap) {
       const int ky = tap / KS, kx = tap - ky * KS;
 #pragma unroll
       for (int kk = 0; kk < CH; kk += 2) {
         const float wa = s_w[((kk + kh) * TAPS + tap) * 32 + j];
-        const float* plane = s_in + (size_t)(kk + kh) * rows_in * pitch;
+        const float* plane = s_in + (kk + kh) * ROWS_IN * PITCH;
 #pragma unroll
         for (int s = 0; s < SPW; ++s) {
           const int seg = wave * SPW + s;
           const int srow = seg / CSEG, scol = (seg - srow * CSEG) * 32;
-          const int r = srow * STRIDE + ky * a.dil;
+          const int r = srow * STRIDE + ky * DIL;
           int di;
           if (STRIDE == 1) {
-            di = scol + j + kx * a.dil;
+            di = scol + j + kx * DIL;
           } else {
-            di = (kx & 1) * half + scol + j + (kx >> 1);   // dil == 1 for strided convs
+            di = (kx & 1) * HALF + scol + j + (kx >> 1);
           }
-          const float xb = plane[r * pitch + di];
+          const float xb = plane[r * PITCH + di];
           acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa, xb, acc[s], 0, 0, 0);
         }
       }
+    }
+    __syncthreads();     // everyone is done reading this chunk
+    if (more) {
+      commit();
+      __syncthreads();
     }
   }
 
@@ -593,6 +633,213 @@ __global__ __launch_bounds__(256, 2) void k_ref_conv_f16(const uint4* __restrict
     img = nimg_i;
     ty = nty;
     tx = ntx;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// v2 of the tower kernel: same tile math, deeper memory pipeline.
+//   * ring of THREE phase buffers; the DMA group of phase g+2 is issued right after the barrier that
+//     opens phase g, so one group is always in flight while another is being waited for;
+//   * raw s_barrier + hand-counted s_waitcnt vmcnt(N) (a __syncthreads() would drain the LDS-DMA queue).
+//     CDNA4 retires VMEM in order and counts stores on vmcnt, so every wave issues a CONSTANT number of
+//     VMEM ops per phase: KW DMA instructions per group (tail instructions re-fetch the last slots) and
+//     4*SPW unconditional 8-byte stores per tile (out-of-image pixels store zeros into the overhang,
+//     which must stay zero anyway).  At the top of phase g the ops younger than group g are exactly
+//     {group g+1} (+ the stores of the tile that just finished when g is even), hence
+//     N = KW (+ 4*SPW), and 0 for the very last phase.
+//   * TW = 32 for dilation 8 keeps three buffers inside the 160 KiB LDS.
+// ------------------------------------------------------------------------------------------
+template <int DIL, int TW_>
+struct RefTile2 {
+  static constexpr int TH = 8, TW = TW_;
+  static constexpr int CSEG = TW / 32, SPW = TH * CSEG / 4;
+  static constexpr int ROWS = TH + 2 * DIL, COLS = TW + 2 * DIL;
+  static constexpr int PLANE = ROWS * COLS;
+  static constexpr int HALF = 2 * PLANE;
+  static constexpr int NINST = (HALF + 63) / 64;
+  static constexpr int KW = (NINST + 3) / 4;            // DMA instructions per wave per group (constant)
+  static constexpr int BUF = NINST * 64;
+  static constexpr int NBUF = 3;
+  static constexpr int LDS_BYTES = NBUF * BUF * 16;
+  static constexpr int NSTORE = 4 * SPW;
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int DIL, int TW>
+__device__ __forceinline__ void ref2_issue_dma(const uint4* __restrict__ in, uint4* lds_buf, const RefGeom& g,
+                                               int img, int y0, int x0, int kk, int wave, int lane) {
+  using T = RefTile2<DIL, TW>;
+#pragma unroll
+  for (int k = 0; k < T::KW; ++k) {
+    int i = wave + 4 * k;
+    i = i < T::NINST ? i : T::NINST - 1;                 // constant op count per wave: repeat the last chunk
+    int s = i * 64 + lane;
+    s = s < T::HALF ? s : T::HALF - 1;
+    const int pc = s / T::PLANE;
+    const int rem = s - pc * T::PLANE;
+    const int r = rem / T::COLS;
+    const int c = rem - r * T::COLS;
+    const size_t slot = (((size_t)img * 4 + (2 * kk + pc)) * g.Hs + (y0 + r - DIL + kRefPad)) * g.Ws +
+                        (x0 + c - DIL + kRefPad);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(in + slot),
+                                     (__attribute__((address_space(3))) void*)(lds_buf + i * 64), 16, 0, 0);
+  }
+}
+
+template <int DIL, int TW, int KK>
+__device__ __forceinline__ void ref2_compute(const uint4* lds_lane, const half8 (&wf)[18],
+                                             f32x16 (&acc)[RefTile2<DIL, TW>::SPW]) {
+  using T = RefTile2<DIL, TW>;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+    for (int s = 0; s < T::SPW; ++s) {
+      const int off = ((s / T::CSEG) + ky * DIL) * T::COLS + (s % T::CSEG) * 32 + kx * DIL;
+      const half8 xb = *reinterpret_cast<const half8*>(lds_lane + off);
+      acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[tap * 2 + KK], xb, acc[s], 0, 0, 0);
+    }
+  }
+}
+
+template <int DIL, int TW, bool RES>
+__global__ __launch_bounds__(256, 2) void k_ref_conv_f16_v2(const uint4* __restrict__ in, uint4* out,
+                                                            const uint4* res, const uint4* __restrict__ wfrag,
+                                                            const float* __restrict__ bias, RefGeom g, int nimg,
+                                                            int lrelu) {
+  using T = RefTile2<DIL, TW>;
+  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, gh = lane >> 5;
+
+  half8 wf[18];
+#pragma unroll
+  for (int i = 0; i < 18; ++i) {
+    const uint4 v = wfrag[i * 64 + lane];
+    wf[i] = *reinterpret_cast<const half8*>(&v);
+  }
+  float bv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bv[r] = bias[(r & 3) + 8 * (r >> 2) + 4 * gh];
+  // Consume the ordinary loads HERE so that hipcc's own vmcnt bookkeeping is clean before the loop;
+  // otherwise it re-inserts s_waitcnt vmcnt(0) at the first MFMA of every iteration (loop-header merge)
+  // and drains the LDS-DMA ring.
+#pragma unroll
+  for (int i = 0; i < 18; ++i) asm volatile("" : "+v"(wf[i]));
+#pragma unroll
+  for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(bv[r]));
+
+  const int per_img = g.tiles_x * g.tiles_y;
+  const int total = per_img * nimg;
+  const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, nlb = gridDim.x >> 3;
+  const int t_begin = (int)((long)xcd * total / 8), t_end = (int)((long)(xcd + 1) * total / 8);
+  const int t0 = t_begin + lb;
+  if (t0 >= t_end) return;
+  const int ntiles = (t_end - t0 + nlb - 1) / nlb;
+  const int G = 2 * ntiles;                                  // phases of this block
+
+  const int seg0 = wave * T::SPW;
+  const int lane_off = gh * T::PLANE + (seg0 / T::CSEG) * T::COLS + j;
+
+  auto tile_xy = [&](int ti, int& img, int& y0, int& x0) {
+    const int t = t0 + ti * nlb;
+    img = t / per_img;
+    const int rem = t - img * per_img;
+    const int ty = rem / g.tiles_x;
+    y0 = ty * T::TH;
+    x0 = (rem - ty * g.tiles_x) * T::TW;
+  };
+  auto issue = [&](int gp) {                                  // DMA group of phase gp into ring slot gp % 3
+    int img, y0, x0;
+    tile_xy(gp >> 1, img, y0, x0);
+    ref2_issue_dma<DIL, TW>(in, lds + (gp % 3) * T::BUF, g, img, y0, x0, gp & 1, wave, lane);
+  };
+
+  wait_vmcnt<0>();
+  issue(0);
+  issue(1);
+
+  f32x16 acc[T::SPW];
+  for (int ti = 0; ti < ntiles; ++ti) {
+    int img, y0, x0;
+    tile_xy(ti, img, y0, x0);
+    const int g0 = 2 * ti;
+    // ---- phase g0 (channels 0..15) ----
+    if (ti == 0) wait_vmcnt<T::KW>();                         // younger than group 0: group 1
+    else wait_vmcnt<T::KW + T::NSTORE>();                     // ... plus the previous tile's stores
+    __builtin_amdgcn_s_barrier();
+    if (g0 + 2 < G) issue(g0 + 2);
+#pragma unroll
+    for (int s = 0; s < T::SPW; ++s)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+    ref2_compute<DIL, TW, 0>(lds + (g0 % 3) * T::BUF + lane_off, wf, acc);
+
+    // ---- phase g0+1 (channels 16..31) ----
+    if (g0 + 2 < G) wait_vmcnt<T::KW>();                      // younger than group g0+1: group g0+2
+    else wait_vmcnt<0>();                                     // last phase of this block
+    __builtin_amdgcn_s_barrier();
+
+    // residual: NSTORE 8-byte loads issued as inline asm BEFORE the next DMA group, so they are older
+    // than it and the counted wait below (all but the newest KW ops) retires them without draining
+    // the ring.  hipcc does not track asm loads: the "+v" wait statement is what orders their use.
+    char* obase[T::SPW];
+    uint2 rres[RES ? T::NSTORE : 1];
+#pragma unroll
+    for (int s = 0; s < T::SPW; ++s) {
+      const int seg = seg0 + s;
+      const int y = y0 + seg / T::CSEG, x = x0 + (seg % T::CSEG) * 32 + j;
+      const size_t slot0 = ((size_t)img * 4 * g.Hs + (y + kRefPad)) * g.Ws + (x + kRefPad);
+      obase[s] = reinterpret_cast<char*>(out) + slot0 * 16 + gh * 8;
+      if (RES) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const char* rp = reinterpret_cast<const char*>(res) + (slot0 + (size_t)q * g.Hs * g.Ws) * 16 + gh * 8;
+          asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rres[RES ? s * 4 + q : 0]) : "v"(rp) : "memory");
+        }
+      }
+    }
+    const bool more = g0 + 3 < G;
+    if (more) issue(g0 + 3);
+    ref2_compute<DIL, TW, 1>(lds + ((g0 + 1) % 3) * T::BUF + lane_off, wf, acc);
+    if (RES) {
+      if (more) wait_vmcnt<T::KW>(); else wait_vmcnt<0>();
+#pragma unroll
+      for (int i = 0; i < T::NSTORE; ++i) asm volatile("" : "+v"(rres[i]));
+    }
+
+    // ---- epilogue: exactly NSTORE stores per wave; out-of-image pixels store zeros ----
+#pragma unroll
+    for (int s = 0; s < T::SPW; ++s) {
+      const int seg = seg0 + s;
+      const int y = y0 + seg / T::CSEG, x = x0 + (seg % T::CSEG) * 32 + j;
+      const bool ok = y < g.H && x < g.W;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[s][4 * q + e] + bv[4 * q + e];
+        if (RES) {
+          const uint2 rw = rres[RES ? s * 4 + q : 0];
+          const half4 rv = *reinterpret_cast<const half4*>(&rw);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+        }
+        half4 hv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float u = v[e];
+          if (lrelu) u = u > 0.f ? u : u * kSlope;
+          hv[e] = ok ? (_Float16)u : (_Float16)0.f;
+        }
+        *reinterpret_cast<half4*>(obase[s] + (size_t)q * g.Hs * g.Ws * 16) = hv;
+      }
+    }
   }
 }
 

@@ -10,6 +10,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -197,9 +198,10 @@ int upload_head(sn_handle* h, const HostLayer& l, HeadLayer* out) {   // [1][32]
 }
 
 // ---- convolution launcher ------------------------------------------------------------------------
-template <int KS, int STRIDE, int CH, int TR, int TC, class Loader, int OUTF = 0>
+template <int KS, int STRIDE, int DIL, int CH, int TR, int TC, class Loader, int OUTF = 0>
 hipError_t launch_conv(hipStream_t st, const ConvLayer& L, const Loader& ld, int nimg, int Ho, int Wo,
-                       int dil, float* out, const float* res, bool lrelu, int f16_Hs = 0, int f16_Ws = 0) {
+                       float* out, const float* res, bool lrelu, int f16_Hs = 0, int f16_Ws = 0) {
+  constexpr int dil = DIL;
   ConvArgs a;
   a.f16_Hs = f16_Hs;
   a.f16_Ws = f16_Ws;
@@ -220,7 +222,7 @@ hipError_t launch_conv(hipStream_t st, const ConvLayer& L, const Loader& ld, int
   const int cols_in = (TC - 1) * STRIDE + (KS - 1) * dil + 1;
   const int pitch = STRIDE == 1 ? cols_in : 2 * ((cols_in + 1) / 2);
   const size_t lds = ((size_t)CH * KS * KS * 32 + (size_t)CH * rows_in * pitch) * sizeof(float);
-  auto kern = k_conv_c32_mfma<KS, STRIDE, CH, TR, TC, Loader, OUTF>;
+  auto kern = k_conv_c32_mfma<KS, STRIDE, DIL, CH, TR, TC, Loader, OUTF>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -232,20 +234,32 @@ hipError_t launch_conv(hipStream_t st, const ConvLayer& L, const Loader& ld, int
 }
 
 // 3x3 C->C conv on a plain NCHW fp32 tensor; tile shape chosen from image size and dilation
+template <int DIL>
+hipError_t conv3x3_d(hipStream_t st, const ConvLayer& L, const float* in, int nimg, int H, int W, float* out,
+                     const float* res, bool lrelu) {
+  LoadF32 ld{in, kC, H, W};
+  if (H * W <= 64 * 128) return launch_conv<3, 1, DIL, 8, 4, 32>(st, L, ld, nimg, H, W, out, res, lrelu);
+  if (DIL >= 4) return launch_conv<3, 1, DIL, 4, 16, 64>(st, L, ld, nimg, H, W, out, res, lrelu);
+  return launch_conv<3, 1, DIL, 8, 8, 64>(st, L, ld, nimg, H, W, out, res, lrelu);
+}
+
 hipError_t conv3x3(hipStream_t st, const ConvLayer& L, const float* in, int nimg, int H, int W, int dil,
                    float* out, const float* res, bool lrelu) {
-  LoadF32 ld{in, kC, H, W};
-  if (H * W <= 64 * 128) return launch_conv<3, 1, 8, 4, 32>(st, L, ld, nimg, H, W, dil, out, res, lrelu);
-  if (dil >= 4) return launch_conv<3, 1, 4, 16, 64>(st, L, ld, nimg, H, W, dil, out, res, lrelu);
-  return launch_conv<3, 1, 8, 8, 64>(st, L, ld, nimg, H, W, dil, out, res, lrelu);
+  switch (dil) {
+    case 1: return conv3x3_d<1>(st, L, in, nimg, H, W, out, res, lrelu);
+    case 2: return conv3x3_d<2>(st, L, in, nimg, H, W, out, res, lrelu);
+    case 4: return conv3x3_d<4>(st, L, in, nimg, H, W, out, res, lrelu);
+    case 8: return conv3x3_d<8>(st, L, in, nimg, H, W, out, res, lrelu);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 hipError_t conv5x5s2(hipStream_t st, const ConvLayer& L, const float* in, int nimg, int Hin, int Win,
                      float* out) {
   LoadF32 ld{in, kC, Hin, Win};
   const int Ho = Hin / 2, Wo = Win / 2;
-  if (Ho * Wo <= 64 * 128) return launch_conv<5, 2, 4, 4, 32>(st, L, ld, nimg, Ho, Wo, 1, out, nullptr, false);
-  return launch_conv<5, 2, 4, 8, 64>(st, L, ld, nimg, Ho, Wo, 1, out, nullptr, false);
+  if (Ho * Wo <= 64 * 128) return launch_conv<5, 2, 1, 4, 4, 32>(st, L, ld, nimg, Ho, Wo, out, nullptr, false);
+  return launch_conv<5, 2, 1, 4, 8, 64>(st, L, ld, nimg, Ho, Wo, out, nullptr, false);
 }
 
 // ---- fp16 refinement tower -------------------------------------------------------------------------
@@ -301,8 +315,44 @@ hipError_t launch_ref_f16(hipStream_t st, const RefLayerF16& L, const RefGeom& g
   return hipGetLastError();
 }
 
+template <int DIL, int TW>
+hipError_t launch_ref_f16_v2(hipStream_t st, const RefLayerF16& L, const RefGeom& g, int num_cu, const uint4* in,
+                             uint4* out, const uint4* res, int nimg, bool lrelu) {
+  using T = RefTile2<DIL, TW>;
+  auto kern = res ? k_ref_conv_f16_v2<DIL, TW, true> : k_ref_conv_f16_v2<DIL, TW, false>;
+  if (T::LDS_BYTES > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
+    if (e != hipSuccess) return e;
+  }
+  RefGeom gt = g;                      // tile grid of this variant (the buffer geometry is for 8x64 tiles)
+  gt.tiles_x = (g.W + TW - 1) / TW;
+  const int total = gt.tiles_x * gt.tiles_y * nimg;
+  const int per_cu = T::LDS_BYTES * 2 <= 160 * 1024 ? 2 : 1;
+  int blocks = num_cu * per_cu;
+  if (blocks > total) blocks = total;
+  blocks = (blocks + 7) / 8 * 8;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), T::LDS_BYTES, st, in, out, res, L.wfrag, L.bias, gt, nimg,
+                     lrelu ? 1 : 0);
+  return hipGetLastError();
+}
+
+bool use_ref_v1() {
+  static const bool v = getenv("SN_REF_V1") != nullptr;   // A/B switch for the first-generation tower kernel
+  return v;
+}
+
 hipError_t ref_conv_f16(hipStream_t st, const RefLayerF16& L, const RefGeom& g, int num_cu, int dil, const uint4* in,
                         uint4* out, const uint4* res, int nimg, bool lrelu) {
+  if (!use_ref_v1()) {
+    switch (dil) {
+      case 1: return launch_ref_f16_v2<1, 64>(st, L, g, num_cu, in, out, res, nimg, lrelu);
+      case 2: return launch_ref_f16_v2<2, 64>(st, L, g, num_cu, in, out, res, nimg, lrelu);
+      case 4: return launch_ref_f16_v2<4, 64>(st, L, g, num_cu, in, out, res, nimg, lrelu);
+      case 8: return launch_ref_f16_v2<8, 32>(st, L, g, num_cu, in, out, res, nimg, lrelu);
+      default: return hipErrorInvalidValue;
+    }
+  }
   switch (dil) {
     case 1: return launch_ref_f16<1>(st, L, g, num_cu, in, out, res, nimg, lrelu);
     case 2: return launch_ref_f16<2>(st, L, g, num_cu, in, out, res, nimg, lrelu);
@@ -369,9 +419,9 @@ int forward(sn_handle* h, Workspace& ws, hipStream_t st, int n, const int8_t* in
     LoadI8Eye ld{in6, h->H, h->W};
     const int Ho = Hp / 2, Wo = Wp / 2;
     if (Ho * Wo <= 64 * 128)
-      HIP_TRY(h, (launch_conv<5, 2, 4, 4, 32>(st, h->down[0], ld, 2 * n, Ho, Wo, 1, ws.down[0], nullptr, false)));
+      HIP_TRY(h, (launch_conv<5, 2, 1, 4, 4, 32>(st, h->down[0], ld, 2 * n, Ho, Wo, ws.down[0], nullptr, false)));
     else
-      HIP_TRY(h, (launch_conv<5, 2, 4, 8, 64>(st, h->down[0], ld, 2 * n, Ho, Wo, 1, ws.down[0], nullptr, false)));
+      HIP_TRY(h, (launch_conv<5, 2, 1, 4, 8, 64>(st, h->down[0], ld, 2 * n, Ho, Wo, ws.down[0], nullptr, false)));
   }
   HIP_TRY(h, conv5x5s2(st, h->down[1], ws.down[0], 2 * n, Hp / 2, Wp / 2, ws.down[1]));
   HIP_TRY(h, conv5x5s2(st, h->down[2], ws.down[1], 2 * n, Hp / 4, Wp / 4, ws.down[2]));
@@ -388,10 +438,10 @@ int forward(sn_handle* h, Workspace& ws, hipStream_t st, int n, const int8_t* in
   // --- cost volume (fused into the first 3-D conv's loader) + 3-D aggregation + soft-argmin ---
   {
     LoadCostVol ld{ws.feat, Dl, hl, wl};
-    HIP_TRY(h, (launch_conv<3, 1, 8, 4, 32>(st, h->agg[0], ld, n * Dl, hl, wl, 1, ws.vol[0], nullptr, true)));
+    HIP_TRY(h, (launch_conv<3, 1, 1, 8, 4, 32>(st, h->agg[0], ld, n * Dl, hl, wl, ws.vol[0], nullptr, true)));
     for (int i = 1; i < kNAgg; ++i) {
       LoadVol3D lv{ws.vol[(i - 1) & 1], Dl, hl, wl};
-      HIP_TRY(h, (launch_conv<3, 1, 8, 4, 32>(st, h->agg[i], lv, n * Dl, hl, wl, 1, ws.vol[i & 1], nullptr, true)));
+      HIP_TRY(h, (launch_conv<3, 1, 1, 8, 4, 32>(st, h->agg[i], lv, n * Dl, hl, wl, ws.vol[i & 1], nullptr, true)));
     }
     const float* v = ws.vol[(kNAgg - 1) & 1];
     const int npix = n * hl * wl;
@@ -413,9 +463,9 @@ int forward(sn_handle* h, Workspace& ws, hipStream_t st, int n, const int8_t* in
       float* rx = ws.ref[0];
       float* rt = ws.ref[1];
       if (Hp * Wp <= 64 * 128)
-        HIP_TRY(h, (launch_conv<3, 1, 4, 4, 32>(st, h->rin, ld, m, Hp, Wp, 1, rx, nullptr, true)));
+        HIP_TRY(h, (launch_conv<3, 1, 1, 4, 4, 32>(st, h->rin, ld, m, Hp, Wp, rx, nullptr, true)));
       else
-        HIP_TRY(h, (launch_conv<3, 1, 4, 8, 64>(st, h->rin, ld, m, Hp, Wp, 1, rx, nullptr, true)));
+        HIP_TRY(h, (launch_conv<3, 1, 1, 4, 8, 64>(st, h->rin, ld, m, Hp, Wp, rx, nullptr, true)));
       if (prof && p0 == 0) HIP_TRY(h, hipEventRecord(h->ev[4], st));
       for (int i = 0; i < kNRefRes; ++i) {
         HIP_TRY(h, conv3x3(st, h->rres[i][0], rx, m, Hp, Wp, kRefDil[i], rt, nullptr, true));
@@ -435,10 +485,10 @@ int forward(sn_handle* h, Workspace& ws, hipStream_t st, int n, const int8_t* in
       uint4* rt = ws.ref16[1];
       const RefGeom& g = h->rg;
       if (Hp * Wp <= 64 * 128)
-        HIP_TRY(h, (launch_conv<3, 1, 4, 4, 32, LoadRefineIn, 1>(st, h->rin, ld, m, Hp, Wp, 1, reinterpret_cast<float*>(rx),
+        HIP_TRY(h, (launch_conv<3, 1, 1, 4, 4, 32, LoadRefineIn, 1>(st, h->rin, ld, m, Hp, Wp, reinterpret_cast<float*>(rx),
                                                                   nullptr, true, g.Hs, g.Ws)));
       else
-        HIP_TRY(h, (launch_conv<3, 1, 4, 8, 64, LoadRefineIn, 1>(st, h->rin, ld, m, Hp, Wp, 1, reinterpret_cast<float*>(rx),
+        HIP_TRY(h, (launch_conv<3, 1, 1, 4, 8, 64, LoadRefineIn, 1>(st, h->rin, ld, m, Hp, Wp, reinterpret_cast<float*>(rx),
                                                                   nullptr, true, g.Hs, g.Ws)));
       if (prof && p0 == 0) HIP_TRY(h, hipEventRecord(h->ev[4], st));
       for (int i = 0; i < kNRefRes; ++i) {
@@ -936,11 +986,12 @@ int sn_dbg_conv2d(sn_handle* h, const float* in, int cin, int h_px, int w, const
   LoadF32 ld{din, cin, h_px, w};
   hipError_t e;
   if (k == 5) {
-    e = (Ho * Wo <= 64 * 128) ? launch_conv<5, 2, 4, 4, 32>(st, L, ld, 1, Ho, Wo, 1, dout, dres, lrelu != 0)
-                              : launch_conv<5, 2, 4, 8, 64>(st, L, ld, 1, Ho, Wo, 1, dout, dres, lrelu != 0);
+    e = (Ho * Wo <= 64 * 128) ? launch_conv<5, 2, 1, 4, 4, 32>(st, L, ld, 1, Ho, Wo, dout, dres, lrelu != 0)
+                              : launch_conv<5, 2, 1, 4, 8, 64>(st, L, ld, 1, Ho, Wo, dout, dres, lrelu != 0);
   } else if (cin <= 4) {
-    e = (Ho * Wo <= 64 * 128) ? launch_conv<3, 1, 4, 4, 32>(st, L, ld, 1, Ho, Wo, dil, dout, dres, lrelu != 0)
-                              : launch_conv<3, 1, 4, 8, 64>(st, L, ld, 1, Ho, Wo, dil, dout, dres, lrelu != 0);
+    if (dil != 1) return SN_ERR_ARG;
+    e = (Ho * Wo <= 64 * 128) ? launch_conv<3, 1, 1, 4, 4, 32>(st, L, ld, 1, Ho, Wo, dout, dres, lrelu != 0)
+                              : launch_conv<3, 1, 1, 4, 8, 64>(st, L, ld, 1, Ho, Wo, dout, dres, lrelu != 0);
   } else {
     e = conv3x3(st, L, din, 1, h_px, w, dil, dout, dres, lrelu != 0);
   }
@@ -973,7 +1024,7 @@ int sn_dbg_conv3d(sn_handle* h, const float* in, int d, int h_px, int w, const f
   HIP_TRY(h, dalloc(&dout, n));
   HIP_TRY(h, hipMemcpy(din, tmp.data(), n * 4, hipMemcpyHostToDevice));
   LoadVol3D lv{din, d, h_px, w};
-  HIP_TRY(h, (launch_conv<3, 1, 8, 4, 32>(h->stream, L, lv, d, h_px, w, 1, dout, nullptr, lrelu != 0)));
+  HIP_TRY(h, (launch_conv<3, 1, 1, 8, 4, 32>(h->stream, L, lv, d, h_px, w, dout, nullptr, lrelu != 0)));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   HIP_TRY(h, hipMemcpy(tmp.data(), dout, n * 4, hipMemcpyDeviceToHost));
   for (int co = 0; co < kC; ++co)
