@@ -51,8 +51,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=8, help="pairs per GPU per step")
-    ap.add_argument("--refine-chunk", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=64, help="pairs per GPU per step")
+    ap.add_argument("--refine-chunk", type=int, default=2)
     ap.add_argument("--precision", choices=["fp32", "f16"], default="f16",
                     help="arithmetic of the refinement-tower contractions (the low-res branch is always fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -329,9 +329,17 @@ hipError_t launch_ref_f16_v2(hipStream_t st, const RefLayerF16& L, const RefGeom
   gt.tiles_x = (g.W + TW - 1) / TW;
   const int total = gt.tiles_x * gt.tiles_y * nimg;
   const int per_cu = T::LDS_BYTES * 2 <= 160 * 1024 ? 2 : 1;
-  int blocks = num_cu * per_cu;
-  if (blocks > total) blocks = total;
-  blocks = (blocks + 7) / 8 * 8;
+  // persistent grid: 8 XCD bands; pick the block count per band so that every block walks the same number
+  // of tiles (e.g. 225 tiles per band -> 57 blocks x 4 tiles, not 64 blocks x 3.5)
+  const int band = (total + 7) / 8;
+  int cap = num_cu * per_cu / 8;
+  static const int cap_env = getenv("SN_REF_NLB") ? atoi(getenv("SN_REF_NLB")) : 0;
+  if (cap_env > 0) cap = cap_env;
+  if (cap < 1) cap = 1;
+  const int rounds = (band + cap - 1) / cap;
+  int nlb = (band + rounds - 1) / rounds;
+  if (cap_env > 0) nlb = cap_env < band ? cap_env : band;
+  const int blocks = nlb * 8;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), T::LDS_BYTES, st, in, out, res, L.wfrag, L.bias, gt, nimg,
                      lrelu ? 1 : 0);
   return hipGetLastError();
@@ -610,7 +618,7 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
   h->max_batch = c.max_batch > 0 ? c.max_batch : 1;
   h->precision = c.precision;
   h->task_num = c.task_num > 0 ? c.task_num : 4;
-  h->refine_chunk = c.refine_chunk > 0 ? c.refine_chunk : 1;
+  h->refine_chunk = c.refine_chunk > 0 ? c.refine_chunk : 2;   // 2 pairs per tower launch measured best
   h->rg = make_ref_geom(h->Hp, h->Wp);
   h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (h->refine_chunk > h->max_batch) h->refine_chunk = h->max_batch;
