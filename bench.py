@@ -46,6 +46,23 @@ def cpu_baseline(blob, x_one):
             "ms_per_frame": med * 1e3}
 
 
+def pmc_traffic(kernel_match="k_ref_conv_f16"):
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary
+    (profiles/r*_pmc_traffic.json, made by scripts/pmc_traffic.py from separate rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE passes with the gfx950 2x FETCH correction).  None if no summary matches."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+    except Exception:
+        return None, None
+    if d.get("dominant_match") != kernel_match or not d.get("dominant_avg_hbm_bytes_per_launch"):
+        return None, None
+    return float(d["dominant_avg_hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -55,6 +72,7 @@ def main():
     ap.add_argument("--refine-chunk", type=int, default=2)
     ap.add_argument("--precision", choices=["fp32", "f16"], default="f16",
                     help="arithmetic of the refinement-tower contractions (the low-res branch is always fp32)")
+    ap.add_argument("--piece", type=int, default=8, help="pairs per low-res piece of the two-stream pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -80,7 +98,8 @@ def main():
     model = os.path.join(tmp, "bench.snw")
     weights.save_snw(model, blob, W, H, D)
     prec = api.PREC_F16 if args.precision == "f16" else api.PREC_FP32
-    eng = api.StereoNetHIP(model, device=local_rank, max_batch=B, refine_chunk=args.refine_chunk, precision=prec)
+    eng = api.StereoNetHIP(model, device=local_rank, max_batch=B, refine_chunk=args.refine_chunk, precision=prec,
+                           piece=args.piece)
 
     # synthetic shard for this rank: distinct seeds per pair; a few distinct pairs tiled to B
     uniq = min(B, 4)
@@ -139,7 +158,13 @@ def main():
                     "frac": tflops / MFMA_F32_PEAK_TFLOPS}
         else:                            # fp16 MFMA at AI ~ 125 FLOP/B: HBM-bound
             roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
-        roof.update({"traffic": None, "kernel": dk["name"], "avg_launch_ms": launch_ms,
+        traffic, traffic_src = (None, None)
+        if args.precision == "f16":
+            traffic, traffic_src = pmc_traffic()
+            if traffic is not None:
+                traffic *= args.refine_chunk / 1.0 if False else 1.0   # summary is per 1-pair launch; see traffic_pairs
+        roof.update({"traffic": traffic, "traffic_unit": "HBM bytes per 1-pair launch (PMC, 2xFETCH_SIZE+WRITE_SIZE)",
+                     "traffic_source": traffic_src, "kernel": dk["name"], "avg_launch_ms": launch_ms,
                      "launches_per_refine_chunk": dk["launches"], "algorithmic_bytes_per_launch": dk["bytes_per_launch"],
                      "algorithmic_flops_per_launch": dk["flops_per_launch"], "tflops": tflops, "gbytes_per_s": gbs,
                      "mfma_peak_tflops": MFMA_F16_PEAK_TFLOPS if args.precision == "f16" else MFMA_F32_PEAK_TFLOPS})
@@ -156,7 +181,7 @@ def main():
             "data": "synthetic (seeded stereo pairs, seeded random SN-K4 weights)",
             "config": {"workload": f"BASELINE configs[1]/[2] shape: 1280x720 D=192, {B} synthetic pairs/GPU/step resident in HBM",
                        "pairs_per_gpu_per_step": B, "width": W, "height": H, "dmax": D, "precision": args.precision,
-                       "refine_chunk": args.refine_chunk, "parallelism": f"shard{world}+rccl-gather" if world > 1 else "1gpu"},
+                       "refine_chunk": args.refine_chunk, "piece": args.piece, "parallelism": f"shard{world}+rccl-gather" if world > 1 else "1gpu"},
             "gflop_per_pair": eng.flops_per_pair / 1e9,
             "model_tflops": value * eng.flops_per_pair / 1e12 / world,
             "stage_ms_per_step": stage,

@@ -24,7 +24,8 @@ STAGES = ("features", "aggregate", "refine", "refine_conv", "total")
 
 class SnConfig(C.Structure):
     _fields_ = [("device", C.c_int), ("max_batch", C.c_int), ("width", C.c_int), ("height", C.c_int),
-                ("dmax", C.c_int), ("precision", C.c_int), ("task_num", C.c_int), ("refine_chunk", C.c_int)]
+                ("dmax", C.c_int), ("precision", C.c_int), ("task_num", C.c_int), ("refine_chunk", C.c_int),
+                ("piece", C.c_int)]
 
 
 class SnIoInfo(C.Structure):
@@ -74,10 +75,11 @@ def load_library(path: Optional[str] = None):
     lib.sn_dbg_conv2d.argtypes = [vp, fp, ip, ip, ip, fp, fp, ip, ip, ip, ip, fp, fp]
     lib.sn_dbg_conv3d.argtypes = [vp, fp, ip, ip, ip, fp, fp, ip, fp]
     lib.sn_dbg_ref_conv_f16.argtypes = [vp, fp, ip, ip, fp, fp, ip, ip, fp, fp]
+    lib.sn_dbg_ref_block_f16.argtypes = [vp, fp, ip, ip, fp, fp, fp, fp, ip, fp]
     lib.sn_dbg_read.argtypes = [vp, C.c_char_p, fp, C.c_size_t, C.POINTER(C.c_size_t)]
     for name in ("sn_create", "sn_destroy", "sn_get_io_info", "sn_infer_i8", "sn_infer_batch", "sn_preprocess_nv12",
                  "sn_infer_sbs_nv12", "sn_submit", "sn_wait", "sn_synchronize", "sn_set_profiling",
-                 "sn_get_stage_ms", "sn_get_dominant_kernel", "sn_dbg_conv2d", "sn_dbg_conv3d", "sn_dbg_ref_conv_f16", "sn_dbg_read"):
+                 "sn_get_stage_ms", "sn_get_dominant_kernel", "sn_dbg_conv2d", "sn_dbg_conv3d", "sn_dbg_ref_conv_f16", "sn_dbg_ref_block_f16", "sn_dbg_read"):
         getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
@@ -95,10 +97,11 @@ class StereoNetHIP:
     """One GPU's StereoNet engine (sn_handle)."""
 
     def __init__(self, model_file: str, device: int = -1, max_batch: int = 1, width: int = 0, height: int = 0,
-                 dmax: int = 0, precision: int = PREC_FP32, task_num: int = 4, refine_chunk: int = 0):
+                 dmax: int = 0, precision: int = PREC_FP32, task_num: int = 4, refine_chunk: int = 0,
+                 piece: int = 0):
         self._lib = load_library()
         self._h = C.c_void_p()
-        cfg = SnConfig(device, max_batch, width, height, dmax, precision, task_num, refine_chunk)
+        cfg = SnConfig(device, max_batch, width, height, dmax, precision, task_num, refine_chunk, piece)
         rc = self._lib.sn_create(model_file.encode(), C.byref(cfg), C.byref(self._h))
         if rc != 0:
             self._h = C.c_void_p()
@@ -242,6 +245,15 @@ class StereoNetHIP:
         res = np.ascontiguousarray(residual, np.float32) if residual is not None else None
         self._check(self._lib.sn_dbg_ref_conv_f16(self._h, x.ctypes.data, h, w, wt.ctypes.data, bias.ctypes.data, dil,
                                                   int(lrelu), _np_ptr(res), out.ctypes.data), "sn_dbg_ref_conv_f16")
+        return out
+
+    def dbg_ref_block_f16(self, x, w1, b1, w2, b2, dil=1):
+        a = [np.ascontiguousarray(v, np.float32) for v in (x, w1, b1, w2, b2)]
+        _, h, w = a[0].shape
+        out = np.empty((32, h, w), np.float32)
+        self._check(self._lib.sn_dbg_ref_block_f16(self._h, a[0].ctypes.data, h, w, a[1].ctypes.data, a[2].ctypes.data,
+                                                   a[3].ctypes.data, a[4].ctypes.data, dil, out.ctypes.data),
+                    "sn_dbg_ref_block_f16")
         return out
 
     def dbg_read(self, what: str) -> np.ndarray:

@@ -180,8 +180,8 @@ struct ConvArgs {
   int f16_Hs, f16_Ws;  // OUTF == 1 only: padded plane dims of the fp16 NCHW8c output
 };
 
-template <int KS, int STRIDE, int DIL, int CH, int TR, int TC, class Loader, int OUTF = 0>
-__global__ __launch_bounds__(256) void k_conv_c32_mfma(ConvArgs a, Loader ld) {
+template <int KS, int STRIDE, int DIL, int CH, int TR, int TC, class Loader, int OUTF = 0, bool PF = true, int MINW = 1>
+__global__ __launch_bounds__(256, MINW) void k_conv_c32_mfma(ConvArgs a, Loader ld) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int TAPS = KS * KS;
   constexpr int CSEG = TC / 32;
@@ -225,9 +225,13 @@ __global__ __launch_bounds__(256) void k_conv_c32_mfma(ConvArgs a, Loader ld) {
   float pre[EPT];
   float4 wpre[WPT];
   auto fetch = [&](int c0) {
+    // opaque copy of the thread id: keeps hipcc from hoisting all EPT address computations out of the
+    // chunk loop (that cost ~2 VGPRs per staged element and halved the occupancy)
+    int tq = tid;
+    asm volatile("" : "+v"(tq));
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
-      const int idx = e * 256 + tid;
+      const int idx = e * 256 + tq;
       const int c = idx / (ROWS_IN * COLS_IN);
       const int rem = idx - c * (ROWS_IN * COLS_IN);
       const int r = rem / COLS_IN;
@@ -237,14 +241,16 @@ __global__ __launch_bounds__(256) void k_conv_c32_mfma(ConvArgs a, Loader ld) {
     const float4* wsrc = reinterpret_cast<const float4*>(a.wpk + (size_t)c0 * TAPS * 32);
 #pragma unroll
     for (int e = 0; e < WPT; ++e) {
-      const int idx = e * 256 + tid;
+      const int idx = e * 256 + tq;
       wpre[e] = idx < NW4 ? wsrc[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto commit = [&]() {
+    int tq = tid;
+    asm volatile("" : "+v"(tq));
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
-      const int idx = e * 256 + tid;
+      const int idx = e * 256 + tq;
       const int c = idx / (ROWS_IN * COLS_IN);
       const int rem = idx - c * (ROWS_IN * COLS_IN);
       const int r = rem / COLS_IN;
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(256) void k_conv_c32_mfma(ConvArgs a, Loader ld) {
     }
 #pragma unroll
     for (int e = 0; e < WPT; ++e) {
-      const int idx = e * 256 + tid;
+      const int idx = e * 256 + tq;
       if (idx < NW4) reinterpret_cast<float4*>(s_w)[idx] = wpre[e];
     }
   };
@@ -265,7 +271,7 @@ __global__ __launch_bounds__(256) void k_conv_c32_mfma(ConvArgs a, Loader ld) {
 
   for (int c0 = 0; c0 < a.cin_pad; c0 += CH) {
     const bool more = c0 + CH < a.cin_pad;
-    if (more) fetch(c0 + CH);
+    if (PF && more) fetch(c0 + CH);     // PF: next chunk's loads fly under this chunk's MFMAs (more VGPRs)
 
 #pragma unroll 1
     for (int tap = 0; tap < TAPS; ++tap) {
@@ -292,7 +298,8 @@ __global__ __launch_bounds__(256) void k_conv_c32_mfma(ConvArgs a, Loader ld) {
     }
     __syncthreads();     // everyone is done reading this chunk
     if (more) {
-      commit();
+      if (!PF) fetch(c0 + CH);          // !PF: staging registers are dead during the MFMAs -> higher occupancy,
+      commit();                         //      other resident blocks keep the matrix pipe busy meanwhile
       __syncthreads();
     }
   }
@@ -838,6 +845,227 @@ __global__ __launch_bounds__(256, 2) void k_ref_conv_f16_v2(const uint4* __restr
           hv[e] = ok ? (_Float16)u : (_Float16)0.f;
         }
         *reinterpret_cast<half4*>(obase[s] + (size_t)q * g.Hs * g.Ws * 16) = hv;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused residual block (dilation DIL, built for DIL = 1):  y = lrelu(x + conv2(lrelu(conv1(x) + b1)) + b2)
+// in ONE kernel: the intermediate activation t lives only in LDS, so a block costs one read of x and one
+// write of y (118 MB / pair at 1280x720) instead of 295 MB for two separate convolutions.
+//   output tile 8 x (64 - 2*DIL); t is needed on (8 + 2*DIL) rows x 64 columns (= whole 32-px MFMA
+//   segments), x on (8 + 4*DIL) x (64 + 2*DIL).  t outside the image is forced to 0 (conv2's zero padding).
+//   LDS: four x half-tiles (two per tile, full double buffering: the NEXT tile's x streams in by LDS-DMA
+//   during the whole current tile) + the fp16 t tile.  Both weight sets (36 MFMA A-fragments) and biases
+//   stay in registers: one workgroup per CU, one wave per SIMD, so each wave may use the whole 512-entry
+//   register file.  The residual x is re-read from the LDS x tile, not from HBM.
+//   y goes to a different tensor than x (neighbouring tiles still read x's halo).
+// vmcnt discipline as in v2: per tile every wave issues 2*KW DMA instructions and exactly 16 stores
+// (masked lanes store a zero into a pad slot that is zero anyway), so "everything but the last 16 ops"
+// at the top of a tile retires the tile's own x.
+// ------------------------------------------------------------------------------------------
+template <int DIL>
+struct FusedTile {
+  static constexpr int TH = 8, TWO = 64 - 2 * DIL;            // output tile
+  static constexpr int RT = TH + 2 * DIL, CT = 64;            // t region
+  static constexpr int RX = TH + 4 * DIL, CX = 64 + 2 * DIL;  // x region
+  static constexpr int PX = RX * CX, PT = RT * CT;            // slots per channel block
+  static constexpr int XHALF = 2 * PX;
+  static constexpr int NINST = (XHALF + 63) / 64;
+  static constexpr int KW = (NINST + 3) / 4;
+  static constexpr int XBUF = NINST * 64;
+  static constexpr int TBUF = 4 * PT + 64;                    // + slack: discarded lanes read past the last row
+  static constexpr int LDS_BYTES = (4 * XBUF + TBUF) * 16;
+  static constexpr int S1 = RT * 2 / 4;                       // stage-1 segments per wave
+  static constexpr int S2 = TH * 2 / 4;                       // stage-2 segments per wave
+  static constexpr int NSTORE = 4 * S2;
+  static_assert((RT * 2) % 4 == 0, "t rows must split over 4 waves");
+  static_assert(LDS_BYTES <= 160 * 1024, "fused block does not fit the LDS at this dilation");
+};
+
+template <int DIL>
+__global__ __launch_bounds__(256, 1) void k_ref_block_f16(const uint4* __restrict__ xin, uint4* __restrict__ yout,
+                                                          const uint4* __restrict__ wfrag1, const float* __restrict__ bias1,
+                                                          const uint4* __restrict__ wfrag2, const float* __restrict__ bias2,
+                                                          RefGeom g, int nimg, uint4* zero_slot) {
+  using T = FusedTile<DIL>;
+  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+  uint4* xbuf = lds;                       // 4 half-tile buffers
+  uint4* tbuf = lds + 4 * T::XBUF;         // t tile [4 blocks][RT][CT]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, gh = lane >> 5;
+
+  half8 w1[18], w2[18];
+  float b1[16], b2[16];
+#pragma unroll
+  for (int i = 0; i < 18; ++i) {
+    const uint4 a = wfrag1[i * 64 + lane], b = wfrag2[i * 64 + lane];
+    w1[i] = *reinterpret_cast<const half8*>(&a);
+    w2[i] = *reinterpret_cast<const half8*>(&b);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = (r & 3) + 8 * (r >> 2) + 4 * gh;
+    b1[r] = bias1[co];
+    b2[r] = bias2[co];
+  }
+#pragma unroll
+  for (int i = 0; i < 18; ++i) {
+    asm volatile("" : "+v"(w1[i]));
+    asm volatile("" : "+v"(w2[i]));
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    asm volatile("" : "+v"(b1[r]));
+    asm volatile("" : "+v"(b2[r]));
+  }
+
+  const int per_img = g.tiles_x * g.tiles_y;
+  const int total = per_img * nimg;
+  const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, nlb = gridDim.x >> 3;
+  const int t_begin = (int)((long)xcd * total / 8), t_end = (int)((long)(xcd + 1) * total / 8);
+  const int t0 = t_begin + lb;
+  if (t0 >= t_end) return;
+  const int ntiles = (t_end - t0 + nlb - 1) / nlb;
+
+  auto tile_xy = [&](int ti, int& img, int& y0, int& x0) {
+    const int t = t0 + ti * nlb;
+    img = t / per_img;
+    const int rem = t - img * per_img;
+    const int ty = rem / g.tiles_x;
+    y0 = ty * T::TH;
+    x0 = (rem - ty * g.tiles_x) * T::TWO;
+  };
+  // both x half-tiles of tile ti into buffers 2*(ti&1), 2*(ti&1)+1
+  auto issue_x = [&](int ti) {
+    int img, y0, x0;
+    tile_xy(ti, img, y0, x0);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      uint4* dst = xbuf + (2 * (ti & 1) + kk) * T::XBUF;
+#pragma unroll
+      for (int k = 0; k < T::KW; ++k) {
+        int i = wave + 4 * k;
+        i = i < T::NINST ? i : T::NINST - 1;
+        int s = i * 64 + lane;
+        s = s < T::XHALF ? s : T::XHALF - 1;
+        const int pc = s / T::PX;
+        const int rem = s - pc * T::PX;
+        const int r = rem / T::CX;
+        const int c = rem - r * T::CX;
+        const size_t slot = (((size_t)img * 4 + (2 * kk + pc)) * g.Hs + (y0 + r - 2 * DIL + kRefPad)) * g.Ws +
+                            (x0 + c - 2 * DIL + kRefPad);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xin + slot),
+                                         (__attribute__((address_space(3))) void*)(dst + i * 64), 16, 0, 0);
+      }
+    }
+  };
+
+  wait_vmcnt<0>();
+  issue_x(0);
+
+  for (int ti = 0; ti < ntiles; ++ti) {
+    int img, y0, x0;
+    tile_xy(ti, img, y0, x0);
+    if (ti == 0) wait_vmcnt<0>();
+    else wait_vmcnt<T::NSTORE>();                 // younger than this tile's x: the previous tile's stores
+    __builtin_amdgcn_s_barrier();                 // x tile visible; everyone is done with the previous tile
+    if (ti + 1 < ntiles) issue_x(ti + 1);
+    const uint4* xa = xbuf + (2 * (ti & 1)) * T::XBUF;
+    const uint4* xb = xa + T::XBUF;
+
+    // ---- stage 1: t = lrelu(conv1(x) + b1) on RT x 64, S1 segments per wave ----
+    {
+      f32x16 acc[T::S1];
+#pragma unroll
+      for (int s = 0; s < T::S1; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+      const int seg0 = wave * T::S1;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const uint4* base = (kk ? xb : xa) + gh * T::PX + j;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+          for (int s = 0; s < T::S1; ++s) {
+            const int seg = seg0 + s;                                   // runtime (wave) + constant
+            const int off = ((seg >> 1) + ky * DIL) * T::CX + (seg & 1) * 32 + kx * DIL;
+            const half8 v = *reinterpret_cast<const half8*>(base + off);
+            acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[tap * 2 + kk], v, acc[s], 0, 0, 0);
+          }
+        }
+      }
+      // t -> LDS (fp16); positions outside the image are conv2's zero padding
+#pragma unroll
+      for (int s = 0; s < T::S1; ++s) {
+        const int seg = seg0 + s;
+        const int tr = seg >> 1, tc = (seg & 1) * 32 + j;
+        const int gy = y0 - DIL + tr, gx = x0 - DIL + tc;
+        const bool inside = (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          half4 hv;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float u = acc[s][4 * q + e] + b1[4 * q + e];
+            u = u > 0.f ? u : u * kSlope;
+            hv[e] = inside ? (_Float16)u : (_Float16)0.f;
+          }
+          *reinterpret_cast<half4*>(reinterpret_cast<char*>(tbuf + q * T::PT + tr * T::CT + tc) + gh * 8) = hv;
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                 // t tile complete
+
+    // ---- stage 2: y = lrelu(x + conv2(t) + b2) on 8 x TWO, S2 segments per wave ----
+    {
+      f32x16 acc[T::S2];
+#pragma unroll
+      for (int s = 0; s < T::S2; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+      const int seg0 = wave * T::S2;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const uint4* base = tbuf + (2 * kk + gh) * T::PT + j;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+          for (int s = 0; s < T::S2; ++s) {
+            const int seg = seg0 + s;
+            const int off = ((seg >> 1) + ky * DIL) * T::CT + (seg & 1) * 32 + kx * DIL;
+            const half8 v = *reinterpret_cast<const half8*>(base + off);
+            acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2[tap * 2 + kk], v, acc[s], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < T::S2; ++s) {
+        const int seg = seg0 + s;
+        const int orow = seg >> 1, ocol = (seg & 1) * 32 + j;
+        const int y = y0 + orow, x = x0 + ocol;
+        const bool ok = ocol < T::TWO && y < g.H && x < g.W;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          // residual: x at the output pixel = x tile position (orow + 2*DIL, ocol + 2*DIL), channel block q
+          const uint4* xs = (q < 2 ? xa : xb) + (q & 1) * T::PX + (orow + 2 * DIL) * T::CX + (ocol + 2 * DIL);
+          const half4 rv = *reinterpret_cast<const half4*>(reinterpret_cast<const char*>(xs) + gh * 8);
+          half4 hv;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float u = acc[s][4 * q + e] + b2[4 * q + e] + (float)rv[e];
+            u = u > 0.f ? u : u * kSlope;
+            hv[e] = ok ? (_Float16)u : (_Float16)0.f;
+          }
+          uint4* dst = ok ? yout + ((((size_t)img * 4 + q) * g.Hs + (y + kRefPad)) * g.Ws + (x + kRefPad)) : zero_slot;
+          *reinterpret_cast<half4*>(reinterpret_cast<char*>(dst) + gh * 8) = hv;
+        }
       }
     }
   }

@@ -26,6 +26,7 @@ using namespace sn;
 constexpr int kNDown = 4, kNFeatRes = 6, kNAgg = 4, kNRefRes = 6;
 constexpr int kRefDil[kNRefRes] = {1, 2, 4, 8, 1, 1};
 constexpr float kOutScale = 2.60443857769133e-6f;   // stereonet_node.cpp:282
+constexpr int kMaxPieceEvents = 64;
 
 #define HIP_TRY(h, expr)                                                              \
   do {                                                                                \
@@ -53,7 +54,7 @@ struct HeadLayer {          // C -> 1 layers (VALU kernels)
 };
 
 struct Workspace {          // activations for up to `nb` pairs
-  int nb = 0, rb = 0;
+  int nb = 0, rb = 0, pb = 0;   // batch capacity, pairs per tower launch, pairs per low-res piece
   int8_t* in6 = nullptr;
   float* down[3] = {nullptr, nullptr, nullptr};
   float* low[3] = {nullptr, nullptr, nullptr};
@@ -85,8 +86,11 @@ struct Slot {                // async request slot (sn_submit / sn_wait)
 struct sn_handle {
   int device = 0;
   int W = 0, H = 0, D = 0, Wp = 0, Hp = 0, wl = 0, hl = 0, Dl = 0;
-  int max_batch = 1, precision = 0, task_num = 4, refine_chunk = 1;
+  int max_batch = 1, precision = 0, task_num = 4, refine_chunk = 1, piece = 8;
   hipStream_t stream = nullptr;
+  hipStream_t s_low = nullptr, s_ref = nullptr;     // low-res branch / refinement tower (piece pipeline)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_piece[kMaxPieceEvents] = {};
+  bool overlap = true;
   ConvLayer down[kNDown], fres[kNFeatRes][2], fout, agg[kNAgg], rin, rres[kNRefRes][2];
   HeadLayer aout, rout;
   RefLayerF16 rres16[kNRefRes][2];
@@ -198,7 +202,7 @@ int upload_head(sn_handle* h, const HostLayer& l, HeadLayer* out) {   // [1][32]
 }
 
 // ---- convolution launcher ------------------------------------------------------------------------
-template <int KS, int STRIDE, int DIL, int CH, int TR, int TC, class Loader, int OUTF = 0>
+template <int KS, int STRIDE, int DIL, int CH, int TR, int TC, class Loader, int OUTF = 0, bool PF = true, int MINW = 1>
 hipError_t launch_conv(hipStream_t st, const ConvLayer& L, const Loader& ld, int nimg, int Ho, int Wo,
                        float* out, const float* res, bool lrelu, int f16_Hs = 0, int f16_Ws = 0) {
   constexpr int dil = DIL;
@@ -222,7 +226,7 @@ hipError_t launch_conv(hipStream_t st, const ConvLayer& L, const Loader& ld, int
   const int cols_in = (TC - 1) * STRIDE + (KS - 1) * dil + 1;
   const int pitch = STRIDE == 1 ? cols_in : 2 * ((cols_in + 1) / 2);
   const size_t lds = ((size_t)CH * KS * KS * 32 + (size_t)CH * rows_in * pitch) * sizeof(float);
-  auto kern = k_conv_c32_mfma<KS, STRIDE, DIL, CH, TR, TC, Loader, OUTF>;
+  auto kern = k_conv_c32_mfma<KS, STRIDE, DIL, CH, TR, TC, Loader, OUTF, PF, MINW>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -275,6 +279,7 @@ RefGeom make_ref_geom(int Hp, int Wp) {
 }
 
 size_t ref16_slots(const RefGeom& g, int nimg) { return (size_t)nimg * 4 * g.Hs * g.Ws; }
+constexpr size_t kRefSlack = 4096;   // slots: the fused block's x tile may over-read past the last padded row
 
 // [co][ci][ky][kx] fp32 -> wfrag[tap][kk][lane][e] fp16 = w[co = lane&31][ci = 16kk + 8(lane>>5) + e][tap]
 int upload_ref_f16(sn_handle* h, const HostLayer& l, RefLayerF16* out) {
@@ -328,7 +333,9 @@ hipError_t launch_ref_f16_v2(hipStream_t st, const RefLayerF16& L, const RefGeom
   RefGeom gt = g;                      // tile grid of this variant (the buffer geometry is for 8x64 tiles)
   gt.tiles_x = (g.W + TW - 1) / TW;
   const int total = gt.tiles_x * gt.tiles_y * nimg;
-  const int per_cu = T::LDS_BYTES * 2 <= 160 * 1024 ? 2 : 1;
+  static const int per_cu_env = getenv("SN_REF_PER_CU") ? atoi(getenv("SN_REF_PER_CU")) : 0;
+  int per_cu = T::LDS_BYTES * 2 <= 160 * 1024 ? 2 : 1;
+  if (per_cu_env > 0 && per_cu_env < per_cu) per_cu = per_cu_env;
   // persistent grid: 8 XCD bands; pick the block count per band so that every block walks the same number
   // of tiles (e.g. 225 tiles per band -> 57 blocks x 4 tiles, not 64 blocks x 3.5)
   const int band = (total + 7) / 8;
@@ -344,6 +351,40 @@ hipError_t launch_ref_f16_v2(hipStream_t st, const RefLayerF16& L, const RefGeom
                      lrelu ? 1 : 0);
   return hipGetLastError();
 }
+
+// fused residual block (conv1 + conv2 + residual in one launch); x and y must be different tensors
+template <int DIL>
+hipError_t launch_ref_block_f16(hipStream_t st, const RefLayerF16& L1, const RefLayerF16& L2, const RefGeom& g,
+                                int num_cu, const uint4* x, uint4* y, int nimg) {
+  using T = FusedTile<DIL>;
+  auto kern = k_ref_block_f16<DIL>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     T::LDS_BYTES);
+  if (e != hipSuccess) return e;
+  RefGeom gt = g;
+  gt.tiles_x = (g.W + T::TWO - 1) / T::TWO;
+  const int total = gt.tiles_x * gt.tiles_y * nimg;
+  const int band = (total + 7) / 8;
+  int cap = num_cu / 8;                    // one workgroup per CU
+  if (cap < 1) cap = 1;
+  const int rounds = (band + cap - 1) / cap;
+  const int nlb = (band + rounds - 1) / rounds;
+  hipLaunchKernelGGL(kern, dim3(nlb * 8), dim3(256), T::LDS_BYTES, st, x, y, L1.wfrag, L1.bias, L2.wfrag, L2.bias, gt,
+                     nimg, y /* slot 0 = top-left pad corner, zero by construction */);
+  return hipGetLastError();
+}
+
+// Opt-in (SN_FUSE=1): correct and parity-tested, but with one wave per SIMD its per-tile VALU work is exposed
+// and it is currently ~12 % slower than the two v2 launches it replaces ("fused block").
+bool g_force_fused = false;   // the parity hook sets this to exercise the fused kernel regardless of the env
+bool use_fused_block(int dil) {
+  static const bool on = getenv("SN_FUSE") != nullptr && getenv("SN_REF_V1") == nullptr;
+  return dil == 1 && (on || g_force_fused);
+}
+
+// One residual block of the fp16 tower on `*cur` (input and, on return, output); `*oth` is scratch.
+hipError_t ref_block_f16(hipStream_t st, const RefLayerF16& L1, const RefLayerF16& L2, const RefGeom& g, int num_cu,
+                         int dil, uint4** cur, uint4** oth, int nimg);
 
 bool use_ref_v1() {
   static const bool v = getenv("SN_REF_V1") != nullptr;   // A/B switch for the first-generation tower kernel
@@ -370,17 +411,35 @@ hipError_t ref_conv_f16(hipStream_t st, const RefLayerF16& L, const RefGeom& g, 
   }
 }
 
+hipError_t ref_block_f16(hipStream_t st, const RefLayerF16& L1, const RefLayerF16& L2, const RefGeom& g, int num_cu,
+                         int dil, uint4** cur, uint4** oth, int nimg) {
+  if (use_fused_block(dil)) {
+    hipError_t e = launch_ref_block_f16<1>(st, L1, L2, g, num_cu, *cur, *oth, nimg);
+    uint4* t = *cur;
+    *cur = *oth;
+    *oth = t;
+    return e;
+  }
+  hipError_t e = ref_conv_f16(st, L1, g, num_cu, dil, *cur, *oth, nullptr, nimg, true);
+  if (e != hipSuccess) return e;
+  return ref_conv_f16(st, L2, g, num_cu, dil, *oth, *cur, *cur, nimg, true);   // in-place residual
+}
+
 // ---- workspace -----------------------------------------------------------------------------------
 int alloc_ws(sn_handle* h, Workspace* ws, int nb, int rb) {
   ws->nb = nb;
   ws->rb = rb;
+  ws->pb = h->piece > 0 ? h->piece : 8;
+  if (ws->pb > nb) ws->pb = nb;
+  if (ws->pb < rb) ws->pb = rb;
+  const int pb = ws->pb;
   const size_t HW = (size_t)h->H * h->W, HWp = (size_t)h->Hp * h->Wp, hw = (size_t)h->hl * h->wl;
   HIP_TRY(h, dalloc(&ws->in6, (size_t)nb * 6 * HW));
   for (int k = 0; k < 3; ++k)
-    HIP_TRY(h, dalloc(&ws->down[k], (size_t)2 * nb * kC * (HWp >> (2 * (k + 1)))));
-  for (int k = 0; k < 3; ++k) HIP_TRY(h, dalloc(&ws->low[k], (size_t)2 * nb * kC * hw));
-  HIP_TRY(h, dalloc(&ws->feat, (size_t)2 * nb * kC * hw));
-  for (int k = 0; k < 2; ++k) HIP_TRY(h, dalloc(&ws->vol[k], (size_t)nb * h->Dl * kC * hw));
+    HIP_TRY(h, dalloc(&ws->down[k], (size_t)2 * pb * kC * (HWp >> (2 * (k + 1)))));
+  for (int k = 0; k < 3; ++k) HIP_TRY(h, dalloc(&ws->low[k], (size_t)2 * pb * kC * hw));
+  HIP_TRY(h, dalloc(&ws->feat, (size_t)2 * pb * kC * hw));
+  for (int k = 0; k < 2; ++k) HIP_TRY(h, dalloc(&ws->vol[k], (size_t)pb * h->Dl * kC * hw));
   HIP_TRY(h, dalloc(&ws->cost, (size_t)nb * h->Dl * hw));
   HIP_TRY(h, dalloc(&ws->disp_low, (size_t)nb * hw));
   if (h->precision == SN_PREC_FP32) {
@@ -388,8 +447,8 @@ int alloc_ws(sn_handle* h, Workspace* ws, int nb, int rb) {
   } else {
     for (int k = 0; k < 2; ++k) {
       const size_t slots = ref16_slots(h->rg, rb);
-      HIP_TRY(h, dalloc(&ws->ref16[k], slots));
-      HIP_TRY(h, hipMemset(ws->ref16[k], 0, slots * sizeof(uint4)));   // the zero border is never written again
+      HIP_TRY(h, dalloc(&ws->ref16[k], slots + kRefSlack));
+      HIP_TRY(h, hipMemset(ws->ref16[k], 0, (slots + kRefSlack) * sizeof(uint4)));   // the zero border is never written again
     }
   }
   HIP_TRY(h, dalloc(&ws->out_disp, (size_t)nb * HW));
@@ -415,77 +474,79 @@ void free_ws(Workspace* ws) {
 }
 
 // ---- the forward pass on device buffers ------------------------------------------------------------
-// in6: device int8 [n][6][H][W]; out_disp / out_raw: device, nullable.
-int forward(sn_handle* h, Workspace& ws, hipStream_t st, int n, const int8_t* in6, float* out_disp,
-            int32_t* out_raw, bool want_cost) {
+// Low-resolution branch for pairs [p0, p0+m): Siamese features -> cost volume -> 3-D aggregation ->
+// soft-argmin.  Intermediate buffers are piece-local; disp_low (and cost) are indexed by p0.
+int lowres(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, const int8_t* in6, bool want_cost, bool prof) {
   const int Hp = h->Hp, Wp = h->Wp, hl = h->hl, wl = h->wl, Dl = h->Dl;
-  const bool prof = h->profiling && (&ws == &h->ws);
-  if (prof) HIP_TRY(h, hipEventRecord(h->ev[0], st));
-
-  // --- Siamese feature tower: images = 2n (left, right interleaved), shared weights ---
+  const size_t HW = (size_t)h->H * h->W;
+  const int8_t* in = in6 + (size_t)p0 * 6 * HW;
+  // --- Siamese feature tower: images = 2m (left, right interleaved), shared weights ---
   {
-    LoadI8Eye ld{in6, h->H, h->W};
+    LoadI8Eye ld{in, h->H, h->W};
     const int Ho = Hp / 2, Wo = Wp / 2;
     if (Ho * Wo <= 64 * 128)
-      HIP_TRY(h, (launch_conv<5, 2, 1, 4, 4, 32>(st, h->down[0], ld, 2 * n, Ho, Wo, ws.down[0], nullptr, false)));
+      HIP_TRY(h, (launch_conv<5, 2, 1, 4, 4, 32>(st, h->down[0], ld, 2 * m, Ho, Wo, ws.down[0], nullptr, false)));
     else
-      HIP_TRY(h, (launch_conv<5, 2, 1, 4, 8, 64>(st, h->down[0], ld, 2 * n, Ho, Wo, ws.down[0], nullptr, false)));
+      HIP_TRY(h, (launch_conv<5, 2, 1, 4, 8, 64>(st, h->down[0], ld, 2 * m, Ho, Wo, ws.down[0], nullptr, false)));
   }
-  HIP_TRY(h, conv5x5s2(st, h->down[1], ws.down[0], 2 * n, Hp / 2, Wp / 2, ws.down[1]));
-  HIP_TRY(h, conv5x5s2(st, h->down[2], ws.down[1], 2 * n, Hp / 4, Wp / 4, ws.down[2]));
-  HIP_TRY(h, conv5x5s2(st, h->down[3], ws.down[2], 2 * n, Hp / 8, Wp / 8, ws.low[0]));
+  HIP_TRY(h, conv5x5s2(st, h->down[1], ws.down[0], 2 * m, Hp / 2, Wp / 2, ws.down[1]));
+  HIP_TRY(h, conv5x5s2(st, h->down[2], ws.down[1], 2 * m, Hp / 4, Wp / 4, ws.down[2]));
+  HIP_TRY(h, conv5x5s2(st, h->down[3], ws.down[2], 2 * m, Hp / 8, Wp / 8, ws.low[0]));
   float* x = ws.low[0];
   float* t = ws.low[1];
   for (int i = 0; i < kNFeatRes; ++i) {
-    HIP_TRY(h, conv3x3(st, h->fres[i][0], x, 2 * n, hl, wl, 1, t, nullptr, true));
-    HIP_TRY(h, conv3x3(st, h->fres[i][1], t, 2 * n, hl, wl, 1, x, x, true));   // in-place residual
+    HIP_TRY(h, conv3x3(st, h->fres[i][0], x, 2 * m, hl, wl, 1, t, nullptr, true));
+    HIP_TRY(h, conv3x3(st, h->fres[i][1], t, 2 * m, hl, wl, 1, x, x, true));   // in-place residual
   }
-  HIP_TRY(h, conv3x3(st, h->fout, x, 2 * n, hl, wl, 1, ws.feat, nullptr, false));
+  HIP_TRY(h, conv3x3(st, h->fout, x, 2 * m, hl, wl, 1, ws.feat, nullptr, false));
   if (prof) HIP_TRY(h, hipEventRecord(h->ev[1], st));
 
   // --- cost volume (fused into the first 3-D conv's loader) + 3-D aggregation + soft-argmin ---
-  {
-    LoadCostVol ld{ws.feat, Dl, hl, wl};
-    HIP_TRY(h, (launch_conv<3, 1, 1, 8, 4, 32>(st, h->agg[0], ld, n * Dl, hl, wl, ws.vol[0], nullptr, true)));
-    for (int i = 1; i < kNAgg; ++i) {
-      LoadVol3D lv{ws.vol[(i - 1) & 1], Dl, hl, wl};
-      HIP_TRY(h, (launch_conv<3, 1, 1, 8, 4, 32>(st, h->agg[i], lv, n * Dl, hl, wl, ws.vol[i & 1], nullptr, true)));
-    }
-    const float* v = ws.vol[(kNAgg - 1) & 1];
-    const int npix = n * hl * wl;
-    hipLaunchKernelGGL(k_head_softargmin<16>, dim3((npix + 63) / 64), dim3(256), 0, st, v, h->aout.w,
-                       h->aout.bias, Dl, hl, wl, npix, ws.disp_low, want_cost ? ws.cost : nullptr);
-    HIP_TRY(h, hipGetLastError());
+  LoadCostVol ld{ws.feat, Dl, hl, wl};
+  HIP_TRY(h, (launch_conv<3, 1, 1, 8, 4, 32>(st, h->agg[0], ld, m * Dl, hl, wl, ws.vol[0], nullptr, true)));
+  for (int i = 1; i < kNAgg; ++i) {
+    LoadVol3D lv{ws.vol[(i - 1) & 1], Dl, hl, wl};
+    HIP_TRY(h, (launch_conv<3, 1, 1, 8, 4, 32>(st, h->agg[i], lv, m * Dl, hl, wl, ws.vol[i & 1], nullptr, true)));
   }
-  if (prof) HIP_TRY(h, hipEventRecord(h->ev[2], st));
+  const float* v = ws.vol[(kNAgg - 1) & 1];
+  const int npix = m * hl * wl;
+  hipLaunchKernelGGL(k_head_softargmin<16>, dim3((npix + 63) / 64), dim3(256), 0, st, v, h->aout.w, h->aout.bias, Dl,
+                     hl, wl, npix, ws.disp_low + (size_t)p0 * hl * wl,
+                     want_cost ? ws.cost + (size_t)p0 * Dl * hl * wl : nullptr);
+  HIP_TRY(h, hipGetLastError());
+  return SN_OK;
+}
 
-  // --- refinement, `rb` pairs at a time so the two full-resolution activation buffers stay small ---
+// Refinement of pairs [p0, p0+m), `rb` pairs per tower launch.
+int refine(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, const int8_t* in6, float* out_disp,
+           int32_t* out_raw, bool prof) {
+  const int Hp = h->Hp, Wp = h->Wp, hl = h->hl, wl = h->wl;
+  const size_t HW = (size_t)h->H * h->W;
   const float inv_q = (float)(1.0 / ((double)h->D * (double)kOutScale));
-  h->dom_launches = 0;
-  for (int p0 = 0; p0 < n; p0 += ws.rb) {
-    const int m = (n - p0) < ws.rb ? (n - p0) : ws.rb;
-    const size_t HW = (size_t)h->H * h->W;
-    LoadRefineIn ld{ws.disp_low + (size_t)p0 * hl * wl, in6 + (size_t)p0 * 6 * HW, hl, wl, h->H, h->W, Hp, Wp,
+  for (int q0 = p0; q0 < p0 + m; q0 += ws.rb) {
+    const int c = (p0 + m - q0) < ws.rb ? (p0 + m - q0) : ws.rb;
+    const bool pe = prof && q0 == 0;
+    LoadRefineIn ld{ws.disp_low + (size_t)q0 * hl * wl, in6 + (size_t)q0 * 6 * HW, hl, wl, h->H, h->W, Hp, Wp,
                     1.0f / (float)h->D};
+    float* od = out_disp ? out_disp + (size_t)q0 * HW : nullptr;
+    int32_t* orw = out_raw ? out_raw + (size_t)q0 * HW : nullptr;
+    const float* dl = ws.disp_low + (size_t)q0 * hl * wl;
+    dim3 grid((h->W + 63) / 64, (h->H + 3) / 4, c);
     if (h->precision == SN_PREC_FP32) {
       float* rx = ws.ref[0];
       float* rt = ws.ref[1];
       if (Hp * Wp <= 64 * 128)
-        HIP_TRY(h, (launch_conv<3, 1, 1, 4, 4, 32>(st, h->rin, ld, m, Hp, Wp, rx, nullptr, true)));
+        HIP_TRY(h, (launch_conv<3, 1, 1, 4, 4, 32>(st, h->rin, ld, c, Hp, Wp, rx, nullptr, true)));
       else
-        HIP_TRY(h, (launch_conv<3, 1, 1, 4, 8, 64>(st, h->rin, ld, m, Hp, Wp, rx, nullptr, true)));
-      if (prof && p0 == 0) HIP_TRY(h, hipEventRecord(h->ev[4], st));
+        HIP_TRY(h, (launch_conv<3, 1, 1, 4, 8, 64>(st, h->rin, ld, c, Hp, Wp, rx, nullptr, true)));
+      if (pe) HIP_TRY(h, hipEventRecord(h->ev[4], st));
       for (int i = 0; i < kNRefRes; ++i) {
-        HIP_TRY(h, conv3x3(st, h->rres[i][0], rx, m, Hp, Wp, kRefDil[i], rt, nullptr, true));
-        HIP_TRY(h, conv3x3(st, h->rres[i][1], rt, m, Hp, Wp, kRefDil[i], rx, rx, true));
-        h->dom_launches += 2;
+        HIP_TRY(h, conv3x3(st, h->rres[i][0], rx, c, Hp, Wp, kRefDil[i], rt, nullptr, true));
+        HIP_TRY(h, conv3x3(st, h->rres[i][1], rt, c, Hp, Wp, kRefDil[i], rx, rx, true));
       }
-      if (prof && p0 == 0) HIP_TRY(h, hipEventRecord(h->ev[5], st));
-      dim3 grid((h->W + 63) / 64, (h->H + 3) / 4, m);
-      hipLaunchKernelGGL(k_head_final, grid, dim3(256), 0, st, rx, h->rout.w, h->rout.bias,
-                         ws.disp_low + (size_t)p0 * hl * wl, hl, wl, Hp, Wp, h->H, h->W, (float)h->D, inv_q,
-                         out_disp ? out_disp + (size_t)p0 * HW : nullptr,
-                         out_raw ? out_raw + (size_t)p0 * HW : nullptr);
+      if (pe) HIP_TRY(h, hipEventRecord(h->ev[5], st));
+      hipLaunchKernelGGL(k_head_final, grid, dim3(256), 0, st, rx, h->rout.w, h->rout.bias, dl, hl, wl, Hp, Wp, h->H,
+                         h->W, (float)h->D, inv_q, od, orw);
     } else {
       // fp16 tower: ref.in (K=36, fp32 MFMA) writes the NCHW8c fp16 tensor, the 12 C->C convs run on
       // v_mfma_f32_32x32x16_f16, the head reads fp16 and finishes in fp32
@@ -493,27 +554,59 @@ int forward(sn_handle* h, Workspace& ws, hipStream_t st, int n, const int8_t* in
       uint4* rt = ws.ref16[1];
       const RefGeom& g = h->rg;
       if (Hp * Wp <= 64 * 128)
-        HIP_TRY(h, (launch_conv<3, 1, 1, 4, 4, 32, LoadRefineIn, 1>(st, h->rin, ld, m, Hp, Wp, reinterpret_cast<float*>(rx),
+        HIP_TRY(h, (launch_conv<3, 1, 1, 4, 4, 32, LoadRefineIn, 1>(st, h->rin, ld, c, Hp, Wp, reinterpret_cast<float*>(rx),
                                                                   nullptr, true, g.Hs, g.Ws)));
       else
-        HIP_TRY(h, (launch_conv<3, 1, 1, 4, 8, 64, LoadRefineIn, 1>(st, h->rin, ld, m, Hp, Wp, reinterpret_cast<float*>(rx),
+        HIP_TRY(h, (launch_conv<3, 1, 1, 4, 8, 64, LoadRefineIn, 1>(st, h->rin, ld, c, Hp, Wp, reinterpret_cast<float*>(rx),
                                                                   nullptr, true, g.Hs, g.Ws)));
-      if (prof && p0 == 0) HIP_TRY(h, hipEventRecord(h->ev[4], st));
-      for (int i = 0; i < kNRefRes; ++i) {
-        HIP_TRY(h, ref_conv_f16(st, h->rres16[i][0], g, h->num_cu, kRefDil[i], rx, rt, nullptr, m, true));
-        HIP_TRY(h, ref_conv_f16(st, h->rres16[i][1], g, h->num_cu, kRefDil[i], rt, rx, rx, m, true));
-        h->dom_launches += 2;
-      }
-      if (prof && p0 == 0) HIP_TRY(h, hipEventRecord(h->ev[5], st));
-      dim3 grid((h->W + 63) / 64, (h->H + 3) / 4, m);
-      hipLaunchKernelGGL(k_head_final_f16, grid, dim3(256), 0, st, rx, g, h->rout.w, h->rout.bias,
-                         ws.disp_low + (size_t)p0 * hl * wl, hl, wl, h->H, h->W, (float)h->D, inv_q,
-                         out_disp ? out_disp + (size_t)p0 * HW : nullptr,
-                         out_raw ? out_raw + (size_t)p0 * HW : nullptr);
+      if (pe) HIP_TRY(h, hipEventRecord(h->ev[4], st));
+      for (int i = 0; i < kNRefRes; ++i)
+        HIP_TRY(h, ref_block_f16(st, h->rres16[i][0], h->rres16[i][1], g, h->num_cu, kRefDil[i], &rx, &rt, c));
+      if (pe) HIP_TRY(h, hipEventRecord(h->ev[5], st));
+      hipLaunchKernelGGL(k_head_final_f16, grid, dim3(256), 0, st, rx, g, h->rout.w, h->rout.bias, dl, hl, wl, h->H,
+                         h->W, (float)h->D, inv_q, od, orw);
     }
     HIP_TRY(h, hipGetLastError());
   }
-  if (prof) HIP_TRY(h, hipEventRecord(h->ev[3], st));
+  return SN_OK;
+}
+
+// in6: device int8 [n][6][H][W]; out_disp / out_raw: device, nullable.
+// The batch is cut into pieces of ws.pb pairs.  The low-resolution branch is fp32-MFMA bound and touches
+// little HBM, the refinement tower is HBM bound and keeps the matrix pipe ~25 % busy, so the two run on
+// separate HIP streams: low-res(piece k+1) overlaps refine(piece k).  Both streams fork from / join back
+// into the caller's stream with events, so the call keeps plain stream semantics for the caller.
+int forward(sn_handle* h, Workspace& ws, hipStream_t st, int n, const int8_t* in6, float* out_disp,
+            int32_t* out_raw, bool want_cost) {
+  const bool prof = h->profiling && (&ws == &h->ws);
+  const bool overlap = !prof && (&ws == &h->ws) && h->overlap && n > ws.pb;
+  int rc;
+  if (!overlap) {
+    if (prof) HIP_TRY(h, hipEventRecord(h->ev[0], st));
+    for (int p0 = 0; p0 < n; p0 += ws.pb) {
+      const int m = (n - p0) < ws.pb ? (n - p0) : ws.pb;
+      if ((rc = lowres(h, ws, st, p0, m, in6, want_cost, prof && p0 == 0))) return rc;
+      if (prof && p0 == 0) HIP_TRY(h, hipEventRecord(h->ev[2], st));
+      if ((rc = refine(h, ws, st, p0, m, in6, out_disp, out_raw, prof))) return rc;
+    }
+    if (prof) HIP_TRY(h, hipEventRecord(h->ev[3], st));
+    return SN_OK;
+  }
+  HIP_TRY(h, hipEventRecord(h->ev_fork, st));
+  HIP_TRY(h, hipStreamWaitEvent(h->s_low, h->ev_fork, 0));
+  HIP_TRY(h, hipStreamWaitEvent(h->s_ref, h->ev_fork, 0));
+  int k = 0;
+  for (int p0 = 0; p0 < n; p0 += ws.pb, ++k) {
+    const int m = (n - p0) < ws.pb ? (n - p0) : ws.pb;
+    // the piece-local low-res buffers are reused by the next piece: only disp_low crosses streams
+    if ((rc = lowres(h, ws, h->s_low, p0, m, in6, want_cost, false))) return rc;
+    hipEvent_t e = h->ev_piece[k % kMaxPieceEvents];
+    HIP_TRY(h, hipEventRecord(e, h->s_low));
+    HIP_TRY(h, hipStreamWaitEvent(h->s_ref, e, 0));
+    if ((rc = refine(h, ws, h->s_ref, p0, m, in6, out_disp, out_raw, false))) return rc;
+  }
+  HIP_TRY(h, hipEventRecord(h->ev_join, h->s_ref));
+  HIP_TRY(h, hipStreamWaitEvent(st, h->ev_join, 0));
   return SN_OK;
 }
 
@@ -619,6 +712,7 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
   h->precision = c.precision;
   h->task_num = c.task_num > 0 ? c.task_num : 4;
   h->refine_chunk = c.refine_chunk > 0 ? c.refine_chunk : 2;   // 2 pairs per tower launch measured best
+  h->piece = c.piece > 0 ? c.piece : 8;
   h->rg = make_ref_geom(h->Hp, h->Wp);
   h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (h->refine_chunk > h->max_batch) h->refine_chunk = h->max_batch;
@@ -632,6 +726,14 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(SN_ERR_DEVICE);
   for (auto& e : h->ev)
     if (hipEventCreate(&e) != hipSuccess) return fail(SN_ERR_DEVICE);
+  if (hipStreamCreateWithFlags(&h->s_low, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&h->s_ref, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess)
+    return fail(SN_ERR_DEVICE);
+  for (auto& e : h->ev_piece)
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(SN_ERR_DEVICE);
+  h->overlap = getenv("SN_NO_OVERLAP") == nullptr;
 
   BlobWalker bw{blob.data()};
   for (int i = 0; i < kNDown; ++i)
@@ -696,6 +798,12 @@ int sn_destroy(sn_handle* h) {
   }
   for (auto& e : h->ev)
     if (e) hipEventDestroy(e);
+  for (auto& e : h->ev_piece)
+    if (e) hipEventDestroy(e);
+  if (h->ev_fork) hipEventDestroy(h->ev_fork);
+  if (h->ev_join) hipEventDestroy(h->ev_join);
+  if (h->s_low) hipStreamDestroy(h->s_low);
+  if (h->s_ref) hipStreamDestroy(h->s_ref);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
   return SN_OK;
@@ -1103,6 +1211,58 @@ int sn_dbg_ref_conv_f16(sn_handle* h, const float* in, int h_px, int w, const fl
   hipFree(dout);
   hipFree(L.wfrag);
   hipFree(L.bias);
+  return SN_OK;
+}
+
+int sn_dbg_ref_block_f16(sn_handle* h, const float* in, int h_px, int w, const float* w1, const float* b1,
+                         const float* w2, const float* b2, int dil, float* out) {
+  if (!h || !in || !w1 || !b1 || !w2 || !b2 || !out || h_px <= 0 || w <= 0) return SN_ERR_ARG;
+  if (dil != 1 && dil != 2 && dil != 4 && dil != 8) return SN_ERR_ARG;
+  int rc = check_device(h);
+  if (rc) return rc;
+  const RefGeom g = make_ref_geom(h_px, w);
+  const size_t slots = ref16_slots(g, 1);
+  auto idx = [&](int c, int y, int x) { return ((((size_t)(c >> 3)) * g.Hs + y + kRefPad) * g.Ws + x + kRefPad) * 8 + (c & 7); };
+  std::vector<_Float16> hin(slots * 8, (_Float16)0.f);
+  for (int c = 0; c < kC; ++c)
+    for (int y = 0; y < h_px; ++y)
+      for (int x = 0; x < w; ++x) hin[idx(c, y, x)] = (_Float16)in[((size_t)c * h_px + y) * w + x];
+  RefLayerF16 L1, L2;
+  if ((rc = upload_ref_f16(h, HostLayer{w1, b1, kC, kC, 9}, &L1))) return rc;
+  if ((rc = upload_ref_f16(h, HostLayer{w2, b2, kC, kC, 9}, &L2))) return rc;
+  uint4 *da = nullptr, *db = nullptr;
+  HIP_TRY(h, dalloc(&da, slots + kRefSlack));
+  HIP_TRY(h, dalloc(&db, slots + kRefSlack));
+  HIP_TRY(h, hipMemset(da, 0, (slots + kRefSlack) * 16));
+  HIP_TRY(h, hipMemset(db, 0, (slots + kRefSlack) * 16));
+  HIP_TRY(h, hipMemcpy(da, hin.data(), slots * 16, hipMemcpyHostToDevice));
+  uint4 *cur = da, *oth = db;
+  g_force_fused = true;     // dilation 1 goes through the fused kernel here even when the pipeline does not use it
+  const hipError_t e_blk = ref_block_f16(h->stream, L1, L2, g, h->num_cu, dil, &cur, &oth, 1);
+  g_force_fused = false;
+  HIP_TRY(h, e_blk);
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  std::vector<_Float16> hout(slots * 8);
+  HIP_TRY(h, hipMemcpy(hout.data(), cur, slots * 16, hipMemcpyDeviceToHost));
+  for (int c = 0; c < kC; ++c)
+    for (int y = 0; y < h_px; ++y)
+      for (int x = 0; x < w; ++x) out[((size_t)c * h_px + y) * w + x] = (float)hout[idx(c, y, x)];
+  for (int c = 0; c < 4; ++c)        // the zero border of the result tensor must have survived
+    for (int y = 0; y < g.Hs; ++y)
+      for (int x = 0; x < g.Ws; ++x) {
+        if (y >= kRefPad && y < kRefPad + h_px && x >= kRefPad && x < kRefPad + w) continue;
+        for (int e = 0; e < 8; ++e)
+          if ((float)hout[(((size_t)c * g.Hs + y) * g.Ws + x) * 8 + e] != 0.f) {
+            set_err(h, "fp16 residual block wrote into the zero border");
+            return SN_ERR_DEVICE;
+          }
+      }
+  hipFree(da);
+  hipFree(db);
+  hipFree(L1.wfrag);
+  hipFree(L1.bias);
+  hipFree(L2.wfrag);
+  hipFree(L2.bias);
   return SN_OK;
 }
 

@@ -73,7 +73,8 @@ typedef struct sn_config {
   int dmax;          /* max disparity D (multiple of 16, <= 256); 0 = from the model file        */
   int precision;     /* SN_PREC_*                                                                 */
   int task_num;      /* async slots for sn_submit; <=0 -> 4 (stereonet_node.cpp:144)              */
-  int refine_chunk;  /* pairs refined together (activation residency); <=0 -> auto                */
+  int refine_chunk;  /* pairs per refinement-tower launch; <=0 -> 2                               */
+  int piece;         /* pairs per low-resolution piece of the two-stream pipeline; <=0 -> 8       */
 } sn_config;
 
 typedef struct sn_io_info {
@@ -147,6 +148,10 @@ int sn_dbg_conv3d(sn_handle *h, const float *in, int d, int h_px, int w, const f
  * fp32 [32][h][w] on the host; the hook converts to the kernel's fp16 NCHW8c layout and back. */
 int sn_dbg_ref_conv_f16(sn_handle *h, const float *in, int h_px, int w, const float *wt, const float *bias,
                         int dil, int lrelu, const float *residual, float *out);
+/* one residual block y = lrelu(x + conv2(lrelu(conv1(x)+b1)) + b2) of the fp16 tower, exactly as the pipeline runs it
+ * (one fused kernel for dilation 1, two convolution launches otherwise); fp32 [32][h][w] host tensors. */
+int sn_dbg_ref_block_f16(sn_handle *h, const float *in, int h_px, int w, const float *w1, const float *b1,
+                         const float *w2, const float *b2, int dil, float *out);
 /* intermediates of the most recent batch-1 inference: "feat_l" / "feat_r" [32][hl][wl],
  * "cost"... see DESIGN.md §6; returns the element count in *n (dst may be NULL to query). */
 int sn_dbg_read(sn_handle *h, const char *what, float *dst, size_t cap, size_t *n);

@@ -82,3 +82,40 @@ def test_padded_geometry_f16(model_factory, oracle, weights_blob):
         disp, _ = eng.infer(x)
     odisp, _, _ = oracle.forward(weights_blob, x, d)
     assert np.abs(disp - odisp).mean() < EPE_TOL
+
+
+@pytest.mark.parametrize("prec", [api.PREC_F16, api.PREC_FP32])
+def test_two_stream_piece_pipeline_is_bit_identical(model_factory, prec):
+    """n > piece switches on the two-stream pipeline (low-res of piece k+1 overlaps refinement of piece k);
+    results must equal the one-pair-at-a-time results bit for bit, including a ragged last piece."""
+    w, h, d = 160, 96, 96
+    xs = np.stack([synth.model_input_i8(w, h, d, 20 + s) for s in range(7)])
+    with api.StereoNetHIP(model_factory(w, h, d), precision=prec, max_batch=7, refine_chunk=2, piece=2) as eng:
+        disp, raw = eng.infer(xs)
+        disp2, raw2 = eng.infer(xs)
+        singles = [eng.infer(xs[i]) for i in range(7)]
+    assert (disp == disp2).all() and (raw == raw2).all()
+    for i in range(7):
+        assert (singles[i][0] == disp[i]).all() and (singles[i][1] == raw[i]).all(), i
+
+
+@pytest.mark.parametrize("h,w,dil", [(8, 62, 1), (64, 96, 1), (45, 80, 1), (100, 129, 1), (37, 250, 1), (720, 1280, 1),
+                                     (40, 70, 2)])
+def test_residual_block_f16(eng16, oracle, h, w, dil):
+    """y = lrelu(x + conv2(lrelu(conv1(x)+b1)) + b2): fused single-kernel form for dilation 1 (t never leaves LDS),
+    two launches otherwise.  Reference: oracle convs on fp16-rounded operands with t rounded to fp16."""
+    rng = np.random.default_rng(h * 7 + w + dil)
+    x = q16(rng.standard_normal((32, h, w)))
+    w1 = q16(rng.standard_normal((32, 32, 3, 3)) / 17.0)
+    w2 = q16(rng.standard_normal((32, 32, 3, 3)) / 17.0)
+    b1 = rng.standard_normal(32).astype(np.float32)
+    b2 = rng.standard_normal(32).astype(np.float32)
+    t = oracle.conv2d(x, w1, b1, 1, dil, dil)
+    t = q16(np.where(t > 0, t, t * np.float32(0.2)))
+    v = x + oracle.conv2d(t, w2, b2, 1, dil, dil)
+    ref = np.where(v > 0, v, v * np.float32(0.2))
+    got = eng16.dbg_ref_block_f16(x, w1, b1, w2, b2, dil)
+    scale = np.abs(ref).max()
+    # t may round differently by one fp16 ulp at a few positions (fp32 summation order), then one output rounding
+    assert np.abs(got - ref).max() <= 3e-3 * scale
+    assert np.abs(got - ref).mean() < 3e-4 * scale
