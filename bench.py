@@ -60,7 +60,8 @@ def pmc_traffic(kernel_match="k_ref_conv_f16"):
         return None, None
     if d.get("dominant_match") != kernel_match or not d.get("dominant_avg_hbm_bytes_per_launch"):
         return None, None
-    return float(d["dominant_avg_hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
+    per_pair = float(d["dominant_avg_hbm_bytes_per_launch"]) / float(d.get("pairs_per_launch", 1))
+    return per_pair, os.path.relpath(files[-1], ROOT)
 
 
 def main():
@@ -162,8 +163,8 @@ def main():
         if args.precision == "f16":
             traffic, traffic_src = pmc_traffic()
             if traffic is not None:
-                traffic *= args.refine_chunk / 1.0 if False else 1.0   # summary is per 1-pair launch; see traffic_pairs
-        roof.update({"traffic": traffic, "traffic_unit": "HBM bytes per 1-pair launch (PMC, 2xFETCH_SIZE+WRITE_SIZE)",
+                traffic *= args.refine_chunk           # summary is per pair; a launch covers refine_chunk pairs
+        roof.update({"traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, KiB->B)",
                      "traffic_source": traffic_src, "kernel": dk["name"], "avg_launch_ms": launch_ms,
                      "launches_per_refine_chunk": dk["launches"], "algorithmic_bytes_per_launch": dk["bytes_per_launch"],
                      "algorithmic_flops_per_launch": dk["flops_per_launch"], "tflops": tflops, "gbytes_per_s": gbs,

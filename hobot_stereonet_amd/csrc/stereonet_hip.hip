@@ -682,7 +682,7 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
   const int W = c.width > 0 ? c.width : (int)hd.width;
   const int H = c.height > 0 ? c.height : (int)hd.height;
   const int D = c.dmax > 0 ? c.dmax : (int)hd.dmax;
-  if (W <= 0 || H <= 0 || (W & 3) || (H & 1) || D < 16 || D % 16 || D > 256) return SN_ERR_ARG;
+  if (W <= 0 || H <= 0 || D < 16 || D % 16 || D > 256) return SN_ERR_ARG;   // NV12 entry points add w%4, h%2
   if (c.precision != SN_PREC_FP32 && c.precision != SN_PREC_F16) return SN_ERR_ARG;   // F16X3: not built yet
 
   int ndev = 0;
@@ -908,7 +908,7 @@ int sn_infer_sbs_nv12(sn_handle* h, const uint8_t* sbs, int w2, int h_px, int32_
                       int8_t* out_tensor, int mem, void* stream) {
   if (!h) return SN_ERR_ARG;
   // geometry check of FeedImg (stereonet_node.cpp:682-690): height == model h, width == 2 * model w
-  if (!sbs || (!out_i32 && !out_disp) || !pre_args_ok(h, w2 / 2, h_px) || (w2 & 1) ||
+  if (!sbs || (!out_i32 && !out_disp) || !pre_args_ok(h, w2 / 2, h_px) || (w2 & 7) || (h_px & 1) ||
       (mem != SN_MEM_HOST && mem != SN_MEM_DEVICE)) {
     set_err(h, "sn_infer_sbs_nv12: image size does not match the model input");
     return SN_ERR_ARG;

@@ -5,7 +5,7 @@ for gfx950: FETCH_SIZE under-reports wide coalesced reads by exactly 2x (TCC_EA0
 128-B requests) -> doubled; WRITE_SIZE is used as reported (it matches the known output bytes of the tower
 kernel exactly: 57,600 KiB = 720*1280*32*2 B).  Units in the CSV: KiB.
 
-    python scripts/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [match]
+    python scripts/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [match] [pairs_per_launch]
 """
 import collections
 import csv
@@ -25,6 +25,7 @@ def per_kernel(path):
 def main():
     fetch, write = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
     match = sys.argv[4] if len(sys.argv) > 4 else "k_ref_conv_f16"
+    pairs_per_launch = int(sys.argv[5]) if len(sys.argv) > 5 else 1
     out = {"unit": "bytes per launch", "correction": "2 x FETCH_SIZE (gfx950) + WRITE_SIZE, KiB -> bytes", "kernels": {}}
     tot_b, tot_n = 0.0, 0
     for k in sorted(fetch):
@@ -37,6 +38,7 @@ def main():
             tot_b += b * n
             tot_n += n
     out["dominant_match"] = match
+    out["pairs_per_launch"] = pairs_per_launch
     out["dominant_avg_hbm_bytes_per_launch"] = tot_b / tot_n if tot_n else None
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     print(json.dumps({k: round(v["hbm_bytes_per_launch"] / 1e6, 1) for k, v in out["kernels"].items()}, indent=0))

@@ -198,3 +198,31 @@ def test_error_behaviour(model_factory, tmp_path):
             eng.infer(np.zeros((6, 32, 32), np.int8))           # geometry mismatch (stereonet_node.cpp:682-690)
         with pytest.raises(api.StereoNetError):
             eng.infer(np.zeros((3, 6, 64, 96), np.int8))        # n > max_batch
+
+
+@pytest.mark.parametrize("prec", [api.PREC_FP32, api.PREC_F16])
+def test_baseline_config_c1_960x540_d48(model_factory, oracle, weights_blob, prec):
+    """BASELINE.json configs[0] shape: one 960x540 pair, D=48 (H is padded to 544 internally and cropped)."""
+    w, h, d = 960, 540, 48
+    x = synth.model_input_i8(w, h, d, 21)
+    with api.StereoNetHIP(model_factory(w, h, d), precision=prec) as eng:
+        disp, raw = eng.infer(x)
+    odisp, oraw, _ = oracle.forward(weights_blob, x, d)
+    epe = float(np.abs(disp - odisp).mean())
+    print(f"C1 960x540 D=48 prec={prec}: EPE {epe:.3e} px")
+    assert disp.shape == (h, w) and epe < EPE_TOL
+
+
+@pytest.mark.parametrize("prec", [api.PREC_FP32, api.PREC_F16])
+def test_baseline_config_c5_kitti_1242x375_d256(model_factory, oracle, weights_blob, prec):
+    """BASELINE.json configs[4] shape: KITTI-2015 1242x375, D=256 (16 planes; padded to 1248x384)."""
+    w, h, d = 1242, 375, 256
+    x = synth.model_input_i8(w, h, d, 22)
+    with api.StereoNetHIP(model_factory(w, h, d), precision=prec) as eng:
+        disp, raw = eng.infer(x)
+    odisp, oraw, _ = oracle.forward(weights_blob, x, d)
+    epe = float(np.abs(disp - odisp).mean())
+    print(f"C5 1242x375 D=256 prec={prec}: EPE {epe:.3e} px")
+    assert disp.shape == (h, w) and epe < EPE_TOL
+    inv_q = np.float32(1.0 / (float(d) * float(np.float32(spec.OUT_SCALE))))
+    assert (raw == np.rint(disp * inv_q).astype(np.int32)).all()
