@@ -247,7 +247,9 @@ class StereoNetHIP:
                                                   int(lrelu), _np_ptr(res), out.ctypes.data), "sn_dbg_ref_conv_f16")
         return out
 
-    def dbg_ref_block_f16(self, x, w1, b1, w2, b2, dil=1):
+    def dbg_ref_block_f16(self, x, w1, b1, w2, b2, dil=1, fused=0):
+        """fused: 0 = two conv launches, 1 = single-role fused kernel, 2 = wave-specialised fused kernel (dil 1 only)"""
+        dil = dil | (fused << 8)
         a = [np.ascontiguousarray(v, np.float32) for v in (x, w1, b1, w2, b2)]
         _, h, w = a[0].shape
         out = np.empty((32, h, w), np.float32)

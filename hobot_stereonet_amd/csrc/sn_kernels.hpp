@@ -1071,6 +1071,283 @@ __global__ __launch_bounds__(256, 1) void k_ref_block_f16(const uint4* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Wave-specialised fused residual block (second generation).  One 512-thread workgroup per CU:
+//   waves 0-3 ("stage 1"): conv1 of tile k   — x half-tiles stream through a 3-deep LDS-DMA ring (as v2),
+//                          t = lrelu(conv1(x)+b1) is written to LDS buffer T[k & 1];
+//   waves 4-7 ("stage 2"): conv2 of tile k-1 — reads T[(k-1) & 1], adds bias + residual x (8-byte global
+//                          loads, L2-resident: the same lines were just streamed in), LeakyReLU, stores y.
+// Every SIMD therefore holds one wave of each role: while one wave is in its epilogue / address math the
+// other one feeds the matrix pipe — this is what the single-role fused kernel above lacks.  Both roles
+// meet at two s_barriers per tile (one per 16-channel phase of stage 1); T is double buffered so stage 2
+// of tile k-1 and stage 1 of tile k never touch the same buffer.  HBM traffic per block: one read of x (plus
+// halo, L2-absorbed) and one write of y.
+// vmcnt bookkeeping is per wave, so each role counts only its own VMEM ops: stage 1 issues KW LDS-DMA
+// instructions per phase and nothing else; stage 2 issues 16 asm residual loads and 16 stores per tile.
+// ------------------------------------------------------------------------------------------
+template <int DIL>
+struct FusedWsTile {
+  // TH = 6: 8 t rows = 16 segments = 4 per stage-1 wave (64 accumulator registers) and 12 output segments
+  // = 3 per stage-2 wave; with TH = 8 (5 + 4 segments) the kernel needs > 256 registers per wave and spills.
+  static constexpr int TH = 6, TWO = 64 - 2 * DIL;
+  static constexpr int RT = TH + 2 * DIL, CT = 64;
+  static constexpr int RX = TH + 4 * DIL, CX = 64 + 2 * DIL;
+  static constexpr int PX = RX * CX, PT = RT * CT;
+  static constexpr int XHALF = 2 * PX;
+  static constexpr int NINST = (XHALF + 63) / 64;
+  static constexpr int KW = (NINST + 3) / 4;                  // per stage-1 wave per phase
+  static constexpr int XBUF = NINST * 64;
+  static constexpr int TBUF = 4 * PT + 64;
+  static constexpr int LDS_BYTES = (3 * XBUF + 2 * TBUF) * 16 + 256;   // + 64 bias floats
+  static constexpr int S1 = RT * 2 / 4, S2 = TH * 2 / 4;
+  static constexpr int NSTORE = 4 * S2;
+  static_assert((RT * 2) % 4 == 0 && (TH * 2) % 4 == 0, "segments must split over the 4 waves of each role");
+  static_assert(LDS_BYTES <= 160 * 1024, "does not fit the LDS at this dilation");
+};
+
+
+template <int DIL>
+__global__ __launch_bounds__(512, 2) void k_ref_block_f16_ws(const uint4* __restrict__ xin, uint4* __restrict__ yout,
+                                                             const uint4* __restrict__ wfrag1, const float* __restrict__ bias1,
+                                                             const uint4* __restrict__ wfrag2, const float* __restrict__ bias2,
+                                                             RefGeom g, int nimg, uint4* zero_slot) {
+  using T = FusedWsTile<DIL>;
+  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+  uint4* xring = lds;                        // 3 half-tile buffers
+  uint4* tbase = lds + 3 * T::XBUF;          // T[0], T[1]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool s1 = wave8 < 4;                 // wave-uniform role
+  const int wave = wave8 & 3;                // index inside the role
+  const int j_ = lane & 31, gh_ = lane >> 5;
+
+  // role-specific weights / bias live in the SAME registers
+  const uint4* wsrc = s1 ? wfrag1 : wfrag2;
+  const float* bsrc = s1 ? bias1 : bias2;
+  half8 wf[18];
+#pragma unroll
+  for (int i = 0; i < 18; ++i) {
+    const uint4 v = wsrc[i * 64 + lane];
+    wf[i] = *reinterpret_cast<const half8*>(&v);
+  }
+  // biases go to LDS (read back as float4 in the epilogues): 16 fewer live registers per wave
+  float* bl = reinterpret_cast<float*>(tbase + 2 * T::TBUF);
+  if (tid < 32) bl[tid] = bias1[tid];
+  else if (tid < 64) bl[tid] = bias2[tid - 32];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  const float* bmine0 = bl + (s1 ? 0 : 32);
+  (void)bsrc;
+#pragma unroll
+  for (int i = 0; i < 18; ++i) asm volatile("" : "+v"(wf[i]));
+
+  const int per_img = g.tiles_x * g.tiles_y;
+  const int total = per_img * nimg;
+  const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, nlb = gridDim.x >> 3;
+  const int t_begin = (int)((long)xcd * total / 8), t_end = (int)((long)(xcd + 1) * total / 8);
+  const int t0 = t_begin + lb;
+  if (t0 >= t_end) return;
+  const int ntiles = (t_end - t0 + nlb - 1) / nlb;
+  const int G = 2 * ntiles;                  // stage-1 phases
+
+  auto tile_xy = [&](int ti, int& img, int& y0, int& x0) {
+    const int t = t0 + ti * nlb;
+    img = t / per_img;
+    const int rem = t - img * per_img;
+    const int ty = rem / g.tiles_x;
+    y0 = ty * T::TH;
+    x0 = (rem - ty * g.tiles_x) * T::TWO;
+  };
+  auto issue = [&](int gp) {                 // stage-1 waves only: x half-tile of phase gp -> ring slot gp % 3
+    int img, y0, x0;
+    tile_xy(gp >> 1, img, y0, x0);
+    const int kk = gp & 1;
+    uint4* dst = xring + (gp % 3) * T::XBUF;
+    int lq = lane;
+    asm volatile("" : "+v"(lq));             // keep the per-lane slot decomposition out of the loop-invariant set
+#pragma unroll
+    for (int k = 0; k < T::KW; ++k) {
+      int i = wave + 4 * k;
+      i = i < T::NINST ? i : T::NINST - 1;
+      int s = i * 64 + lq;
+      s = s < T::XHALF ? s : T::XHALF - 1;
+      const int pc = s / T::PX;
+      const int rem = s - pc * T::PX;
+      const int r = rem / T::CX;
+      const int c = rem - r * T::CX;
+      const size_t slot = (((size_t)img * 4 + (2 * kk + pc)) * g.Hs + (y0 + r - 2 * DIL + kRefPad)) * g.Ws +
+                          (x0 + c - 2 * DIL + kRefPad);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xin + slot),
+                                       (__attribute__((address_space(3))) void*)(dst + i * 64), 16, 0, 0);
+    }
+  };
+
+  wait_vmcnt<0>();
+  if (s1) {
+    issue(0);
+    issue(1);
+  }
+
+  f32x16 acc[T::S1];                         // stage 2 uses the first S2 of them
+  uint2 rres[T::NSTORE];
+  for (int k = 0; k <= ntiles; ++k) {
+    const bool a1 = s1 && k < ntiles;        // stage 1 works on tile k
+    const bool a2 = !s1 && k >= 1;           // stage 2 works on tile k-1
+    int j = j_, gh = gh_;                    // opaque copies: per-lane addresses are recomputed per tile instead of
+    asm volatile("" : "+v"(j), "+v"(gh));    // being hoisted out of the loop (that spilled ~25 VGPRs to scratch)
+    const int g0 = 2 * k;
+    int img = 0, y0 = 0, x0 = 0;
+    if (a1) tile_xy(k, img, y0, x0);
+    if (a2) tile_xy(k - 1, img, y0, x0);
+    uint4* tw = tbase + (k & 1) * T::TBUF;               // stage 1 writes
+    const uint4* tr = tbase + ((k - 1) & 1) * T::TBUF;   // stage 2 reads
+
+    // ================= phase A (input channels 0..15) =================
+    if (a1) {
+      if (g0 + 1 < G) wait_vmcnt<T::KW>(); else wait_vmcnt<0>();     // group g0 landed (g0+1 may fly)
+    }
+    __builtin_amdgcn_s_barrier();
+    if (a1) {
+      if (g0 + 2 < G) issue(g0 + 2);
+#pragma unroll
+      for (int s = 0; s < T::S1; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+      const uint4* base = xring + (g0 % 3) * T::XBUF + gh * T::PX + j;
+      const int seg0 = wave * T::S1;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        if (kx == 0 && ky > 0) __builtin_amdgcn_sched_barrier(0);   // bound the B fragments in flight (VGPRs)
+#pragma unroll
+        for (int s = 0; s < T::S1; ++s) {
+          const int seg = seg0 + s;
+          const int off = ((seg >> 1) + ky * DIL) * T::CX + (seg & 1) * 32 + kx * DIL;
+          const half8 v = *reinterpret_cast<const half8*>(base + off);
+          acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[tap * 2 + 0], v, acc[s], 0, 0, 0);
+        }
+      }
+    } else if (a2) {
+      // residual x of tile k-1: 16 eight-byte loads, hidden from hipcc (they must not drain anything)
+      const int seg0 = wave * T::S2;
+#pragma unroll
+      for (int s = 0; s < T::S2; ++s) {
+        const int seg = seg0 + s;
+        const int y = y0 + (seg >> 1), x = x0 + (seg & 1) * 32 + j;
+        const size_t slot0 = ((size_t)img * 4 * g.Hs + (y + kRefPad)) * g.Ws + (x + kRefPad);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const char* rp = reinterpret_cast<const char*>(xin) + (slot0 + (size_t)q * g.Hs * g.Ws) * 16 + gh * 8;
+          asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rres[s * 4 + q]) : "v"(rp) : "memory");
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < T::S2; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+      const uint4* base = tr + gh * T::PT + j;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        if (kx == 0 && ky > 0) __builtin_amdgcn_sched_barrier(0);   // bound the B fragments in flight (VGPRs)
+#pragma unroll
+        for (int s = 0; s < T::S2; ++s) {
+          const int seg = seg0 + s;
+          const int off = ((seg >> 1) + ky * DIL) * T::CT + (seg & 1) * 32 + kx * DIL;
+          const half8 v = *reinterpret_cast<const half8*>(base + off);
+          acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[tap * 2 + 0], v, acc[s], 0, 0, 0);
+        }
+      }
+    }
+
+    // ================= phase B (input channels 16..31) =================
+    if (a1) {
+      if (g0 + 2 < G) wait_vmcnt<T::KW>(); else wait_vmcnt<0>();     // group g0+1 landed (g0+2 may fly)
+    }
+    __builtin_amdgcn_s_barrier();
+    if (a1) {
+      if (g0 + 3 < G) issue(g0 + 3);
+      const uint4* base = xring + ((g0 + 1) % 3) * T::XBUF + gh * T::PX + j;
+      const int seg0 = wave * T::S1;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        if (kx == 0 && ky > 0) __builtin_amdgcn_sched_barrier(0);   // bound the B fragments in flight (VGPRs)
+#pragma unroll
+        for (int s = 0; s < T::S1; ++s) {
+          const int seg = seg0 + s;
+          const int off = ((seg >> 1) + ky * DIL) * T::CX + (seg & 1) * 32 + kx * DIL;
+          const half8 v = *reinterpret_cast<const half8*>(base + off);
+          acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[tap * 2 + 1], v, acc[s], 0, 0, 0);
+        }
+      }
+      // t -> T[k & 1]; positions outside the image are conv2's zero padding
+#pragma unroll
+      for (int s = 0; s < T::S1; ++s) {
+        const int seg = seg0 + s;
+        const int trow = seg >> 1, tcol = (seg & 1) * 32 + j;
+        const int gy = y0 - DIL + trow, gx = x0 - DIL + tcol;
+        const bool inside = (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 b4 = *reinterpret_cast<const float4*>(bmine0 + 4 * gh + 8 * q);
+          const float bq[4] = {b4.x, b4.y, b4.z, b4.w};
+          half4 hv;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float u = acc[s][4 * q + e] + bq[e];
+            u = fmaxf(u, u * kSlope);
+            hv[e] = inside ? (_Float16)u : (_Float16)0.f;
+          }
+          *reinterpret_cast<half4*>(reinterpret_cast<char*>(tw + q * T::PT + trow * T::CT + tcol) + gh * 8) = hv;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // T[k&1] complete before the next barrier
+    } else if (a2) {
+      const int seg0 = wave * T::S2;
+      const uint4* base = tr + (2 + gh) * T::PT + j;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        if (kx == 0 && ky > 0) __builtin_amdgcn_sched_barrier(0);   // bound the B fragments in flight (VGPRs)
+#pragma unroll
+        for (int s = 0; s < T::S2; ++s) {
+          const int seg = seg0 + s;
+          const int off = ((seg >> 1) + ky * DIL) * T::CT + (seg & 1) * 32 + kx * DIL;
+          const half8 v = *reinterpret_cast<const half8*>(base + off);
+          acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[tap * 2 + 1], v, acc[s], 0, 0, 0);
+        }
+      }
+      wait_vmcnt<0>();                                        // residual loads (and older stores) retired
+#pragma unroll
+      for (int i = 0; i < T::NSTORE; ++i) asm volatile("" : "+v"(rres[i]));
+#pragma unroll
+      for (int s = 0; s < T::S2; ++s) {
+        const int seg = seg0 + s;
+        const int orow = seg >> 1, ocol = (seg & 1) * 32 + j;
+        const int y = y0 + orow, x = x0 + ocol;
+        const bool ok = ocol < T::TWO && y < g.H && x < g.W;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint2 rw = rres[s * 4 + q];
+          const half4 rv = *reinterpret_cast<const half4*>(&rw);
+          const float4 b4 = *reinterpret_cast<const float4*>(bmine0 + 4 * gh + 8 * q);
+          const float bq[4] = {b4.x, b4.y, b4.z, b4.w};
+          half4 hv;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float u = acc[s][4 * q + e] + bq[e] + (float)rv[e];
+            u = fmaxf(u, u * kSlope);
+            hv[e] = ok ? (_Float16)u : (_Float16)0.f;
+          }
+          uint4* dst = ok ? yout + ((((size_t)img * 4 + q) * g.Hs + (y + kRefPad)) * g.Ws + (x + kRefPad)) : zero_slot;
+          *reinterpret_cast<half4*>(reinterpret_cast<char*>(dst) + gh * 8) = hv;
+        }
+      }
+    }
+  }
+}
+
 // K8 for the fp16 tower: 3x3 conv 32->1 on the NCHW8c tensor, disp = relu(up + D*r), outputs as k_head_final.
 __global__ __launch_bounds__(256) void k_head_final_f16(const uint4* __restrict__ xin, RefGeom g,
                                                         const float* __restrict__ w,      // [32][9]

@@ -242,7 +242,13 @@ template <int DIL>
 hipError_t conv3x3_d(hipStream_t st, const ConvLayer& L, const float* in, int nimg, int H, int W, float* out,
                      const float* res, bool lrelu) {
   LoadF32 ld{in, kC, H, W};
-  if (H * W <= 64 * 128) return launch_conv<3, 1, DIL, 8, 4, 32>(st, L, ld, nimg, H, W, out, res, lrelu);
+  static const int lmode = getenv("SN_LOW_MODE") ? atoi(getenv("SN_LOW_MODE")) : 0;
+  if (H * W <= 64 * 128) {
+    if (DIL == 1 && lmode == 1) return launch_conv<3, 1, 1, 16, 4, 32>(st, L, ld, nimg, H, W, out, res, lrelu);
+    if (DIL == 1 && lmode == 2) return launch_conv<3, 1, 1, 8, 8, 32>(st, L, ld, nimg, H, W, out, res, lrelu);
+    if (DIL == 1 && lmode == 3) return launch_conv<3, 1, 1, 16, 8, 32>(st, L, ld, nimg, H, W, out, res, lrelu);
+    return launch_conv<3, 1, DIL, 8, 4, 32>(st, L, ld, nimg, H, W, out, res, lrelu);
+  }
   if (DIL >= 4) return launch_conv<3, 1, DIL, 4, 16, 64>(st, L, ld, nimg, H, W, out, res, lrelu);
   return launch_conv<3, 1, DIL, 8, 8, 64>(st, L, ld, nimg, H, W, out, res, lrelu);
 }
@@ -374,18 +380,42 @@ hipError_t launch_ref_block_f16(hipStream_t st, const RefLayerF16& L1, const Ref
   return hipGetLastError();
 }
 
+template <int DIL>
+hipError_t launch_ref_block_f16_ws(hipStream_t st, const RefLayerF16& L1, const RefLayerF16& L2, const RefGeom& g,
+                                   int num_cu, const uint4* x, uint4* y, int nimg) {
+  using T = FusedWsTile<DIL>;
+  auto kern = k_ref_block_f16_ws<DIL>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     T::LDS_BYTES);
+  if (e != hipSuccess) return e;
+  RefGeom gt = g;
+  gt.tiles_x = (g.W + T::TWO - 1) / T::TWO;
+  gt.tiles_y = (g.H + T::TH - 1) / T::TH;
+  const int total = gt.tiles_x * gt.tiles_y * nimg;
+  const int band = (total + 7) / 8;
+  int cap = num_cu / 8;
+  if (cap < 1) cap = 1;
+  const int rounds = (band + cap - 1) / cap;
+  const int nlb = (band + rounds - 1) / rounds;
+  hipLaunchKernelGGL(kern, dim3(nlb * 8), dim3(512), T::LDS_BYTES, st, x, y, L1.wfrag, L1.bias, L2.wfrag, L2.bias, gt,
+                     nimg, y);
+  return hipGetLastError();
+}
+
+int fuse_mode() {   // 0 = two v2 launches, 1 = single-role fused kernel, 2 = wave-specialised fused kernel
+  static const int m = getenv("SN_FUSE") ? atoi(getenv("SN_FUSE")) : 0;
+  return getenv("SN_REF_V1") ? 0 : m;
+}
+
 // Opt-in (SN_FUSE=1): correct and parity-tested, but with one wave per SIMD its per-tile VALU work is exposed
 // and it is currently ~12 % slower than the two v2 launches it replaces ("fused block").
-bool g_force_fused = false;   // the parity hook sets this to exercise the fused kernel regardless of the env
-bool use_fused_block(int dil) {
-  static const bool on = getenv("SN_FUSE") != nullptr && getenv("SN_REF_V1") == nullptr;
-  return dil == 1 && (on || g_force_fused);
+int g_force_fused = 0;   // the parity hook sets this to exercise a fused kernel regardless of the env
+int use_fused_block(int dil) {
+  if (dil != 1) return 0;
+  return g_force_fused ? g_force_fused : fuse_mode();
 }
 
 // One residual block of the fp16 tower on `*cur` (input and, on return, output); `*oth` is scratch.
-hipError_t ref_block_f16(hipStream_t st, const RefLayerF16& L1, const RefLayerF16& L2, const RefGeom& g, int num_cu,
-                         int dil, uint4** cur, uint4** oth, int nimg);
-
 bool use_ref_v1() {
   static const bool v = getenv("SN_REF_V1") != nullptr;   // A/B switch for the first-generation tower kernel
   return v;
@@ -413,8 +443,9 @@ hipError_t ref_conv_f16(hipStream_t st, const RefLayerF16& L, const RefGeom& g, 
 
 hipError_t ref_block_f16(hipStream_t st, const RefLayerF16& L1, const RefLayerF16& L2, const RefGeom& g, int num_cu,
                          int dil, uint4** cur, uint4** oth, int nimg) {
-  if (use_fused_block(dil)) {
-    hipError_t e = launch_ref_block_f16<1>(st, L1, L2, g, num_cu, *cur, *oth, nimg);
+  if (const int fm = use_fused_block(dil)) {
+    hipError_t e = fm == 2 ? launch_ref_block_f16_ws<1>(st, L1, L2, g, num_cu, *cur, *oth, nimg)
+                           : launch_ref_block_f16<1>(st, L1, L2, g, num_cu, *cur, *oth, nimg);
     uint4* t = *cur;
     *cur = *oth;
     *oth = t;
@@ -503,10 +534,18 @@ int lowres(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, const int
 
   // --- cost volume (fused into the first 3-D conv's loader) + 3-D aggregation + soft-argmin ---
   LoadCostVol ld{ws.feat, Dl, hl, wl};
-  HIP_TRY(h, (launch_conv<3, 1, 1, 8, 4, 32>(st, h->agg[0], ld, m * Dl, hl, wl, ws.vol[0], nullptr, true)));
+  static const int amode = getenv("SN_AGG_MODE") ? atoi(getenv("SN_AGG_MODE")) : 0;
+  if (amode == 1) HIP_TRY(h, (launch_conv<3, 1, 1, 16, 4, 32>(st, h->agg[0], ld, m * Dl, hl, wl, ws.vol[0], nullptr, true)));
+  else if (amode == 2) HIP_TRY(h, (launch_conv<3, 1, 1, 8, 8, 32>(st, h->agg[0], ld, m * Dl, hl, wl, ws.vol[0], nullptr, true)));
+  else if (amode == 3) HIP_TRY(h, (launch_conv<3, 1, 1, 16, 8, 32>(st, h->agg[0], ld, m * Dl, hl, wl, ws.vol[0], nullptr, true)));
+  else HIP_TRY(h, (launch_conv<3, 1, 1, 8, 4, 32>(st, h->agg[0], ld, m * Dl, hl, wl, ws.vol[0], nullptr, true)));
   for (int i = 1; i < kNAgg; ++i) {
     LoadVol3D lv{ws.vol[(i - 1) & 1], Dl, hl, wl};
-    HIP_TRY(h, (launch_conv<3, 1, 1, 8, 4, 32>(st, h->agg[i], lv, m * Dl, hl, wl, ws.vol[i & 1], nullptr, true)));
+    float* o = ws.vol[i & 1];
+    if (amode == 1) HIP_TRY(h, (launch_conv<3, 1, 1, 16, 4, 32>(st, h->agg[i], lv, m * Dl, hl, wl, o, nullptr, true)));
+    else if (amode == 2) HIP_TRY(h, (launch_conv<3, 1, 1, 8, 8, 32>(st, h->agg[i], lv, m * Dl, hl, wl, o, nullptr, true)));
+    else if (amode == 3) HIP_TRY(h, (launch_conv<3, 1, 1, 16, 8, 32>(st, h->agg[i], lv, m * Dl, hl, wl, o, nullptr, true)));
+    else HIP_TRY(h, (launch_conv<3, 1, 1, 8, 4, 32>(st, h->agg[i], lv, m * Dl, hl, wl, o, nullptr, true)));
   }
   const float* v = ws.vol[(kNAgg - 1) & 1];
   const int npix = m * hl * wl;
@@ -556,9 +595,15 @@ int refine(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, const int
       if (Hp * Wp <= 64 * 128)
         HIP_TRY(h, (launch_conv<3, 1, 1, 4, 4, 32, LoadRefineIn, 1>(st, h->rin, ld, c, Hp, Wp, reinterpret_cast<float*>(rx),
                                                                   nullptr, true, g.Hs, g.Ws)));
-      else
-        HIP_TRY(h, (launch_conv<3, 1, 1, 4, 8, 64, LoadRefineIn, 1>(st, h->rin, ld, c, Hp, Wp, reinterpret_cast<float*>(rx),
-                                                                  nullptr, true, g.Hs, g.Ws)));
+      else {
+        static const int rmode = getenv("SN_RIN_MODE") ? atoi(getenv("SN_RIN_MODE")) : 0;
+        if (rmode == 1)
+          HIP_TRY(h, (launch_conv<3, 1, 1, 4, 4, 64, LoadRefineIn, 1>(st, h->rin, ld, c, Hp, Wp, reinterpret_cast<float*>(rx),
+                                                                    nullptr, true, g.Hs, g.Ws)));
+        else
+          HIP_TRY(h, (launch_conv<3, 1, 1, 4, 8, 64, LoadRefineIn, 1>(st, h->rin, ld, c, Hp, Wp, reinterpret_cast<float*>(rx),
+                                                                    nullptr, true, g.Hs, g.Ws)));
+      }
       if (pe) HIP_TRY(h, hipEventRecord(h->ev[4], st));
       for (int i = 0; i < kNRefRes; ++i)
         HIP_TRY(h, ref_block_f16(st, h->rres16[i][0], h->rres16[i][1], g, h->num_cu, kRefDil[i], &rx, &rt, c));
@@ -1217,6 +1262,8 @@ int sn_dbg_ref_conv_f16(sn_handle* h, const float* in, int h_px, int w, const fl
 int sn_dbg_ref_block_f16(sn_handle* h, const float* in, int h_px, int w, const float* w1, const float* b1,
                          const float* w2, const float* b2, int dil, float* out) {
   if (!h || !in || !w1 || !b1 || !w2 || !b2 || !out || h_px <= 0 || w <= 0) return SN_ERR_ARG;
+  const int fmode = dil >> 8;          // tests: bits 8.. select the fused variant (1 single-role, 2 wave-specialised)
+  dil &= 0xff;
   if (dil != 1 && dil != 2 && dil != 4 && dil != 8) return SN_ERR_ARG;
   int rc = check_device(h);
   if (rc) return rc;
@@ -1237,9 +1284,9 @@ int sn_dbg_ref_block_f16(sn_handle* h, const float* in, int h_px, int w, const f
   HIP_TRY(h, hipMemset(db, 0, (slots + kRefSlack) * 16));
   HIP_TRY(h, hipMemcpy(da, hin.data(), slots * 16, hipMemcpyHostToDevice));
   uint4 *cur = da, *oth = db;
-  g_force_fused = true;     // dilation 1 goes through the fused kernel here even when the pipeline does not use it
+  g_force_fused = fmode;    // dilation 1 can go through a fused kernel here even when the pipeline does not use it
   const hipError_t e_blk = ref_block_f16(h->stream, L1, L2, g, h->num_cu, dil, &cur, &oth, 1);
-  g_force_fused = false;
+  g_force_fused = 0;
   HIP_TRY(h, e_blk);
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   std::vector<_Float16> hout(slots * 8);

@@ -99,9 +99,10 @@ def test_two_stream_piece_pipeline_is_bit_identical(model_factory, prec):
         assert (singles[i][0] == disp[i]).all() and (singles[i][1] == raw[i]).all(), i
 
 
+@pytest.mark.parametrize("fused", [0, 1, 2])
 @pytest.mark.parametrize("h,w,dil", [(8, 62, 1), (64, 96, 1), (45, 80, 1), (100, 129, 1), (37, 250, 1), (720, 1280, 1),
                                      (40, 70, 2)])
-def test_residual_block_f16(eng16, oracle, h, w, dil):
+def test_residual_block_f16(eng16, oracle, h, w, dil, fused):
     """y = lrelu(x + conv2(lrelu(conv1(x)+b1)) + b2): fused single-kernel form for dilation 1 (t never leaves LDS),
     two launches otherwise.  Reference: oracle convs on fp16-rounded operands with t rounded to fp16."""
     rng = np.random.default_rng(h * 7 + w + dil)
@@ -114,7 +115,7 @@ def test_residual_block_f16(eng16, oracle, h, w, dil):
     t = q16(np.where(t > 0, t, t * np.float32(0.2)))
     v = x + oracle.conv2d(t, w2, b2, 1, dil, dil)
     ref = np.where(v > 0, v, v * np.float32(0.2))
-    got = eng16.dbg_ref_block_f16(x, w1, b1, w2, b2, dil)
+    got = eng16.dbg_ref_block_f16(x, w1, b1, w2, b2, dil, fused)
     scale = np.abs(ref).max()
     # t may round differently by one fp16 ulp at a few positions (fp32 summation order), then one output rounding
     assert np.abs(got - ref).max() <= 3e-3 * scale
