@@ -108,17 +108,30 @@ def main():
     host = np.concatenate([host] * ((B + uniq - 1) // uniq))[:B]
     dev = torch.device("cuda", local_rank)
     x = torch.from_numpy(host).to(dev)
-    raw = torch.empty((B, H, W), dtype=torch.int32, device=dev)
-    disp = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    raws = [torch.empty((B, H, W), dtype=torch.int32, device=dev) for _ in range(2)]   # double buffered: the
+    raw = raws[0]                                                                       # gather of step i overlaps
+    disp = torch.empty((B, H, W), dtype=torch.float32, device=dev)                      # the compute of step i+1
     from hobot_stereonet_amd import dist as sdist
 
+    pending = [None, None]
+    counter = [0]
+
     def step():
+        i = counter[0] & 1
+        counter[0] += 1
+        if pending[i] is not None:          # the gather that still reads raws[i] (issued two steps ago)
+            pending[i].wait()
+            pending[i] = None
         st = torch.cuda.current_stream().cuda_stream
-        eng.infer_device(B, x.data_ptr(), raw.data_ptr(), disp.data_ptr(), st)
+        eng.infer_device(B, x.data_ptr(), raws[i].data_ptr(), disp.data_ptr(), st)
         if world > 1:      # the path's one exchange: int32 disparity maps -> rank 0 (RCCL over xGMI)
-            sdist.gather_to_root(raw, [B] * world, dst=0)
+            pending[i] = sdist.AsyncGather(raws[i], dst=0)
 
     def sync_all():
+        for i in range(2):
+            if pending[i] is not None:
+                pending[i].wait()
+                pending[i] = None
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

@@ -242,13 +242,8 @@ template <int DIL>
 hipError_t conv3x3_d(hipStream_t st, const ConvLayer& L, const float* in, int nimg, int H, int W, float* out,
                      const float* res, bool lrelu) {
   LoadF32 ld{in, kC, H, W};
-  static const int lmode = getenv("SN_LOW_MODE") ? atoi(getenv("SN_LOW_MODE")) : 0;
-  if (H * W <= 64 * 128) {
-    if (DIL == 1 && lmode == 1) return launch_conv<3, 1, 1, 16, 4, 32>(st, L, ld, nimg, H, W, out, res, lrelu);
-    if (DIL == 1 && lmode == 2) return launch_conv<3, 1, 1, 8, 8, 32>(st, L, ld, nimg, H, W, out, res, lrelu);
-    if (DIL == 1 && lmode == 3) return launch_conv<3, 1, 1, 16, 8, 32>(st, L, ld, nimg, H, W, out, res, lrelu);
-    return launch_conv<3, 1, DIL, 8, 4, 32>(st, L, ld, nimg, H, W, out, res, lrelu);
-  }
+  // (chunk sizes 8/16 and tile heights 4/8 measured equal within noise on the 45x80 low-resolution maps)
+  if (H * W <= 64 * 128) return launch_conv<3, 1, DIL, 8, 4, 32>(st, L, ld, nimg, H, W, out, res, lrelu);
   if (DIL >= 4) return launch_conv<3, 1, DIL, 4, 16, 64>(st, L, ld, nimg, H, W, out, res, lrelu);
   return launch_conv<3, 1, DIL, 8, 8, 64>(st, L, ld, nimg, H, W, out, res, lrelu);
 }
@@ -339,19 +334,14 @@ hipError_t launch_ref_f16_v2(hipStream_t st, const RefLayerF16& L, const RefGeom
   RefGeom gt = g;                      // tile grid of this variant (the buffer geometry is for 8x64 tiles)
   gt.tiles_x = (g.W + TW - 1) / TW;
   const int total = gt.tiles_x * gt.tiles_y * nimg;
-  static const int per_cu_env = getenv("SN_REF_PER_CU") ? atoi(getenv("SN_REF_PER_CU")) : 0;
-  int per_cu = T::LDS_BYTES * 2 <= 160 * 1024 ? 2 : 1;
-  if (per_cu_env > 0 && per_cu_env < per_cu) per_cu = per_cu_env;
+  const int per_cu = T::LDS_BYTES * 2 <= 160 * 1024 ? 2 : 1;
   // persistent grid: 8 XCD bands; pick the block count per band so that every block walks the same number
   // of tiles (e.g. 225 tiles per band -> 57 blocks x 4 tiles, not 64 blocks x 3.5)
   const int band = (total + 7) / 8;
   int cap = num_cu * per_cu / 8;
-  static const int cap_env = getenv("SN_REF_NLB") ? atoi(getenv("SN_REF_NLB")) : 0;
-  if (cap_env > 0) cap = cap_env;
   if (cap < 1) cap = 1;
   const int rounds = (band + cap - 1) / cap;
-  int nlb = (band + rounds - 1) / rounds;
-  if (cap_env > 0) nlb = cap_env < band ? cap_env : band;
+  const int nlb = (band + rounds - 1) / rounds;
   const int blocks = nlb * 8;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), T::LDS_BYTES, st, in, out, res, L.wfrag, L.bias, gt, nimg,
                      lrelu ? 1 : 0);
@@ -534,18 +524,10 @@ int lowres(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, const int
 
   // --- cost volume (fused into the first 3-D conv's loader) + 3-D aggregation + soft-argmin ---
   LoadCostVol ld{ws.feat, Dl, hl, wl};
-  static const int amode = getenv("SN_AGG_MODE") ? atoi(getenv("SN_AGG_MODE")) : 0;
-  if (amode == 1) HIP_TRY(h, (launch_conv<3, 1, 1, 16, 4, 32>(st, h->agg[0], ld, m * Dl, hl, wl, ws.vol[0], nullptr, true)));
-  else if (amode == 2) HIP_TRY(h, (launch_conv<3, 1, 1, 8, 8, 32>(st, h->agg[0], ld, m * Dl, hl, wl, ws.vol[0], nullptr, true)));
-  else if (amode == 3) HIP_TRY(h, (launch_conv<3, 1, 1, 16, 8, 32>(st, h->agg[0], ld, m * Dl, hl, wl, ws.vol[0], nullptr, true)));
-  else HIP_TRY(h, (launch_conv<3, 1, 1, 8, 4, 32>(st, h->agg[0], ld, m * Dl, hl, wl, ws.vol[0], nullptr, true)));
+  HIP_TRY(h, (launch_conv<3, 1, 1, 8, 4, 32>(st, h->agg[0], ld, m * Dl, hl, wl, ws.vol[0], nullptr, true)));
   for (int i = 1; i < kNAgg; ++i) {
     LoadVol3D lv{ws.vol[(i - 1) & 1], Dl, hl, wl};
-    float* o = ws.vol[i & 1];
-    if (amode == 1) HIP_TRY(h, (launch_conv<3, 1, 1, 16, 4, 32>(st, h->agg[i], lv, m * Dl, hl, wl, o, nullptr, true)));
-    else if (amode == 2) HIP_TRY(h, (launch_conv<3, 1, 1, 8, 8, 32>(st, h->agg[i], lv, m * Dl, hl, wl, o, nullptr, true)));
-    else if (amode == 3) HIP_TRY(h, (launch_conv<3, 1, 1, 16, 8, 32>(st, h->agg[i], lv, m * Dl, hl, wl, o, nullptr, true)));
-    else HIP_TRY(h, (launch_conv<3, 1, 1, 8, 4, 32>(st, h->agg[i], lv, m * Dl, hl, wl, o, nullptr, true)));
+    HIP_TRY(h, (launch_conv<3, 1, 1, 8, 4, 32>(st, h->agg[i], lv, m * Dl, hl, wl, ws.vol[i & 1], nullptr, true)));
   }
   const float* v = ws.vol[(kNAgg - 1) & 1];
   const int npix = m * hl * wl;
@@ -595,15 +577,9 @@ int refine(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, const int
       if (Hp * Wp <= 64 * 128)
         HIP_TRY(h, (launch_conv<3, 1, 1, 4, 4, 32, LoadRefineIn, 1>(st, h->rin, ld, c, Hp, Wp, reinterpret_cast<float*>(rx),
                                                                   nullptr, true, g.Hs, g.Ws)));
-      else {
-        static const int rmode = getenv("SN_RIN_MODE") ? atoi(getenv("SN_RIN_MODE")) : 0;
-        if (rmode == 1)
-          HIP_TRY(h, (launch_conv<3, 1, 1, 4, 4, 64, LoadRefineIn, 1>(st, h->rin, ld, c, Hp, Wp, reinterpret_cast<float*>(rx),
-                                                                    nullptr, true, g.Hs, g.Ws)));
-        else
-          HIP_TRY(h, (launch_conv<3, 1, 1, 4, 8, 64, LoadRefineIn, 1>(st, h->rin, ld, c, Hp, Wp, reinterpret_cast<float*>(rx),
-                                                                    nullptr, true, g.Hs, g.Ws)));
-      }
+      else
+        HIP_TRY(h, (launch_conv<3, 1, 1, 4, 8, 64, LoadRefineIn, 1>(st, h->rin, ld, c, Hp, Wp, reinterpret_cast<float*>(rx),
+                                                                  nullptr, true, g.Hs, g.Ws)));
       if (pe) HIP_TRY(h, hipEventRecord(h->ev[4], st));
       for (int i = 0; i < kNRefRes; ++i)
         HIP_TRY(h, ref_block_f16(st, h->rres16[i][0], h->rres16[i][1], g, h->num_cu, kRefDil[i], &rx, &rt, c));

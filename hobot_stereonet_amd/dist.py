@@ -46,6 +46,23 @@ def gather_to_root(local: torch.Tensor, counts: List[int], dst: int = 0) -> Opti
     return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
 
 
+class AsyncGather:
+    """gather_to_root for equal shards without blocking the compute stream: the collective is enqueued with
+    async_op=True (RCCL runs it on its own stream behind an event on the current stream), so the next batch's
+    kernels overlap the transfer over xGMI.  Call wait() before reusing the source tensor."""
+
+    def __init__(self, local: torch.Tensor, dst: int = 0):
+        world, rank = dist.get_world_size(), dist.get_rank()
+        self.bufs = [torch.empty_like(local) for _ in range(world)] if rank == dst else None
+        self.work = dist.gather(local.contiguous(), self.bufs, dst=dst, async_op=True)
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        return self.bufs
+
+
 def run_sharded(n: int, infer_shard: Callable[[int, int], torch.Tensor], dst: int = 0) -> Optional[torch.Tensor]:
     """infer_shard(begin, end) -> tensor [end-begin, H, W] for this rank's pairs; returns all n maps on dst."""
     world, rank = dist.get_world_size(), dist.get_rank()

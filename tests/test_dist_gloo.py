@@ -45,6 +45,16 @@ def _worker(rank, world, port, n, out_path):
         np.save(out_path, got.numpy())
     else:
         assert got is None
+    # the bench's non-blocking form (equal shards): two gathers in flight, waited out of order
+    a = torch.full((2, 3), rank * 10 + 1, dtype=torch.int32)
+    b = torch.full((2, 3), rank * 10 + 2, dtype=torch.int32)
+    ga, gb = sdist.AsyncGather(a, dst=0), sdist.AsyncGather(b, dst=0)
+    rb, ra = gb.wait(), ga.wait()
+    if rank == 0:
+        assert [int(t[0, 0]) for t in ra] == [r * 10 + 1 for r in range(world)]
+        assert [int(t[0, 0]) for t in rb] == [r * 10 + 2 for r in range(world)]
+    else:
+        assert ra is None and rb is None
     dist.barrier()
     dist.destroy_process_group()
 

@@ -120,3 +120,19 @@ def test_residual_block_f16(eng16, oracle, h, w, dil, fused):
     # t may round differently by one fp16 ulp at a few positions (fp32 summation order), then one output rounding
     assert np.abs(got - ref).max() <= 3e-3 * scale
     assert np.abs(got - ref).mean() < 3e-4 * scale
+
+
+def test_race_screen_full_size(model_factory):
+    """Screen for rare races in the hand-synchronised kernels (LDS-DMA ring, counted vmcnt, raw barriers, two
+    streams): the same 1280x720 batch must come out bit-identical on every one of 12 runs, and distinct inputs
+    interleaved between the runs must not disturb it."""
+    w, h, d = 1280, 720, 192
+    xs = np.stack([synth.model_input_i8(w, h, d, 40 + s) for s in range(6)])
+    other = np.stack([synth.model_input_i8(w, h, d, 60 + s) for s in range(6)])
+    with api.StereoNetHIP(model_factory(w, h, d), precision=api.PREC_F16, max_batch=6, refine_chunk=2, piece=2) as eng:
+        ref_disp, ref_raw = eng.infer(xs)
+        for it in range(12):
+            if it % 3 == 0:
+                eng.infer(other)
+            dsp, rw = eng.infer(xs)
+            assert (rw == ref_raw).all() and (dsp == ref_disp).all(), it
