@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=64, help="pairs per GPU per step")
     ap.add_argument("--refine-chunk", type=int, default=2)
-    ap.add_argument("--precision", choices=["fp32", "f16"], default="f16",
+    ap.add_argument("--precision", choices=["fp32", "f16", "f16x3"], default="f16",
                     help="arithmetic of the refinement-tower contractions (the low-res branch is always fp32)")
     ap.add_argument("--piece", type=int, default=8, help="pairs per low-res piece of the two-stream pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -98,7 +98,7 @@ def main():
     tmp = tempfile.mkdtemp(prefix=f"snbench{rank}_")
     model = os.path.join(tmp, "bench.snw")
     weights.save_snw(model, blob, W, H, D)
-    prec = api.PREC_F16 if args.precision == "f16" else api.PREC_FP32
+    prec = {"f16": api.PREC_F16, "f16x3": api.PREC_F16X3, "fp32": api.PREC_FP32}[args.precision]
     eng = api.StereoNetHIP(model, device=local_rank, max_batch=B, refine_chunk=args.refine_chunk, precision=prec,
                            piece=args.piece)
 
@@ -181,7 +181,7 @@ def main():
                      "traffic_source": traffic_src, "kernel": dk["name"], "avg_launch_ms": launch_ms,
                      "launches_per_refine_chunk": dk["launches"], "algorithmic_bytes_per_launch": dk["bytes_per_launch"],
                      "algorithmic_flops_per_launch": dk["flops_per_launch"], "tflops": tflops, "gbytes_per_s": gbs,
-                     "mfma_peak_tflops": MFMA_F16_PEAK_TFLOPS if args.precision == "f16" else MFMA_F32_PEAK_TFLOPS})
+                     "mfma_peak_tflops": MFMA_F32_PEAK_TFLOPS if args.precision == "fp32" else MFMA_F16_PEAK_TFLOPS})
 
     if rank == 0:
         pairs = B * world * args.steps
@@ -191,7 +191,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "ms_per_frame": elapsed / (B * args.steps) * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "fp32" else "f16 (refinement MFMA operands; fp32 accumulate; low-res branch f32)",
+            "dtype": {"fp32": "f32", "f16": "f16 (refinement MFMA operands; fp32 accumulate; low-res branch f32)",
+                      "f16x3": "f16x3 (hi/lo split fp16 operands, 3 MFMAs per product ~ 22-bit; fp32 accumulate)"}[args.precision],
             "data": "synthetic (seeded stereo pairs, seeded random SN-K4 weights)",
             "config": {"workload": f"BASELINE configs[1]/[2] shape: 1280x720 D=192, {B} synthetic pairs/GPU/step resident in HBM",
                        "pairs_per_gpu_per_step": B, "width": W, "height": H, "dmax": D, "precision": args.precision,

@@ -75,11 +75,12 @@ def load_library(path: Optional[str] = None):
     lib.sn_dbg_conv2d.argtypes = [vp, fp, ip, ip, ip, fp, fp, ip, ip, ip, ip, fp, fp]
     lib.sn_dbg_conv3d.argtypes = [vp, fp, ip, ip, ip, fp, fp, ip, fp]
     lib.sn_dbg_ref_conv_f16.argtypes = [vp, fp, ip, ip, fp, fp, ip, ip, fp, fp]
+    lib.sn_dbg_ref_conv_f16x3.argtypes = [vp, fp, ip, ip, fp, fp, ip, ip, fp, fp]
     lib.sn_dbg_ref_block_f16.argtypes = [vp, fp, ip, ip, fp, fp, fp, fp, ip, fp]
     lib.sn_dbg_read.argtypes = [vp, C.c_char_p, fp, C.c_size_t, C.POINTER(C.c_size_t)]
     for name in ("sn_create", "sn_destroy", "sn_get_io_info", "sn_infer_i8", "sn_infer_batch", "sn_preprocess_nv12",
                  "sn_infer_sbs_nv12", "sn_submit", "sn_wait", "sn_synchronize", "sn_set_profiling",
-                 "sn_get_stage_ms", "sn_get_dominant_kernel", "sn_dbg_conv2d", "sn_dbg_conv3d", "sn_dbg_ref_conv_f16", "sn_dbg_ref_block_f16", "sn_dbg_read"):
+                 "sn_get_stage_ms", "sn_get_dominant_kernel", "sn_dbg_conv2d", "sn_dbg_conv3d", "sn_dbg_ref_conv_f16", "sn_dbg_ref_conv_f16x3", "sn_dbg_ref_block_f16", "sn_dbg_read"):
         getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
@@ -245,6 +246,17 @@ class StereoNetHIP:
         res = np.ascontiguousarray(residual, np.float32) if residual is not None else None
         self._check(self._lib.sn_dbg_ref_conv_f16(self._h, x.ctypes.data, h, w, wt.ctypes.data, bias.ctypes.data, dil,
                                                   int(lrelu), _np_ptr(res), out.ctypes.data), "sn_dbg_ref_conv_f16")
+        return out
+
+    def dbg_ref_conv_f16x3(self, x, wt, bias, dil=1, lrelu=False, residual=None):
+        x = np.ascontiguousarray(x, np.float32)
+        wt = np.ascontiguousarray(wt, np.float32)
+        bias = np.ascontiguousarray(bias, np.float32)
+        _, h, w = x.shape
+        out = np.empty((32, h, w), np.float32)
+        res = np.ascontiguousarray(residual, np.float32) if residual is not None else None
+        self._check(self._lib.sn_dbg_ref_conv_f16x3(self._h, x.ctypes.data, h, w, wt.ctypes.data, bias.ctypes.data, dil,
+                                                    int(lrelu), _np_ptr(res), out.ctypes.data), "sn_dbg_ref_conv_f16x3")
         return out
 
     def dbg_ref_block_f16(self, x, w1, b1, w2, b2, dil=1, fused=0):

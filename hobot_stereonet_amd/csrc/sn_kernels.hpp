@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace sn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -18,6 +20,8 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
 constexpr int kC = 32;            // feature channels == MFMA N
 constexpr int kRefPad = 8;        // zero border (px) of the fp16 refinement tensors = max dilation
+constexpr float kSplitScale = 2048.0f;         // F16X3: value = hi + lo * 2^-11
+constexpr float kSplitInv = 1.0f / 2048.0f;
 constexpr float kSlope = 0.2f;    // LeakyReLU
 
 // Bijective XCD-aware remap: hardware places block b on XCD b % 8; give each XCD a contiguous
@@ -177,7 +181,8 @@ struct ConvArgs {
   int dil, pad;
   int lrelu;
   int tiles_x, tiles_y;
-  int f16_Hs, f16_Ws;  // OUTF == 1 only: padded plane dims of the fp16 NCHW8c output
+  int f16_Hs, f16_Ws;  // OUTF >= 1 only: padded plane dims of the fp16 NCHW8c output
+  size_t f16_lo_off;   // OUTF == 2 only: byte offset from the hi tensor to the lo tensor
 };
 
 template <int KS, int STRIDE, int DIL, int CH, int TR, int TC, class Loader, int OUTF = 0, bool PF = true, int MINW = 1>
@@ -311,7 +316,27 @@ __global__ __launch_bounds__(256, MINW) void k_conv_c32_mfma(ConvArgs a, Loader 
     const int seg = wave * SPW + s;
     const int srow = seg / CSEG, scol = (seg - srow * CSEG) * 32;
     const int y = ty * TR + srow, x = tx * TC + scol + j;
-    if (OUTF == 1) {
+    if (OUTF == 2) {
+      // split fp16 pair (SN_PREC_F16X3): hi = fp16(v), lo = fp16((v - hi) * 2^11), two NCHW8c tensors
+      if (y < a.Ho && x < a.Wo) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          half4 hh, hl;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = acc[s][4 * q + e] + a.bias[8 * q + 4 * kh + e];
+            if (a.lrelu) v = v > 0.f ? v : v * kSlope;
+            const _Float16 hi = (_Float16)v;
+            hh[e] = hi;
+            hl[e] = (_Float16)((v - (float)hi) * kSplitScale);
+          }
+          const size_t slot = (((size_t)img * 4 + q) * a.f16_Hs + (y + kRefPad)) * a.f16_Ws + (x + kRefPad);
+          char* p0 = reinterpret_cast<char*>(a.out) + slot * 16 + kh * 8;
+          *reinterpret_cast<half4*>(p0) = hh;
+          *reinterpret_cast<half4*>(p0 + a.f16_lo_off) = hl;
+        }
+      }
+    } else if (OUTF == 1) {
       // fp16 NCHW8c with zero border (RefGeom, below): channel block q = r>>2 holds couts 8q..8q+7,
       // this lane owns 4 of them (4*kh + (r&3)) -> one 8-byte store per block, 512 B per wave-store.
       if (y < a.Ho && x < a.Wo) {
@@ -1348,8 +1373,212 @@ __global__ __launch_bounds__(512, 2) void k_ref_block_f16_ws(const uint4* __rest
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// SN_PREC_F16X3: the v2 tower kernel on split operands.  Every activation / weight is a pair of fp16 numbers
+// (hi = fp16(v), lo = fp16((v - hi) * 2^11)), i.e. 22 significant bits, and a product is evaluated with three
+// fp16 MFMAs:  x*w ~= xhi*whi + (xhi*wlo + xlo*whi) * 2^-11   (the dropped xlo*wlo term is 2^-22 relative).
+// Two accumulators per segment (acc0 for the hi*hi products, acc1 for the cross terms) keep the scaled term
+// exact until the epilogue.  Result: fp32-class accuracy (EPE ~3e-7 px vs the oracle in emulation) at 3/16 of
+// the fp32-MFMA cost.  Tensors are two NCHW8c fp16 tensors (hi at `in`, lo at `in + lo_slots`), so the HBM
+// traffic equals an fp32 tensor.  One workgroup per CU (LDS holds hi and lo tiles), NBUF-deep DMA ring.
+// ------------------------------------------------------------------------------------------
+template <int DIL, int TW, int NBUF, bool RES>
+__global__ __launch_bounds__(256, 1) void k_ref_conv_f16x3(const uint4* __restrict__ in, uint4* out, const uint4* res,
+                                                           size_t lo_slots,                 // hi -> lo tensor offset
+                                                           const uint4* __restrict__ wfrag, // [hi 18][lo 18] x 64 slots
+                                                           const float* __restrict__ bias, RefGeom g, int nimg, int lrelu) {
+  using T = RefTile2<DIL, TW>;
+  constexpr int KW2 = 2 * T::KW;               // DMA instructions per wave per group (hi + lo)
+  constexpr int NST = 2 * T::NSTORE;           // stores per wave per tile (hi + lo)
+  constexpr int RING = 2 * T::BUF;             // slots per ring entry
+  static_assert(NBUF * RING * 16 <= 160 * 1024, "ring does not fit the LDS");
+  static_assert(NBUF == 2 || NBUF == 3, "ring depth");
+  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j_ = lane & 31, gh_ = lane >> 5;
+
+  half8 wh[18], wl[18];
+#pragma unroll
+  for (int i = 0; i < 18; ++i) {
+    const uint4 a = wfrag[i * 64 + lane], b = wfrag[(18 + i) * 64 + lane];
+    wh[i] = *reinterpret_cast<const half8*>(&a);
+    wl[i] = *reinterpret_cast<const half8*>(&b);
+  }
+  float bv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bv[r] = bias[(r & 3) + 8 * (r >> 2) + 4 * gh_];
+#pragma unroll
+  for (int i = 0; i < 18; ++i) {
+    asm volatile("" : "+v"(wh[i]));
+    asm volatile("" : "+v"(wl[i]));
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(bv[r]));
+
+  const int per_img = g.tiles_x * g.tiles_y;
+  const int total = per_img * nimg;
+  const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, nlb = gridDim.x >> 3;
+  const int t_begin = (int)((long)xcd * total / 8), t_end = (int)((long)(xcd + 1) * total / 8);
+  const int t0 = t_begin + lb;
+  if (t0 >= t_end) return;
+  const int ntiles = (t_end - t0 + nlb - 1) / nlb;
+  const int G = 2 * ntiles;
+
+  const int seg0 = wave * T::SPW;
+  auto tile_xy = [&](int ti, int& img, int& y0, int& x0) {
+    const int t = t0 + ti * nlb;
+    img = t / per_img;
+    const int rem = t - img * per_img;
+    const int ty = rem / g.tiles_x;
+    y0 = ty * T::TH;
+    x0 = (rem - ty * g.tiles_x) * T::TW;
+  };
+  auto issue = [&](int gp) {                   // hi and lo half-tiles of phase gp -> ring entry gp % NBUF
+    int img, y0, x0;
+    tile_xy(gp >> 1, img, y0, x0);
+    const int kk = gp & 1;
+    int lq = lane;
+    asm volatile("" : "+v"(lq));
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+      uint4* dst = lds + (gp % NBUF) * RING + part * T::BUF;
+      const uint4* src = in + (size_t)part * lo_slots;
+#pragma unroll
+      for (int k = 0; k < T::KW; ++k) {
+        int i = wave + 4 * k;
+        i = i < T::NINST ? i : T::NINST - 1;
+        int s = i * 64 + lq;
+        s = s < T::HALF ? s : T::HALF - 1;
+        const int pc = s / T::PLANE;
+        const int rem = s - pc * T::PLANE;
+        const int r = rem / T::COLS;
+        const int c = rem - r * T::COLS;
+        const size_t slot = (((size_t)img * 4 + (2 * kk + pc)) * g.Hs + (y0 + r - DIL + kRefPad)) * g.Ws +
+                            (x0 + c - DIL + kRefPad);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + slot),
+                                         (__attribute__((address_space(3))) void*)(dst + i * 64), 16, 0, 0);
+      }
+    }
+  };
+  // three MFMAs per (tap, segment): hi*hi -> acc0; hi*lo and lo*hi -> acc1
+  auto compute = [&](const uint4* ring, auto kkc, f32x16 (&a0)[T::SPW], f32x16 (&a1)[T::SPW], int j, int gh) {
+    constexpr int kk = decltype(kkc)::value;
+    const uint4* bh = ring + gh * T::PLANE + (seg0 / T::CSEG) * T::COLS + j;
+    const uint4* bl = bh + T::BUF;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+      for (int s = 0; s < T::SPW; ++s) {
+        const int off = ((s / T::CSEG) + ky * DIL) * T::COLS + (s % T::CSEG) * 32 + kx * DIL;
+        const half8 xh = *reinterpret_cast<const half8*>(bh + off);
+        const half8 xl = *reinterpret_cast<const half8*>(bl + off);
+        const half8 whi = wh[tap * 2 + kk];
+        const half8 wlo = wl[tap * 2 + kk];
+        a0[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, xh, a0[s], 0, 0, 0);
+        a1[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, xh, a1[s], 0, 0, 0);
+        a1[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, xl, a1[s], 0, 0, 0);
+      }
+    }
+  };
+
+  wait_vmcnt<0>();
+#pragma unroll
+  for (int gp = 0; gp < NBUF - 1; ++gp)
+    if (gp < G) issue(gp);
+
+  f32x16 acc0[T::SPW], acc1[T::SPW];
+  for (int ti = 0; ti < ntiles; ++ti) {
+    int img, y0, x0;
+    tile_xy(ti, img, y0, x0);
+    const int g0 = 2 * ti;
+    int j = j_, gh = gh_;
+    asm volatile("" : "+v"(j), "+v"(gh));
+    // ---- phase g0: ops younger than group g0 = groups g0+1 .. g0+NBUF-2 (+ the previous tile's stores) ----
+    if (NBUF == 3) {
+      if (ti == 0) wait_vmcnt<KW2>(); else wait_vmcnt<KW2 + NST>();     // group g0+1 always exists
+    } else {
+      if (ti == 0) wait_vmcnt<0>(); else wait_vmcnt<NST>();
+    }
+    __builtin_amdgcn_s_barrier();
+    if (g0 + NBUF - 1 < G) issue(g0 + NBUF - 1);
+#pragma unroll
+    for (int s = 0; s < T::SPW; ++s)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc0[s][r] = 0.f;
+        acc1[s][r] = 0.f;
+      }
+    compute(lds + (g0 % NBUF) * RING, std::integral_constant<int, 0>{}, acc0, acc1, j, gh);
+
+    // ---- phase g0+1 ----
+    if (NBUF == 3) {
+      if (g0 + 2 < G) wait_vmcnt<KW2>(); else wait_vmcnt<0>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    char* obase[T::SPW];
+    uint2 rres[RES ? 2 * T::NSTORE : 1];
+#pragma unroll
+    for (int s = 0; s < T::SPW; ++s) {
+      const int seg = seg0 + s;
+      const int y = y0 + seg / T::CSEG, x = x0 + (seg % T::CSEG) * 32 + j;
+      const size_t slot0 = ((size_t)img * 4 * g.Hs + (y + kRefPad)) * g.Ws + (x + kRefPad);
+      obase[s] = reinterpret_cast<char*>(out) + slot0 * 16 + gh * 8;
+      if (RES) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const char* rp = reinterpret_cast<const char*>(res) + (slot0 + (size_t)q * g.Hs * g.Ws) * 16 + gh * 8;
+          const char* rq = rp + lo_slots * 16;
+          asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rres[RES ? 2 * (s * 4 + q) : 0]) : "v"(rp) : "memory");
+          asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rres[RES ? 2 * (s * 4 + q) + 1 : 0]) : "v"(rq) : "memory");
+        }
+      }
+    }
+    const bool more = g0 + 1 + NBUF - 1 < G;
+    if (more) issue(g0 + 1 + NBUF - 1);
+    compute(lds + ((g0 + 1) % NBUF) * RING, std::integral_constant<int, 1>{}, acc0, acc1, j, gh);
+    if (RES) {
+      if (more) wait_vmcnt<KW2>(); else wait_vmcnt<0>();
+#pragma unroll
+      for (int i = 0; i < 2 * T::NSTORE; ++i) asm volatile("" : "+v"(rres[i]));
+    }
+    // ---- epilogue: v = acc0 + acc1 * 2^-11 + bias (+ residual), LeakyReLU, split, 2 * NSTORE stores ----
+#pragma unroll
+    for (int s = 0; s < T::SPW; ++s) {
+      const int seg = seg0 + s;
+      const int y = y0 + seg / T::CSEG, x = x0 + (seg % T::CSEG) * 32 + j;
+      const bool ok = y < g.H && x < g.W;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        half4 hh, hl;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = acc0[s][4 * q + e] + acc1[s][4 * q + e] * kSplitInv + bv[4 * q + e];
+          if (RES) {
+            const uint2 rh = rres[RES ? 2 * (s * 4 + q) : 0], rl = rres[RES ? 2 * (s * 4 + q) + 1 : 0];
+            const half4 vh = *reinterpret_cast<const half4*>(&rh);
+            const half4 vl = *reinterpret_cast<const half4*>(&rl);
+            v += (float)vh[e] + (float)vl[e] * kSplitInv;
+          }
+          if (lrelu) v = fmaxf(v, v * kSlope);
+          const _Float16 hi = (_Float16)v;
+          hh[e] = ok ? hi : (_Float16)0.f;
+          hl[e] = ok ? (_Float16)((v - (float)hi) * kSplitScale) : (_Float16)0.f;
+        }
+        char* p0 = obase[s] + (size_t)q * g.Hs * g.Ws * 16;
+        *reinterpret_cast<half4*>(p0) = hh;
+        *reinterpret_cast<half4*>(p0 + lo_slots * 16) = hl;
+      }
+    }
+  }
+}
+
 // K8 for the fp16 tower: 3x3 conv 32->1 on the NCHW8c tensor, disp = relu(up + D*r), outputs as k_head_final.
-__global__ __launch_bounds__(256) void k_head_final_f16(const uint4* __restrict__ xin, RefGeom g,
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void k_head_final_f16(const uint4* __restrict__ xin, size_t lo_slots, RefGeom g,
                                                         const float* __restrict__ w,      // [32][9]
                                                         float bias, const float* __restrict__ disp_low, int hl,
                                                         int wl, int H, int W, float dmax, float inv_q,
@@ -1368,8 +1597,16 @@ __global__ __launch_bounds__(256) void k_head_final_f16(const uint4* __restrict_
       for (int kx = 0; kx < 3; ++kx) {
         const uint4 raw = row[kx];
         const half8 hv = *reinterpret_cast<const half8*>(&raw);
+        if (SPLIT) {
+          const uint4 rawl = row[kx + lo_slots];
+          const half8 lv = *reinterpret_cast<const half8*>(&rawl);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc = fmaf(w[(8 * q + e) * 9 + ky * 3 + kx], (float)hv[e], acc);
+          for (int e = 0; e < 8; ++e)
+            acc = fmaf(w[(8 * q + e) * 9 + ky * 3 + kx], (float)hv[e] + (float)lv[e] * kSplitInv, acc);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc = fmaf(w[(8 * q + e) * 9 + ky * 3 + kx], (float)hv[e], acc);
+        }
       }
     }
   }

@@ -204,11 +204,13 @@ int upload_head(sn_handle* h, const HostLayer& l, HeadLayer* out) {   // [1][32]
 // ---- convolution launcher ------------------------------------------------------------------------
 template <int KS, int STRIDE, int DIL, int CH, int TR, int TC, class Loader, int OUTF = 0, bool PF = true, int MINW = 1>
 hipError_t launch_conv(hipStream_t st, const ConvLayer& L, const Loader& ld, int nimg, int Ho, int Wo,
-                       float* out, const float* res, bool lrelu, int f16_Hs = 0, int f16_Ws = 0) {
+                       float* out, const float* res, bool lrelu, int f16_Hs = 0, int f16_Ws = 0,
+                       size_t f16_lo_off = 0) {
   constexpr int dil = DIL;
   ConvArgs a;
   a.f16_Hs = f16_Hs;
   a.f16_Ws = f16_Ws;
+  a.f16_lo_off = f16_lo_off;
   a.wpk = L.wpk;
   a.bias = L.bias;
   a.out = out;
@@ -297,6 +299,60 @@ int upload_ref_f16(sn_handle* h, const HostLayer& l, RefLayerF16* out) {
   HIP_TRY(h, hipMemcpy(out->wfrag, pk.data(), pk.size() * sizeof(_Float16), hipMemcpyHostToDevice));
   HIP_TRY(h, hipMemcpy(out->bias, l.b, kC * sizeof(float), hipMemcpyHostToDevice));
   return SN_OK;
+}
+
+// F16X3: [co][ci][ky][kx] fp32 -> hi fragments (18 x 64 slots) followed by lo fragments, lo = fp16((w - hi) * 2^11)
+int upload_ref_f16x3(sn_handle* h, const HostLayer& l, RefLayerF16* out) {
+  std::vector<_Float16> pk((size_t)36 * 64 * 8);
+  for (int tap = 0; tap < 9; ++tap)
+    for (int kk = 0; kk < 2; ++kk)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int e = 0; e < 8; ++e) {
+          const int co = lane & 31, ci = 16 * kk + 8 * (lane >> 5) + e;
+          const float w = l.w[((size_t)co * kC + ci) * 9 + tap];
+          const _Float16 hi = (_Float16)w;
+          const size_t i = (((size_t)tap * 2 + kk) * 64 + lane) * 8 + e;
+          pk[i] = hi;
+          pk[(size_t)18 * 64 * 8 + i] = (_Float16)((w - (float)hi) * kSplitScale);
+        }
+  HIP_TRY(h, dalloc(&out->wfrag, (size_t)36 * 64));
+  HIP_TRY(h, dalloc(&out->bias, kC));
+  HIP_TRY(h, hipMemcpy(out->wfrag, pk.data(), pk.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+  HIP_TRY(h, hipMemcpy(out->bias, l.b, kC * sizeof(float), hipMemcpyHostToDevice));
+  return SN_OK;
+}
+
+template <int DIL, int TW, int NBUF>
+hipError_t launch_ref_f16x3(hipStream_t st, const RefLayerF16& L, const RefGeom& g, int num_cu, const uint4* in,
+                            uint4* out, const uint4* res, size_t lo_slots, int nimg, bool lrelu) {
+  using T = RefTile2<DIL, TW>;
+  constexpr int lds_bytes = NBUF * 2 * T::BUF * 16;
+  auto kern = res ? k_ref_conv_f16x3<DIL, TW, NBUF, true> : k_ref_conv_f16x3<DIL, TW, NBUF, false>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     lds_bytes);
+  if (e != hipSuccess) return e;
+  RefGeom gt = g;
+  gt.tiles_x = (g.W + TW - 1) / TW;
+  const int total = gt.tiles_x * gt.tiles_y * nimg;
+  const int band = (total + 7) / 8;
+  int cap = num_cu / 8;                      // one workgroup per CU
+  if (cap < 1) cap = 1;
+  const int rounds = (band + cap - 1) / cap;
+  const int nlb = (band + rounds - 1) / rounds;
+  hipLaunchKernelGGL(kern, dim3(nlb * 8), dim3(256), lds_bytes, st, in, out, res, lo_slots, L.wfrag, L.bias, gt, nimg,
+                     lrelu ? 1 : 0);
+  return hipGetLastError();
+}
+
+hipError_t ref_conv_f16x3(hipStream_t st, const RefLayerF16& L, const RefGeom& g, int num_cu, int dil, const uint4* in,
+                          uint4* out, const uint4* res, size_t lo_slots, int nimg, bool lrelu) {
+  switch (dil) {
+    case 1: return launch_ref_f16x3<1, 64, 3>(st, L, g, num_cu, in, out, res, lo_slots, nimg, lrelu);
+    case 2: return launch_ref_f16x3<2, 64, 3>(st, L, g, num_cu, in, out, res, lo_slots, nimg, lrelu);
+    case 4: return launch_ref_f16x3<4, 32, 3>(st, L, g, num_cu, in, out, res, lo_slots, nimg, lrelu);
+    case 8: return launch_ref_f16x3<8, 32, 2>(st, L, g, num_cu, in, out, res, lo_slots, nimg, lrelu);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 template <int DIL>
@@ -467,9 +523,9 @@ int alloc_ws(sn_handle* h, Workspace* ws, int nb, int rb) {
     for (int k = 0; k < 2; ++k) HIP_TRY(h, dalloc(&ws->ref[k], (size_t)rb * kC * HWp));
   } else {
     for (int k = 0; k < 2; ++k) {
-      const size_t slots = ref16_slots(h->rg, rb);
-      HIP_TRY(h, dalloc(&ws->ref16[k], slots + kRefSlack));
-      HIP_TRY(h, hipMemset(ws->ref16[k], 0, (slots + kRefSlack) * sizeof(uint4)));   // the zero border is never written again
+      const size_t slots = (ref16_slots(h->rg, rb) + kRefSlack) * (h->precision == SN_PREC_F16X3 ? 2 : 1);
+      HIP_TRY(h, dalloc(&ws->ref16[k], slots));
+      HIP_TRY(h, hipMemset(ws->ref16[k], 0, slots * sizeof(uint4)));   // the zero border is never written again
     }
   }
   HIP_TRY(h, dalloc(&ws->out_disp, (size_t)nb * HW));
@@ -574,18 +630,37 @@ int refine(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, const int
       uint4* rx = ws.ref16[0];
       uint4* rt = ws.ref16[1];
       const RefGeom& g = h->rg;
-      if (Hp * Wp <= 64 * 128)
+      const bool x3 = h->precision == SN_PREC_F16X3;
+      const size_t lo_slots = ref16_slots(g, ws.rb) + kRefSlack;       // hi tensor -> lo tensor (F16X3)
+      if (x3) {
+        if (Hp * Wp <= 64 * 128)
+          HIP_TRY(h, (launch_conv<3, 1, 1, 4, 4, 32, LoadRefineIn, 2>(st, h->rin, ld, c, Hp, Wp, reinterpret_cast<float*>(rx),
+                                                                    nullptr, true, g.Hs, g.Ws, lo_slots * 16)));
+        else
+          HIP_TRY(h, (launch_conv<3, 1, 1, 4, 8, 64, LoadRefineIn, 2>(st, h->rin, ld, c, Hp, Wp, reinterpret_cast<float*>(rx),
+                                                                    nullptr, true, g.Hs, g.Ws, lo_slots * 16)));
+      } else if (Hp * Wp <= 64 * 128)
         HIP_TRY(h, (launch_conv<3, 1, 1, 4, 4, 32, LoadRefineIn, 1>(st, h->rin, ld, c, Hp, Wp, reinterpret_cast<float*>(rx),
                                                                   nullptr, true, g.Hs, g.Ws)));
       else
         HIP_TRY(h, (launch_conv<3, 1, 1, 4, 8, 64, LoadRefineIn, 1>(st, h->rin, ld, c, Hp, Wp, reinterpret_cast<float*>(rx),
                                                                   nullptr, true, g.Hs, g.Ws)));
       if (pe) HIP_TRY(h, hipEventRecord(h->ev[4], st));
-      for (int i = 0; i < kNRefRes; ++i)
-        HIP_TRY(h, ref_block_f16(st, h->rres16[i][0], h->rres16[i][1], g, h->num_cu, kRefDil[i], &rx, &rt, c));
+      for (int i = 0; i < kNRefRes; ++i) {
+        if (x3) {
+          HIP_TRY(h, ref_conv_f16x3(st, h->rres16[i][0], g, h->num_cu, kRefDil[i], rx, rt, nullptr, lo_slots, c, true));
+          HIP_TRY(h, ref_conv_f16x3(st, h->rres16[i][1], g, h->num_cu, kRefDil[i], rt, rx, rx, lo_slots, c, true));
+        } else {
+          HIP_TRY(h, ref_block_f16(st, h->rres16[i][0], h->rres16[i][1], g, h->num_cu, kRefDil[i], &rx, &rt, c));
+        }
+      }
       if (pe) HIP_TRY(h, hipEventRecord(h->ev[5], st));
-      hipLaunchKernelGGL(k_head_final_f16, grid, dim3(256), 0, st, rx, g, h->rout.w, h->rout.bias, dl, hl, wl, h->H,
-                         h->W, (float)h->D, inv_q, od, orw);
+      if (x3)
+        hipLaunchKernelGGL(k_head_final_f16<true>, grid, dim3(256), 0, st, rx, lo_slots, g, h->rout.w, h->rout.bias, dl,
+                           hl, wl, h->H, h->W, (float)h->D, inv_q, od, orw);
+      else
+        hipLaunchKernelGGL(k_head_final_f16<false>, grid, dim3(256), 0, st, rx, (size_t)0, g, h->rout.w, h->rout.bias,
+                           dl, hl, wl, h->H, h->W, (float)h->D, inv_q, od, orw);
     }
     HIP_TRY(h, hipGetLastError());
   }
@@ -704,7 +779,7 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
   const int H = c.height > 0 ? c.height : (int)hd.height;
   const int D = c.dmax > 0 ? c.dmax : (int)hd.dmax;
   if (W <= 0 || H <= 0 || D < 16 || D % 16 || D > 256) return SN_ERR_ARG;   // NV12 entry points add w%4, h%2
-  if (c.precision != SN_PREC_FP32 && c.precision != SN_PREC_F16) return SN_ERR_ARG;   // F16X3: not built yet
+  if (c.precision != SN_PREC_FP32 && c.precision != SN_PREC_F16 && c.precision != SN_PREC_F16X3) return SN_ERR_ARG;
 
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SN_ERR_DEVICE;
@@ -772,6 +847,8 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
       const HostLayer hl_ = bw.next(kC, kC, 9);
       if (h->precision == SN_PREC_FP32) {
         if ((rc = upload_conv2d(h, hl_, 8, &h->rres[i][j]))) return fail(rc);
+      } else if (h->precision == SN_PREC_F16X3) {
+        if ((rc = upload_ref_f16x3(h, hl_, &h->rres16[i][j]))) return fail(rc);
       } else {
         if ((rc = upload_ref_f16(h, hl_, &h->rres16[i][j]))) return fail(rc);
       }
@@ -1083,10 +1160,12 @@ int sn_get_stage_ms(sn_handle* h, float* ms, int count) {
 
 int sn_get_dominant_kernel(sn_handle* h, char* name, size_t cap, int* launches, double* flops, double* bytes) {
   if (!h) return SN_ERR_ARG;
-  const bool f16 = h->precision != SN_PREC_FP32;
+  const bool f16 = h->precision == SN_PREC_F16;
   if (name && cap)
-    snprintf(name, cap, "%s", f16 ? "k_ref_conv_f16<DIL> (refinement 3x3 C->C, fp16 MFMA 32x32x16)"
-                                  : "k_conv_c32_mfma<3,1,*> (refinement 3x3 C->C, fp32 MFMA 32x32x2)");
+    snprintf(name, cap, "%s",
+             h->precision == SN_PREC_F16     ? "k_ref_conv_f16<DIL> (refinement 3x3 C->C, fp16 MFMA 32x32x16)"
+             : h->precision == SN_PREC_F16X3 ? "k_ref_conv_f16x3<DIL> (refinement 3x3 C->C, 3x fp16 MFMA on hi/lo split operands)"
+                                             : "k_conv_c32_mfma<3,1,*> (refinement 3x3 C->C, fp32 MFMA 32x32x2)");
   const double px = (double)h->Hp * h->Wp * h->ws.rb;
   if (launches) *launches = 2 * kNRefRes;   // per refinement chunk
   if (flops) *flops = 2.0 * px * kC * kC * 9;
@@ -1228,6 +1307,69 @@ int sn_dbg_ref_conv_f16(sn_handle* h, const float* in, int h_px, int w, const fl
             return SN_ERR_DEVICE;
           }
       }
+  hipFree(din);
+  hipFree(dout);
+  hipFree(L.wfrag);
+  hipFree(L.bias);
+  return SN_OK;
+}
+
+int sn_dbg_ref_conv_f16x3(sn_handle* h, const float* in, int h_px, int w, const float* wt, const float* bias, int dil,
+                          int lrelu, const float* residual, float* out) {
+  if (!h || !in || !wt || !bias || !out || h_px <= 0 || w <= 0) return SN_ERR_ARG;
+  if (dil != 1 && dil != 2 && dil != 4 && dil != 8) return SN_ERR_ARG;
+  int rc = check_device(h);
+  if (rc) return rc;
+  const RefGeom g = make_ref_geom(h_px, w);
+  const size_t lo_slots = ref16_slots(g, 1) + kRefSlack, slots = 2 * lo_slots;
+  auto idx = [&](int c, int y, int x) { return ((((size_t)(c >> 3)) * g.Hs + y + kRefPad) * g.Ws + x + kRefPad) * 8 + (c & 7); };
+  auto split_to = [&](const float* src, std::vector<_Float16>& dst) {
+    dst.assign(slots * 8, (_Float16)0.f);
+    for (int c = 0; c < kC; ++c)
+      for (int y = 0; y < h_px; ++y)
+        for (int x = 0; x < w; ++x) {
+          const float v = src[((size_t)c * h_px + y) * w + x];
+          const _Float16 hi = (_Float16)v;
+          dst[idx(c, y, x)] = hi;
+          dst[lo_slots * 8 + idx(c, y, x)] = (_Float16)((v - (float)hi) * kSplitScale);
+        }
+  };
+  std::vector<_Float16> hin, hres;
+  split_to(in, hin);
+  RefLayerF16 L;
+  if ((rc = upload_ref_f16x3(h, HostLayer{wt, bias, kC, kC, 9}, &L))) return rc;
+  uint4 *din = nullptr, *dout = nullptr;
+  HIP_TRY(h, dalloc(&din, slots));
+  HIP_TRY(h, dalloc(&dout, slots));
+  HIP_TRY(h, hipMemcpy(din, hin.data(), slots * 16, hipMemcpyHostToDevice));
+  const uint4* dres = nullptr;
+  if (residual) {
+    split_to(residual, hres);
+    HIP_TRY(h, hipMemcpy(dout, hres.data(), slots * 16, hipMemcpyHostToDevice));
+    dres = dout;
+  } else {
+    HIP_TRY(h, hipMemset(dout, 0, slots * 16));
+  }
+  HIP_TRY(h, ref_conv_f16x3(h->stream, L, g, h->num_cu, dil, din, dout, dres, lo_slots, 1, lrelu != 0));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  std::vector<_Float16> hout(slots * 8);
+  HIP_TRY(h, hipMemcpy(hout.data(), dout, slots * 16, hipMemcpyDeviceToHost));
+  for (int c = 0; c < kC; ++c)
+    for (int y = 0; y < h_px; ++y)
+      for (int x = 0; x < w; ++x)
+        out[((size_t)c * h_px + y) * w + x] =
+            (float)hout[idx(c, y, x)] + (float)hout[lo_slots * 8 + idx(c, y, x)] * kSplitInv;
+  for (int part = 0; part < 2; ++part)       // both zero borders must have survived
+    for (int c = 0; c < 4; ++c)
+      for (int y = 0; y < g.Hs; ++y)
+        for (int x = 0; x < g.Ws; ++x) {
+          if (y >= kRefPad && y < kRefPad + h_px && x >= kRefPad && x < kRefPad + w) continue;
+          for (int e = 0; e < 8; ++e)
+            if ((float)hout[part * lo_slots * 8 + (((size_t)c * g.Hs + y) * g.Ws + x) * 8 + e] != 0.f) {
+              set_err(h, "f16x3 conv wrote into the zero border");
+              return SN_ERR_DEVICE;
+            }
+        }
   hipFree(din);
   hipFree(dout);
   hipFree(L.wfrag);

@@ -61,7 +61,8 @@ enum { SN_MEM_HOST = 0, SN_MEM_DEVICE = 1 };
 enum {
   SN_PREC_FP32 = 0,      /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere                  */
   SN_PREC_F16X3 = 1,     /* refinement tower on fp16 MFMA with hi/lo operand split (3 MFMAs per   */
-                         /* product, ~2^-22 relative): fp32-class accuracy at the fp16 MFMA rate  */
+                         /* product, ~2^-22 relative): fp32-class accuracy at 3/16 of the fp32    */
+                         /* MFMA cost; activations stored as two fp16 tensors                     */
   SN_PREC_F16 = 2        /* refinement tower on plain fp16 MFMA operands                          */
 };
 
@@ -148,6 +149,9 @@ int sn_dbg_conv3d(sn_handle *h, const float *in, int d, int h_px, int w, const f
  * fp32 [32][h][w] on the host; the hook converts to the kernel's fp16 NCHW8c layout and back. */
 int sn_dbg_ref_conv_f16(sn_handle *h, const float *in, int h_px, int w, const float *wt, const float *bias,
                         int dil, int lrelu, const float *residual, float *out);
+/* the same layer through the split-operand (SN_PREC_F16X3) kernel */
+int sn_dbg_ref_conv_f16x3(sn_handle *h, const float *in, int h_px, int w, const float *wt, const float *bias,
+                          int dil, int lrelu, const float *residual, float *out);
 /* one residual block y = lrelu(x + conv2(lrelu(conv1(x)+b1)) + b2) of the fp16 tower, exactly as the pipeline runs it
  * (one fused kernel for dilation 1, two convolution launches otherwise); fp32 [32][h][w] host tensors. */
 int sn_dbg_ref_block_f16(sn_handle *h, const float *in, int h_px, int w, const float *w1, const float *b1,

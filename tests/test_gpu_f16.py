@@ -136,3 +136,47 @@ def test_race_screen_full_size(model_factory):
                 eng.infer(other)
             dsp, rw = eng.infer(xs)
             assert (rw == ref_raw).all() and (dsp == ref_disp).all(), it
+
+
+# ---- SN_PREC_F16X3: hi/lo split operands, three fp16 MFMAs per product (fp32-class accuracy) -----------------
+@pytest.mark.parametrize("h,w,dil", [(16, 64, 1), (45, 80, 2), (72, 200, 4), (130, 300, 8), (8, 64, 8), (100, 129, 1),
+                                     (24, 70, 4), (720, 1280, 1)])
+def test_ref_conv_f16x3_layer(eng16, oracle, h, w, dil):
+    rng = np.random.default_rng(h * 13 + w + dil)
+    x = rng.standard_normal((32, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((32, 32, 3, 3)) / 17.0).astype(np.float32)
+    b = rng.standard_normal(32).astype(np.float32)
+    ref = oracle.conv2d(x, wt, b, 1, dil, dil)
+    got = eng16.dbg_ref_conv_f16x3(x, wt, b, dil)
+    scale = np.abs(ref).max()
+    # operands carry 22 bits, the result is stored as a 22-bit pair: a few 1e-6 relative to the largest value
+    assert np.abs(got - ref).max() <= 6e-6 * scale
+    res = rng.standard_normal((32, h, w)).astype(np.float32)
+    v = ref + res
+    ref2 = np.where(v > 0, v, v * np.float32(0.2))
+    got2 = eng16.dbg_ref_conv_f16x3(x, wt, b, dil, lrelu=True, residual=res)
+    assert np.abs(got2 - ref2).max() <= 6e-6 * np.abs(ref2).max()
+
+
+@pytest.mark.parametrize("name,w,h,d,seed", CASES)
+def test_forward_small_f16x3(model_factory, oracle, weights_blob, name, w, h, d, seed):
+    x = synth.model_input_i8(w, h, d, seed)
+    with api.StereoNetHIP(model_factory(w, h, d), precision=api.PREC_F16X3) as eng:
+        disp, raw = eng.infer(x)
+    odisp, _, _ = oracle.forward(weights_blob, x, d)
+    epe = float(np.abs(disp - odisp).mean())
+    assert epe < 1e-4, epe          # same class as the exact-fp32 path
+
+
+def test_full_size_epe_f16x3(model_factory, oracle, weights_blob):
+    w, h, d = 1280, 720, 192
+    xs = np.stack([synth.model_input_i8(w, h, d, s) for s in (0, 1, 2)])
+    with api.StereoNetHIP(model_factory(w, h, d), precision=api.PREC_F16X3, max_batch=3, refine_chunk=2, piece=2) as eng:
+        disp, raw = eng.infer(xs)
+        disp2, _ = eng.infer(xs)
+        d0, _ = eng.infer(xs[0])
+    assert (disp == disp2).all() and (d0 == disp[0]).all()
+    odisp, _, _ = oracle.forward(weights_blob, xs[0], d)
+    epe = float(np.abs(disp[0] - odisp).mean())
+    print(f"f16x3 tower EPE vs oracle: {epe:.3e} px (max {np.abs(disp[0] - odisp).max():.3e})")
+    assert epe < 2e-4
