@@ -369,6 +369,155 @@ __global__ __launch_bounds__(256, MINW) void k_conv_c32_mfma(ConvArgs a, Loader 
 }
 
 // ------------------------------------------------------------------------------------------
+// Split-operand variant of the 3x3 stride-1 implicit GEMM for the LOW-RESOLUTION layers (feature res-blocks,
+// cost-volume / 3-D aggregation convs) in the fp16 modes: the fp32 activations are split on the fly into
+// (hi, lo) fp16 pairs while being staged into LDS, weights are pre-split on the host, and each product is
+// three v_mfma_f32_32x32x16_f16 (see k_ref_conv_f16x3): 22-bit operands, fp32 accumulation, at 3/16 of the
+// cost of the exact-fp32 MFMA the fp32 mode uses.  Inputs/outputs stay fp32 NCHW in HBM.
+//   LDS image: [hi|lo][channel block of 8][row][col] 16-byte slots -> the B fragment of lane (pixel j, half g)
+//   is one conflict-free ds_read_b128; A fragments [tap][hi|lo][lane] are a straight copy of the host packing.
+//   K chunk = 16 (virtual) input channels = one MFMA K step; register staging as in k_conv_c32_mfma.
+// ------------------------------------------------------------------------------------------
+template <int DIL, int TR, int TC, class Loader>
+__global__ __launch_bounds__(256) void k_conv3x3_c32_x3(ConvArgs a, Loader ld) {
+  extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
+  constexpr int CH = 16, TAPS = 9;
+  constexpr int CSEG = TC / 32, NSEG = TR * CSEG;
+  static_assert(NSEG % 4 == 0, "tile must split evenly over 4 waves");
+  constexpr int SPW = NSEG / 4;
+  constexpr int ROWS_IN = TR + 2 * DIL, COLS_IN = TC + 2 * DIL;
+  constexpr int PLANE = ROWS_IN * COLS_IN;             // slots per channel block
+  constexpr int NELEM = CH * PLANE;
+  constexpr int EPT = (NELEM + 255) / 256;
+  constexpr int NW4 = TAPS * 2 * 64;                   // weight slots per chunk
+  constexpr int WPT = (NW4 + 255) / 256;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwg = a.tiles_x * a.tiles_y * a.nimg;
+  const int b = xcd_remap(blockIdx.x, nwg);
+  const int tx = b % a.tiles_x;
+  const int t2 = b / a.tiles_x;
+  const int ty = t2 % a.tiles_y;
+  const int img = t2 / a.tiles_y;
+
+  uint4* s_w = smem4;                        // [TAPS][hi|lo][64]
+  uint4* s_xh = smem4 + NW4;                 // [2 blocks][PLANE]
+  uint4* s_xl = s_xh + 2 * PLANE;
+  const int iy0 = ty * TR - a.pad, ix0 = tx * TC - a.pad;
+
+  f32x16 acc0[SPW], acc1[SPW];
+#pragma unroll
+  for (int s = 0; s < SPW; ++s)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc0[s][r] = 0.f;
+      acc1[s][r] = 0.f;
+    }
+  const int gh = lane >> 5, j = lane & 31;
+
+  float pre[EPT];
+  uint4 wpre[WPT];
+  auto fetch = [&](int c0) {
+    int tq = tid;
+    asm volatile("" : "+v"(tq));
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int idx = e * 256 + tq;
+      const int c = idx / PLANE;
+      const int rem = idx - c * PLANE;
+      const int r = rem / COLS_IN;
+      const int cc = rem - r * COLS_IN;
+      pre[e] = idx < NELEM ? ld(img, c0 + c, iy0 + r, ix0 + cc) : 0.f;
+    }
+    const uint4* wsrc = reinterpret_cast<const uint4*>(a.wpk) + (size_t)(c0 / CH) * NW4;
+#pragma unroll
+    for (int e = 0; e < WPT; ++e) {
+      const int idx = e * 256 + tq;
+      wpre[e] = idx < NW4 ? wsrc[idx] : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto commit = [&]() {
+    int tq = tid;
+    asm volatile("" : "+v"(tq));
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int idx = e * 256 + tq;
+      const int c = idx / PLANE;
+      const int rem = idx - c * PLANE;          // = r * COLS_IN + cc
+      if (idx < NELEM) {
+        const float v = pre[e];
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)((v - (float)hi) * kSplitScale);
+        const int off = ((c >> 3) * PLANE + rem) * 8 + (c & 7);      // in halves
+        reinterpret_cast<_Float16*>(s_xh)[off] = hi;
+        reinterpret_cast<_Float16*>(s_xl)[off] = lo;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < WPT; ++e) {
+      const int idx = e * 256 + tq;
+      if (idx < NW4) s_w[idx] = wpre[e];
+    }
+  };
+
+  fetch(0);
+  commit();
+  __syncthreads();
+
+  for (int c0 = 0; c0 < a.cin_pad; c0 += CH) {
+    const bool more = c0 + CH < a.cin_pad;
+    if (more) fetch(c0 + CH);
+    const uint4* bh = s_xh + gh * PLANE + j;
+    const uint4* bl = s_xl + gh * PLANE + j;
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const uint4 wa = s_w[(tap * 2 + 0) * 64 + lane], wb = s_w[(tap * 2 + 1) * 64 + lane];
+      const half8 whi = *reinterpret_cast<const half8*>(&wa);
+      const half8 wlo = *reinterpret_cast<const half8*>(&wb);
+#pragma unroll
+      for (int s = 0; s < SPW; ++s) {
+        const int seg = wave * SPW + s;
+        const int srow = seg / CSEG, scol = (seg - srow * CSEG) * 32;
+        const int off = (srow + ky * DIL) * COLS_IN + scol + kx * DIL;
+        const uint4 xa = bh[off], xb = bl[off];
+        const half8 xh = *reinterpret_cast<const half8*>(&xa);
+        const half8 xl = *reinterpret_cast<const half8*>(&xb);
+        acc0[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, xh, acc0[s], 0, 0, 0);
+        acc1[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, xh, acc1[s], 0, 0, 0);
+        acc1[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, xl, acc1[s], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    if (more) {
+      commit();
+      __syncthreads();
+    }
+  }
+
+  const size_t plane_o = (size_t)a.Ho * a.Wo;
+#pragma unroll
+  for (int s = 0; s < SPW; ++s) {
+    const int seg = wave * SPW + s;
+    const int srow = seg / CSEG, scol = (seg - srow * CSEG) * 32;
+    const int y = ty * TR + srow, x = tx * TC + scol + j;
+    if (y < a.Ho && x < a.Wo) {
+      const size_t base = (size_t)img * kC * plane_o + (size_t)y * a.Wo + x;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = (r & 3) + 8 * (r >> 2) + 4 * gh;
+        float v = acc0[s][r] + acc1[s][r] * kSplitInv + a.bias[co];
+        const size_t idx = base + (size_t)co * plane_o;
+        if (a.res) v += a.res[idx];
+        if (a.lrelu) v = v > 0.f ? v : v * kSlope;
+        a.out[idx] = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // K6: final 3x3x3 conv 32->1 fused with soft-argmin.
 //   cost[d] = b + sum_{ci,dz,ky,kx} w[ci][dz][ky][kx] * vol[n][d+dz-1][ci][y+ky-1][x+kx-1]
 //   disp    = sum_d d * softmax_d(-cost)

@@ -38,6 +38,7 @@ constexpr int kMaxPieceEvents = 64;
   } while (0)
 
 struct ConvLayer {
+  uint4* wx3 = nullptr;    // device, split fp16 A-fragments [cin_pad/16][9][hi|lo][64 lanes] (fp16 modes, 3x3 layers)
   float* wpk = nullptr;    // device, packed [cin_pad][taps][32]
   float* bias = nullptr;   // device [32]
   int cin = 0, cin_pad = 0, taps = 0;
@@ -194,6 +195,52 @@ int upload_conv3d(sn_handle* h, const HostLayer& l, ConvLayer* out) {
   return SN_OK;
 }
 
+// split fp16 A-fragments for k_conv3x3_c32_x3: wv(co, c', tap) is the weight of virtual input channel c'
+template <class WV>
+int upload_x3(sn_handle* h, int cin_virtual, WV wv, ConvLayer* out) {
+  const int nchunk = cin_virtual / 16;
+  std::vector<_Float16> pk((size_t)nchunk * 9 * 2 * 64 * 8);
+  for (int ch = 0; ch < nchunk; ++ch)
+    for (int tap = 0; tap < 9; ++tap)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int e = 0; e < 8; ++e) {
+          const int co = lane & 31, c = ch * 16 + 8 * (lane >> 5) + e;
+          const float w = wv(co, c, tap);
+          const _Float16 hi = (_Float16)w;
+          const size_t base = (((size_t)ch * 9 + tap) * 2) * 64 * 8 + (size_t)lane * 8 + e;
+          pk[base] = hi;
+          pk[base + 64 * 8] = (_Float16)((w - (float)hi) * kSplitScale);
+        }
+  HIP_TRY(h, dalloc(&out->wx3, pk.size() / 8));
+  HIP_TRY(h, hipMemcpy(out->wx3, pk.data(), pk.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+  return SN_OK;
+}
+
+template <int DIL, int TR, int TC, class Loader>
+hipError_t launch_conv_x3(hipStream_t st, const ConvLayer& L, const Loader& ld, int nimg, int Ho, int Wo, float* out,
+                          const float* res, bool lrelu) {
+  ConvArgs a{};
+  a.wpk = reinterpret_cast<const float*>(L.wx3);
+  a.bias = L.bias;
+  a.out = out;
+  a.res = res;
+  a.nimg = nimg;
+  a.cin_pad = L.cin_pad;
+  a.Ho = Ho;
+  a.Wo = Wo;
+  a.dil = DIL;
+  a.pad = DIL;
+  a.lrelu = lrelu ? 1 : 0;
+  a.tiles_x = (Wo + TC - 1) / TC;
+  a.tiles_y = (Ho + TR - 1) / TR;
+  constexpr int plane = (TR + 2 * DIL) * (TC + 2 * DIL);
+  constexpr size_t lds = ((size_t)9 * 2 * 64 + 4 * plane) * 16;
+  static_assert(lds <= 64 * 1024, "x3 conv tile too large for the default LDS limit");
+  hipLaunchKernelGGL((k_conv3x3_c32_x3<DIL, TR, TC, Loader>), dim3(a.tiles_x * a.tiles_y * nimg), dim3(256), lds, st, a,
+                     ld);
+  return hipGetLastError();
+}
+
 int upload_head(sn_handle* h, const HostLayer& l, HeadLayer* out) {   // [1][32][taps] as-is
   HIP_TRY(h, dalloc(&out->w, (size_t)kC * l.taps));
   HIP_TRY(h, hipMemcpy(out->w, l.w, (size_t)kC * l.taps * sizeof(float), hipMemcpyHostToDevice));
@@ -245,6 +292,7 @@ hipError_t conv3x3_d(hipStream_t st, const ConvLayer& L, const float* in, int ni
                      const float* res, bool lrelu) {
   LoadF32 ld{in, kC, H, W};
   // (chunk sizes 8/16 and tile heights 4/8 measured equal within noise on the 45x80 low-resolution maps)
+  if (DIL == 1 && L.wx3) return launch_conv_x3<1, 8, 32>(st, L, ld, nimg, H, W, out, res, lrelu);   // fp16 modes
   if (H * W <= 64 * 128) return launch_conv<3, 1, DIL, 8, 4, 32>(st, L, ld, nimg, H, W, out, res, lrelu);
   if (DIL >= 4) return launch_conv<3, 1, DIL, 4, 16, 64>(st, L, ld, nimg, H, W, out, res, lrelu);
   return launch_conv<3, 1, DIL, 8, 8, 64>(st, L, ld, nimg, H, W, out, res, lrelu);
@@ -580,10 +628,16 @@ int lowres(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, const int
 
   // --- cost volume (fused into the first 3-D conv's loader) + 3-D aggregation + soft-argmin ---
   LoadCostVol ld{ws.feat, Dl, hl, wl};
-  HIP_TRY(h, (launch_conv<3, 1, 1, 8, 4, 32>(st, h->agg[0], ld, m * Dl, hl, wl, ws.vol[0], nullptr, true)));
+  if (h->agg[0].wx3)
+    HIP_TRY(h, (launch_conv_x3<1, 8, 32>(st, h->agg[0], ld, m * Dl, hl, wl, ws.vol[0], nullptr, true)));
+  else
+    HIP_TRY(h, (launch_conv<3, 1, 1, 8, 4, 32>(st, h->agg[0], ld, m * Dl, hl, wl, ws.vol[0], nullptr, true)));
   for (int i = 1; i < kNAgg; ++i) {
     LoadVol3D lv{ws.vol[(i - 1) & 1], Dl, hl, wl};
-    HIP_TRY(h, (launch_conv<3, 1, 1, 8, 4, 32>(st, h->agg[i], lv, m * Dl, hl, wl, ws.vol[i & 1], nullptr, true)));
+    if (h->agg[i].wx3)
+      HIP_TRY(h, (launch_conv_x3<1, 8, 32>(st, h->agg[i], lv, m * Dl, hl, wl, ws.vol[i & 1], nullptr, true)));
+    else
+      HIP_TRY(h, (launch_conv<3, 1, 1, 8, 4, 32>(st, h->agg[i], lv, m * Dl, hl, wl, ws.vol[i & 1], nullptr, true)));
   }
   const float* v = ws.vol[(kNAgg - 1) & 1];
   const int npix = m * hl * wl;
@@ -834,12 +888,27 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
   BlobWalker bw{blob.data()};
   for (int i = 0; i < kNDown; ++i)
     if ((rc = upload_conv2d(h, bw.next(kC, i == 0 ? 3 : kC, 25), 4, &h->down[i]))) return fail(rc);
+  // fp16 modes: the low-resolution 3x3 / 3x3x3 layers also get split fp16 A-fragments (22-bit operands on the
+  // fp16 MFMA, k_conv3x3_c32_x3); SN_PREC_FP32 keeps every contraction on the exact-fp32 MFMA
+  const bool low_x3 = h->precision != SN_PREC_FP32 && getenv("SN_LOW_FP32") == nullptr;
+  auto up2d = [&](ConvLayer* L) -> int {
+    const HostLayer hl_ = bw.next(kC, kC, 9);
+    int r = upload_conv2d(h, hl_, 8, L);
+    if (r || !low_x3) return r;
+    return upload_x3(h, kC, [&](int co, int c, int tap) { return hl_.w[((size_t)co * kC + c) * 9 + tap]; }, L);
+  };
   for (int i = 0; i < kNFeatRes; ++i)
     for (int j = 0; j < 2; ++j)
-      if ((rc = upload_conv2d(h, bw.next(kC, kC, 9), 8, &h->fres[i][j]))) return fail(rc);
-  if ((rc = upload_conv2d(h, bw.next(kC, kC, 9), 8, &h->fout))) return fail(rc);
-  for (int i = 0; i < kNAgg; ++i)
-    if ((rc = upload_conv3d(h, bw.next(kC, kC, 27), &h->agg[i]))) return fail(rc);
+      if ((rc = up2d(&h->fres[i][j]))) return fail(rc);
+  if ((rc = up2d(&h->fout))) return fail(rc);
+  for (int i = 0; i < kNAgg; ++i) {
+    const HostLayer hl_ = bw.next(kC, kC, 27);
+    if ((rc = upload_conv3d(h, hl_, &h->agg[i]))) return fail(rc);
+    if (low_x3 && (rc = upload_x3(h, 96, [&](int co, int c, int tap) {      // c = kz*32 + ci
+          return hl_.w[(((size_t)co * kC + (c & 31)) * 3 + (c >> 5)) * 9 + tap];
+        }, &h->agg[i])))
+      return fail(rc);
+  }
   if ((rc = upload_head(h, bw.next(1, kC, 27), &h->aout))) return fail(rc);
   if ((rc = upload_conv2d(h, bw.next(kC, 4, 9), 4, &h->rin))) return fail(rc);
   for (int i = 0; i < kNRefRes; ++i)
@@ -866,6 +935,7 @@ int sn_destroy(sn_handle* h) {
   hipSetDevice(h->device);
   hipDeviceSynchronize();
   auto free_conv = [](ConvLayer& l) {
+    hipFree(l.wx3);
     hipFree(l.wpk);
     hipFree(l.bias);
   };
@@ -1185,9 +1255,14 @@ int sn_dbg_conv2d(sn_handle* h, const float* in, int cin, int h_px, int w, const
   const int taps = k * k;
   const int Ho = stride == 1 ? h_px : h_px / 2, Wo = stride == 1 ? w : w / 2;
   if (stride == 2 && ((h_px & 1) || (w & 1))) return SN_ERR_ARG;
+  const bool x3 = (lrelu & 2) != 0;
+  lrelu &= 1;
+  if (x3 && !(k == 3 && stride == 1 && cin == kC && dil == 1)) return SN_ERR_ARG;
   ConvLayer L;
   HostLayer hl{wt, bias, kC, cin, taps};
   if ((rc = upload_conv2d(h, hl, (k == 5 || cin <= 4) ? 4 : 8, &L))) return rc;
+  if (x3 && (rc = upload_x3(h, kC, [&](int co, int c, int tap) { return wt[((size_t)co * kC + c) * 9 + tap]; }, &L)))
+    return rc;
   float *din = nullptr, *dout = nullptr;
   const size_t nin = (size_t)cin * h_px * w, nout = (size_t)kC * Ho * Wo;
   HIP_TRY(h, dalloc(&din, nin));
@@ -1216,6 +1291,7 @@ int sn_dbg_conv2d(sn_handle* h, const float* in, int cin, int h_px, int w, const
   HIP_TRY(h, hipMemcpy(out, dout, nout * 4, hipMemcpyDeviceToHost));
   hipFree(din);
   hipFree(dout);
+  hipFree(L.wx3);
   hipFree(L.wpk);
   hipFree(L.bias);
   return SN_OK;
@@ -1226,9 +1302,15 @@ int sn_dbg_conv3d(sn_handle* h, const float* in, int d, int h_px, int w, const f
   if (!h || !in || !wt || !bias || !out || d <= 0) return SN_ERR_ARG;
   int rc = check_device(h);
   if (rc) return rc;
+  const bool x3 = (lrelu & 2) != 0;
+  lrelu &= 1;
   ConvLayer L;
   HostLayer hl{wt, bias, kC, kC, 27};
   if ((rc = upload_conv3d(h, hl, &L))) return rc;
+  if (x3 && (rc = upload_x3(h, 96, [&](int co, int c, int tap) {
+        return wt[(((size_t)co * kC + (c & 31)) * 3 + (c >> 5)) * 9 + tap];
+      }, &L)))
+    return rc;
   const size_t plane = (size_t)h_px * w, n = (size_t)kC * d * plane;
   // caller layout [ci][d][h][w] (PyTorch) <-> device layout [d][ci][h][w]
   std::vector<float> tmp(n);
@@ -1240,7 +1322,8 @@ int sn_dbg_conv3d(sn_handle* h, const float* in, int d, int h_px, int w, const f
   HIP_TRY(h, dalloc(&dout, n));
   HIP_TRY(h, hipMemcpy(din, tmp.data(), n * 4, hipMemcpyHostToDevice));
   LoadVol3D lv{din, d, h_px, w};
-  HIP_TRY(h, (launch_conv<3, 1, 1, 8, 4, 32>(h->stream, L, lv, d, h_px, w, dout, nullptr, lrelu != 0)));
+  if (x3) HIP_TRY(h, (launch_conv_x3<1, 8, 32>(h->stream, L, lv, d, h_px, w, dout, nullptr, lrelu != 0)));
+  else HIP_TRY(h, (launch_conv<3, 1, 1, 8, 4, 32>(h->stream, L, lv, d, h_px, w, dout, nullptr, lrelu != 0)));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   HIP_TRY(h, hipMemcpy(tmp.data(), dout, n * 4, hipMemcpyDeviceToHost));
   for (int co = 0; co < kC; ++co)

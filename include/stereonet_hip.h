@@ -138,7 +138,8 @@ int sn_get_dominant_kernel(sn_handle *h, char *name, size_t name_cap, int *launc
                            double *flops_per_launch, double *bytes_per_launch);
 
 /* Parity hooks (tests only; they run the product kernels on caller data, host memory) -------- */
-/* one C->32 convolution through the MFMA kernel: in [cin][h][w] fp32, wt [32][cin][k][k], out [32][ho][wo] */
+/* one C->32 convolution through the MFMA kernel: in [cin][h][w] fp32, wt [32][cin][k][k], out [32][ho][wo].
+ * lrelu bit 0 = LeakyReLU, bit 1 = use the split-operand fp16 kernel of the fp16 modes (3x3, stride 1, cin 32). */
 int sn_dbg_conv2d(sn_handle *h, const float *in, int cin, int h_px, int w, const float *wt,
                   const float *bias, int k, int stride, int dil, int lrelu, const float *residual,
                   float *out);

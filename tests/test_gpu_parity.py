@@ -226,3 +226,31 @@ def test_baseline_config_c5_kitti_1242x375_d256(model_factory, oracle, weights_b
     assert disp.shape == (h, w) and epe < EPE_TOL
     inv_q = np.float32(1.0 / (float(d) * float(np.float32(spec.OUT_SCALE))))
     assert (raw == np.rint(disp * inv_q).astype(np.int32)).all()
+
+
+@pytest.mark.parametrize("h,w", [(45, 80), (34, 60), (24, 78), (64, 96), (9, 33)])
+def test_lowres_split_conv3x3(small_engine, oracle, h, w):
+    """k_conv3x3_c32_x3 (low-resolution layers of the fp16 modes): 22-bit split operands, fp32 in/out."""
+    rng = np.random.default_rng(h * 5 + w)
+    x = rng.standard_normal((32, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((32, 32, 3, 3)) / 17.0).astype(np.float32)
+    b = rng.standard_normal(32).astype(np.float32)
+    ref = oracle.conv2d(x, wt, b, 1, 1, 1)
+    got = small_engine.dbg_conv2d(x, wt, b, 3, 1, 1, x3=True)
+    assert rel_err(got, ref) < 4e-6
+    res = rng.standard_normal((32, h, w)).astype(np.float32)
+    v = ref + res
+    ref2 = np.where(v > 0, v, v * np.float32(0.2))
+    got2 = small_engine.dbg_conv2d(x, wt, b, 3, 1, 1, lrelu=True, residual=res, x3=True)
+    assert rel_err(got2, ref2) < 4e-6
+
+
+@pytest.mark.parametrize("d,h,w", [(3, 4, 6), (12, 45, 80), (16, 24, 78)])
+def test_lowres_split_conv3d(small_engine, oracle, d, h, w):
+    rng = np.random.default_rng(d + h + w)
+    x = rng.standard_normal((32, d, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((32, 32, 3, 3, 3)) / 30.0).astype(np.float32)
+    b = rng.standard_normal(32).astype(np.float32)
+    ref = oracle.conv3d(x, wt, b)
+    got = small_engine.dbg_conv3d(x, wt, b, x3=True)
+    assert rel_err(got, ref) < 4e-6
