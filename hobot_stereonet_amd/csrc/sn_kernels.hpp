@@ -369,8 +369,8 @@ __global__ __launch_bounds__(256, MINW) void k_conv_c32_mfma(ConvArgs a, Loader 
 }
 
 // ------------------------------------------------------------------------------------------
-// Split-operand variant of the 3x3 stride-1 implicit GEMM for the LOW-RESOLUTION layers (feature res-blocks,
-// cost-volume / 3-D aggregation convs) in the fp16 modes: the fp32 activations are split on the fly into
+// Split-operand variant of the implicit GEMM (3x3 stride 1, 5x5 stride 2) for the LOW-RESOLUTION layers (32->32
+// down-convs, feature res-blocks, cost-volume / 3-D aggregation convs) in the fp16 modes: the fp32 activations are split on the fly into
 // (hi, lo) fp16 pairs while being staged into LDS, weights are pre-split on the host, and each product is
 // three v_mfma_f32_32x32x16_f16 (see k_ref_conv_f16x3): 22-bit operands, fp32 accumulation, at 3/16 of the
 // cost of the exact-fp32 MFMA the fp32 mode uses.  Inputs/outputs stay fp32 NCHW in HBM.
@@ -378,19 +378,24 @@ __global__ __launch_bounds__(256, MINW) void k_conv_c32_mfma(ConvArgs a, Loader 
 //   is one conflict-free ds_read_b128; A fragments [tap][hi|lo][lane] are a straight copy of the host packing.
 //   K chunk = 16 (virtual) input channels = one MFMA K step; register staging as in k_conv_c32_mfma.
 // ------------------------------------------------------------------------------------------
-template <int DIL, int TR, int TC, class Loader>
-__global__ __launch_bounds__(256) void k_conv3x3_c32_x3(ConvArgs a, Loader ld) {
+template <int KS, int STRIDE, int DIL, int TR, int TC, class Loader>
+__global__ __launch_bounds__(256) void k_conv_c32_x3(ConvArgs a, Loader ld) {
   extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
-  constexpr int CH = 16, TAPS = 9;
+  constexpr int CH = 16, TAPS = KS * KS;
+  constexpr bool WLDS = TAPS <= 9;                     // 3x3: A fragments staged in LDS; 5x5: read through L1
   constexpr int CSEG = TC / 32, NSEG = TR * CSEG;
   static_assert(NSEG % 4 == 0, "tile must split evenly over 4 waves");
+  static_assert(STRIDE == 1 || DIL == 1, "strided convs are not dilated");
   constexpr int SPW = NSEG / 4;
-  constexpr int ROWS_IN = TR + 2 * DIL, COLS_IN = TC + 2 * DIL;
-  constexpr int PLANE = ROWS_IN * COLS_IN;             // slots per channel block
-  constexpr int NELEM = CH * PLANE;
+  constexpr int ROWS_IN = (TR - 1) * STRIDE + (KS - 1) * DIL + 1;
+  constexpr int COLS_IN = (TC - 1) * STRIDE + (KS - 1) * DIL + 1;
+  constexpr int HALF = (COLS_IN + 1) / 2;
+  constexpr int PITCH = STRIDE == 1 ? COLS_IN : 2 * HALF;   // stride 2: columns split by parity, as in the fp32 kernel
+  constexpr int PLANE = ROWS_IN * PITCH;               // slots per channel block
+  constexpr int NELEM = CH * ROWS_IN * COLS_IN;
   constexpr int EPT = (NELEM + 255) / 256;
   constexpr int NW4 = TAPS * 2 * 64;                   // weight slots per chunk
-  constexpr int WPT = (NW4 + 255) / 256;
+  constexpr int WPT = WLDS ? (NW4 + 255) / 256 : 1;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -401,10 +406,10 @@ __global__ __launch_bounds__(256) void k_conv3x3_c32_x3(ConvArgs a, Loader ld) {
   const int ty = t2 % a.tiles_y;
   const int img = t2 / a.tiles_y;
 
-  uint4* s_w = smem4;                        // [TAPS][hi|lo][64]
-  uint4* s_xh = smem4 + NW4;                 // [2 blocks][PLANE]
+  uint4* s_w = smem4;                                  // [TAPS][hi|lo][64] (WLDS only)
+  uint4* s_xh = smem4 + (WLDS ? NW4 : 0);              // [2 blocks][PLANE]
   uint4* s_xl = s_xh + 2 * PLANE;
-  const int iy0 = ty * TR - a.pad, ix0 = tx * TC - a.pad;
+  const int iy0 = ty * TR * STRIDE - a.pad, ix0 = tx * TC * STRIDE - a.pad;
 
   f32x16 acc0[SPW], acc1[SPW];
 #pragma unroll
@@ -424,17 +429,19 @@ __global__ __launch_bounds__(256) void k_conv3x3_c32_x3(ConvArgs a, Loader ld) {
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
       const int idx = e * 256 + tq;
-      const int c = idx / PLANE;
-      const int rem = idx - c * PLANE;
+      const int c = idx / (ROWS_IN * COLS_IN);
+      const int rem = idx - c * (ROWS_IN * COLS_IN);
       const int r = rem / COLS_IN;
       const int cc = rem - r * COLS_IN;
       pre[e] = idx < NELEM ? ld(img, c0 + c, iy0 + r, ix0 + cc) : 0.f;
     }
-    const uint4* wsrc = reinterpret_cast<const uint4*>(a.wpk) + (size_t)(c0 / CH) * NW4;
+    if (WLDS) {
+      const uint4* wsrc = reinterpret_cast<const uint4*>(a.wpk) + (size_t)(c0 / CH) * NW4;
 #pragma unroll
-    for (int e = 0; e < WPT; ++e) {
-      const int idx = e * 256 + tq;
-      wpre[e] = idx < NW4 ? wsrc[idx] : make_uint4(0, 0, 0, 0);
+      for (int e = 0; e < WPT; ++e) {
+        const int idx = e * 256 + tq;
+        wpre[e] = idx < NW4 ? wsrc[idx] : make_uint4(0, 0, 0, 0);
+      }
     }
   };
   auto commit = [&]() {
@@ -443,21 +450,26 @@ __global__ __launch_bounds__(256) void k_conv3x3_c32_x3(ConvArgs a, Loader ld) {
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
       const int idx = e * 256 + tq;
-      const int c = idx / PLANE;
-      const int rem = idx - c * PLANE;          // = r * COLS_IN + cc
+      const int c = idx / (ROWS_IN * COLS_IN);
+      const int rem = idx - c * (ROWS_IN * COLS_IN);
+      const int r = rem / COLS_IN;
+      const int cc = rem - r * COLS_IN;
       if (idx < NELEM) {
         const float v = pre[e];
         const _Float16 hi = (_Float16)v;
         const _Float16 lo = (_Float16)((v - (float)hi) * kSplitScale);
-        const int off = ((c >> 3) * PLANE + rem) * 8 + (c & 7);      // in halves
+        const int di = STRIDE == 1 ? cc : (cc & 1) * HALF + (cc >> 1);
+        const int off = ((c >> 3) * PLANE + r * PITCH + di) * 8 + (c & 7);      // in halves
         reinterpret_cast<_Float16*>(s_xh)[off] = hi;
         reinterpret_cast<_Float16*>(s_xl)[off] = lo;
       }
     }
+    if (WLDS) {
 #pragma unroll
-    for (int e = 0; e < WPT; ++e) {
-      const int idx = e * 256 + tq;
-      if (idx < NW4) s_w[idx] = wpre[e];
+      for (int e = 0; e < WPT; ++e) {
+        const int idx = e * 256 + tq;
+        if (idx < NW4) s_w[idx] = wpre[e];
+      }
     }
   };
 
@@ -470,17 +482,20 @@ __global__ __launch_bounds__(256) void k_conv3x3_c32_x3(ConvArgs a, Loader ld) {
     if (more) fetch(c0 + CH);
     const uint4* bh = s_xh + gh * PLANE + j;
     const uint4* bl = s_xl + gh * PLANE + j;
+    const uint4* wg = reinterpret_cast<const uint4*>(a.wpk) + (size_t)(c0 / CH) * NW4 + lane;
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
-      const int ky = tap / 3, kx = tap - ky * 3;
-      const uint4 wa = s_w[(tap * 2 + 0) * 64 + lane], wb = s_w[(tap * 2 + 1) * 64 + lane];
+      const int ky = tap / KS, kx = tap - ky * KS;
+      const uint4 wa = WLDS ? s_w[(tap * 2 + 0) * 64 + lane] : wg[(tap * 2 + 0) * 64];
+      const uint4 wb = WLDS ? s_w[(tap * 2 + 1) * 64 + lane] : wg[(tap * 2 + 1) * 64];
       const half8 whi = *reinterpret_cast<const half8*>(&wa);
       const half8 wlo = *reinterpret_cast<const half8*>(&wb);
 #pragma unroll
       for (int s = 0; s < SPW; ++s) {
         const int seg = wave * SPW + s;
         const int srow = seg / CSEG, scol = (seg - srow * CSEG) * 32;
-        const int off = (srow + ky * DIL) * COLS_IN + scol + kx * DIL;
+        const int off = STRIDE == 1 ? (srow + ky * DIL) * PITCH + scol + kx * DIL
+                                    : (srow * STRIDE + ky) * PITCH + (kx & 1) * HALF + scol + (kx >> 1);
         const uint4 xa = bh[off], xb = bl[off];
         const half8 xh = *reinterpret_cast<const half8*>(&xa);
         const half8 xl = *reinterpret_cast<const half8*>(&xb);

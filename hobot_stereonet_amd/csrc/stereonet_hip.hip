@@ -197,17 +197,17 @@ int upload_conv3d(sn_handle* h, const HostLayer& l, ConvLayer* out) {
 
 // split fp16 A-fragments for k_conv3x3_c32_x3: wv(co, c', tap) is the weight of virtual input channel c'
 template <class WV>
-int upload_x3(sn_handle* h, int cin_virtual, WV wv, ConvLayer* out) {
+int upload_x3(sn_handle* h, int cin_virtual, WV wv, ConvLayer* out, int taps = 9) {
   const int nchunk = cin_virtual / 16;
-  std::vector<_Float16> pk((size_t)nchunk * 9 * 2 * 64 * 8);
+  std::vector<_Float16> pk((size_t)nchunk * taps * 2 * 64 * 8);
   for (int ch = 0; ch < nchunk; ++ch)
-    for (int tap = 0; tap < 9; ++tap)
+    for (int tap = 0; tap < taps; ++tap)
       for (int lane = 0; lane < 64; ++lane)
         for (int e = 0; e < 8; ++e) {
           const int co = lane & 31, c = ch * 16 + 8 * (lane >> 5) + e;
           const float w = wv(co, c, tap);
           const _Float16 hi = (_Float16)w;
-          const size_t base = (((size_t)ch * 9 + tap) * 2) * 64 * 8 + (size_t)lane * 8 + e;
+          const size_t base = (((size_t)ch * taps + tap) * 2) * 64 * 8 + (size_t)lane * 8 + e;
           pk[base] = hi;
           pk[base + 64 * 8] = (_Float16)((w - (float)hi) * kSplitScale);
         }
@@ -216,9 +216,9 @@ int upload_x3(sn_handle* h, int cin_virtual, WV wv, ConvLayer* out) {
   return SN_OK;
 }
 
-template <int DIL, int TR, int TC, class Loader>
-hipError_t launch_conv_x3(hipStream_t st, const ConvLayer& L, const Loader& ld, int nimg, int Ho, int Wo, float* out,
-                          const float* res, bool lrelu) {
+template <int KS, int STRIDE, int DIL, int TR, int TC, class Loader>
+hipError_t launch_conv_x3g(hipStream_t st, const ConvLayer& L, const Loader& ld, int nimg, int Ho, int Wo, float* out,
+                           const float* res, bool lrelu) {
   ConvArgs a{};
   a.wpk = reinterpret_cast<const float*>(L.wx3);
   a.bias = L.bias;
@@ -229,16 +229,24 @@ hipError_t launch_conv_x3(hipStream_t st, const ConvLayer& L, const Loader& ld, 
   a.Ho = Ho;
   a.Wo = Wo;
   a.dil = DIL;
-  a.pad = DIL;
+  a.pad = (KS / 2) * DIL;
   a.lrelu = lrelu ? 1 : 0;
   a.tiles_x = (Wo + TC - 1) / TC;
   a.tiles_y = (Ho + TR - 1) / TR;
-  constexpr int plane = (TR + 2 * DIL) * (TC + 2 * DIL);
-  constexpr size_t lds = ((size_t)9 * 2 * 64 + 4 * plane) * 16;
+  constexpr int rows_in = (TR - 1) * STRIDE + (KS - 1) * DIL + 1;
+  constexpr int cols_in = (TC - 1) * STRIDE + (KS - 1) * DIL + 1;
+  constexpr int pitch = STRIDE == 1 ? cols_in : 2 * ((cols_in + 1) / 2);
+  constexpr size_t lds = ((size_t)(KS * KS <= 9 ? KS * KS * 2 * 64 : 0) + 4 * rows_in * pitch) * 16;
   static_assert(lds <= 64 * 1024, "x3 conv tile too large for the default LDS limit");
-  hipLaunchKernelGGL((k_conv3x3_c32_x3<DIL, TR, TC, Loader>), dim3(a.tiles_x * a.tiles_y * nimg), dim3(256), lds, st, a,
-                     ld);
+  hipLaunchKernelGGL((k_conv_c32_x3<KS, STRIDE, DIL, TR, TC, Loader>), dim3(a.tiles_x * a.tiles_y * nimg), dim3(256),
+                     lds, st, a, ld);
   return hipGetLastError();
+}
+
+template <int DIL, int TR, int TC, class Loader>
+hipError_t launch_conv_x3(hipStream_t st, const ConvLayer& L, const Loader& ld, int nimg, int Ho, int Wo, float* out,
+                          const float* res, bool lrelu) {
+  return launch_conv_x3g<3, 1, DIL, TR, TC, Loader>(st, L, ld, nimg, Ho, Wo, out, res, lrelu);
 }
 
 int upload_head(sn_handle* h, const HostLayer& l, HeadLayer* out) {   // [1][32][taps] as-is
@@ -313,6 +321,7 @@ hipError_t conv5x5s2(hipStream_t st, const ConvLayer& L, const float* in, int ni
                      float* out) {
   LoadF32 ld{in, kC, Hin, Win};
   const int Ho = Hin / 2, Wo = Win / 2;
+  if (L.wx3) return launch_conv_x3g<5, 2, 1, 4, 32>(st, L, ld, nimg, Ho, Wo, out, nullptr, false);   // fp16 modes
   if (Ho * Wo <= 64 * 128) return launch_conv<5, 2, 1, 4, 4, 32>(st, L, ld, nimg, Ho, Wo, out, nullptr, false);
   return launch_conv<5, 2, 1, 4, 8, 64>(st, L, ld, nimg, Ho, Wo, out, nullptr, false);
 }
@@ -886,11 +895,17 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
   h->overlap = getenv("SN_NO_OVERLAP") == nullptr;
 
   BlobWalker bw{blob.data()};
-  for (int i = 0; i < kNDown; ++i)
-    if ((rc = upload_conv2d(h, bw.next(kC, i == 0 ? 3 : kC, 25), 4, &h->down[i]))) return fail(rc);
+  const bool low_x3 = h->precision != SN_PREC_FP32 && getenv("SN_LOW_FP32") == nullptr;
+  for (int i = 0; i < kNDown; ++i) {
+    const HostLayer hl_ = bw.next(kC, i == 0 ? 3 : kC, 25);
+    if ((rc = upload_conv2d(h, hl_, 4, &h->down[i]))) return fail(rc);
+    if (low_x3 && i > 0 && getenv("SN_DOWN_FP32") == nullptr &&
+        (rc = upload_x3(h, kC, [&](int co, int c, int tap) { return hl_.w[((size_t)co * kC + c) * 25 + tap]; },
+                        &h->down[i], 25)))
+      return fail(rc);
+  }
   // fp16 modes: the low-resolution 3x3 / 3x3x3 layers also get split fp16 A-fragments (22-bit operands on the
   // fp16 MFMA, k_conv3x3_c32_x3); SN_PREC_FP32 keeps every contraction on the exact-fp32 MFMA
-  const bool low_x3 = h->precision != SN_PREC_FP32 && getenv("SN_LOW_FP32") == nullptr;
   auto up2d = [&](ConvLayer* L) -> int {
     const HostLayer hl_ = bw.next(kC, kC, 9);
     int r = upload_conv2d(h, hl_, 8, L);
@@ -1257,11 +1272,12 @@ int sn_dbg_conv2d(sn_handle* h, const float* in, int cin, int h_px, int w, const
   if (stride == 2 && ((h_px & 1) || (w & 1))) return SN_ERR_ARG;
   const bool x3 = (lrelu & 2) != 0;
   lrelu &= 1;
-  if (x3 && !(k == 3 && stride == 1 && cin == kC && dil == 1)) return SN_ERR_ARG;
+  if (x3 && !(cin == kC && dil == 1)) return SN_ERR_ARG;
   ConvLayer L;
   HostLayer hl{wt, bias, kC, cin, taps};
   if ((rc = upload_conv2d(h, hl, (k == 5 || cin <= 4) ? 4 : 8, &L))) return rc;
-  if (x3 && (rc = upload_x3(h, kC, [&](int co, int c, int tap) { return wt[((size_t)co * kC + c) * 9 + tap]; }, &L)))
+  if (x3 && (rc = upload_x3(h, kC, [&](int co, int c, int tap) { return wt[((size_t)co * kC + c) * taps + tap]; }, &L,
+                            taps)))
     return rc;
   float *din = nullptr, *dout = nullptr;
   const size_t nin = (size_t)cin * h_px * w, nout = (size_t)kC * Ho * Wo;
@@ -1276,7 +1292,9 @@ int sn_dbg_conv2d(sn_handle* h, const float* in, int cin, int h_px, int w, const
   hipStream_t st = h->stream;
   LoadF32 ld{din, cin, h_px, w};
   hipError_t e;
-  if (k == 5) {
+  if (k == 5 && x3) {
+    e = launch_conv_x3g<5, 2, 1, 4, 32>(st, L, ld, 1, Ho, Wo, dout, dres, lrelu != 0);
+  } else if (k == 5) {
     e = (Ho * Wo <= 64 * 128) ? launch_conv<5, 2, 1, 4, 4, 32>(st, L, ld, 1, Ho, Wo, dout, dres, lrelu != 0)
                               : launch_conv<5, 2, 1, 4, 8, 64>(st, L, ld, 1, Ho, Wo, dout, dres, lrelu != 0);
   } else if (cin <= 4) {

@@ -254,3 +254,15 @@ def test_lowres_split_conv3d(small_engine, oracle, d, h, w):
     ref = oracle.conv3d(x, wt, b)
     got = small_engine.dbg_conv3d(x, wt, b, x3=True)
     assert rel_err(got, ref) < 4e-6
+
+
+@pytest.mark.parametrize("h,w", [(90, 160), (46, 82), (360, 640), (64, 96)])
+def test_lowres_split_conv5x5_stride2(small_engine, oracle, h, w):
+    rng = np.random.default_rng(h * 3 + w)
+    x = rng.standard_normal((32, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((32, 32, 5, 5)) / 28.0).astype(np.float32)
+    b = rng.standard_normal(32).astype(np.float32)
+    ref = oracle.conv2d(x, wt, b, 2, 2, 1)
+    got = small_engine.dbg_conv2d(x, wt, b, 5, 2, 1, x3=True)
+    assert got.shape == ref.shape
+    assert rel_err(got, ref) < 4e-6
