@@ -860,6 +860,15 @@ struct RefTile2 {
   static constexpr int NSTORE = 4 * SPW;
 };
 
+// LeakyReLU as max(v, slope*v) with a raw v_max_f32: fmaxf() makes hipcc insert a canonicalising v_max in front
+// (sNaN semantics) and the select form costs cmp + cndmask + mul; MFMA results are never signalling NaNs.
+__device__ __forceinline__ float lrelu_fast(float v) {
+  const float t = v * kSlope;
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(t));
+  return r;
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -942,6 +951,31 @@ __global__ __launch_bounds__(256, 2) void k_ref_conv_f16_v2(const uint4* __restr
   const int seg0 = wave * T::SPW;
   const int lane_off = gh * T::PLANE + (seg0 / T::CSEG) * T::COLS + j;
 
+  // Addressing: every global address is  uniform 32-bit byte offset of the tile (SGPRs, recomputed per tile)
+  // + a per-lane 32-bit byte offset that never changes (VGPRs, computed once).  This keeps 64-bit VALU
+  // address arithmetic (previously ~40 % of the loop's VALU work) out of the tile loop.  The host guarantees
+  // that a tensor stays below 4 GiB.
+  const unsigned plane_b = (unsigned)g.Hs * (unsigned)g.Ws * 16u;           // bytes per channel block
+  unsigned dma_voff[T::KW];                                                    // per DMA instruction of this wave
+#pragma unroll
+  for (int k = 0; k < T::KW; ++k) {
+    int i = wave + 4 * k;
+    i = i < T::NINST ? i : T::NINST - 1;                 // constant op count per wave: repeat the last chunk
+    int s = i * 64 + lane;
+    s = s < T::HALF ? s : T::HALF - 1;
+    const int pc = s / T::PLANE;
+    const int rem = s - pc * T::PLANE;
+    const int r = rem / T::COLS;
+    const int c = rem - r * T::COLS;
+    dma_voff[k] = (unsigned)pc * plane_b + ((unsigned)r * (unsigned)g.Ws + (unsigned)c) * 16u;
+  }
+  unsigned io_voff[T::SPW];                                                    // output / residual, per segment
+#pragma unroll
+  for (int s = 0; s < T::SPW; ++s) {
+    const int seg = seg0 + s;
+    io_voff[s] = ((unsigned)(seg / T::CSEG) * (unsigned)g.Ws + (unsigned)((seg % T::CSEG) * 32 + j)) * 16u + gh * 8u;
+  }
+
   auto tile_xy = [&](int ti, int& img, int& y0, int& x0) {
     const int t = t0 + ti * nlb;
     img = t / per_img;
@@ -950,30 +984,42 @@ __global__ __launch_bounds__(256, 2) void k_ref_conv_f16_v2(const uint4* __restr
     y0 = ty * T::TH;
     x0 = (rem - ty * g.tiles_x) * T::TW;
   };
-  auto issue = [&](int gp) {                                  // DMA group of phase gp into ring slot gp % 3
-    int img, y0, x0;
-    tile_xy(gp >> 1, img, y0, x0);
-    ref2_issue_dma<DIL, TW>(in, lds + (gp % 3) * T::BUF, g, img, y0, x0, gp & 1, wave, lane);
+  // uniform byte offset of (image, channel block 0, padded row y, padded col x)
+  auto tile_base = [&](int img, int y, int x) -> unsigned {
+    return (((unsigned)img * 4u * (unsigned)g.Hs + (unsigned)(y + kRefPad)) * (unsigned)g.Ws + (unsigned)(x + kRefPad)) * 16u;
+  };
+  auto issue = [&](int gp, int img, int y0, int x0) {         // DMA group of phase gp (tile img,y0,x0) -> ring slot gp % 3
+    const char* src = reinterpret_cast<const char*>(in) + (tile_base(img, y0 - DIL, x0 - DIL) + 2u * (gp & 1) * plane_b);
+    uint4* dst = lds + (gp % 3) * T::BUF;
+#pragma unroll
+    for (int k = 0; k < T::KW; ++k) {
+      int i = wave + 4 * k;
+      i = i < T::NINST ? i : T::NINST - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + dma_voff[k]),
+                                       (__attribute__((address_space(3))) void*)(dst + i * 64), 16, 0, 0);
+    }
   };
 
   wait_vmcnt<0>();
-  issue(0);
-  issue(1);
+  int img, y0, x0, nimg_ = 0, ny0 = 0, nx0 = 0;
+  tile_xy(0, img, y0, x0);
+  issue(0, img, y0, x0);
+  issue(1, img, y0, x0);
 
   f32x16 acc[T::SPW];
   for (int ti = 0; ti < ntiles; ++ti) {
-    int img, y0, x0;
-    tile_xy(ti, img, y0, x0);
     const int g0 = 2 * ti;
+    if (ti + 1 < ntiles) tile_xy(ti + 1, nimg_, ny0, nx0);   // one coordinate decode per tile
     // ---- phase g0 (channels 0..15) ----
     if (ti == 0) wait_vmcnt<T::KW>();                         // younger than group 0: group 1
     else wait_vmcnt<T::KW + T::NSTORE>();                     // ... plus the previous tile's stores
     __builtin_amdgcn_s_barrier();
-    if (g0 + 2 < G) issue(g0 + 2);
+    if (g0 + 2 < G) issue(g0 + 2, nimg_, ny0, nx0);
+    // accumulators start at the bias: saves one add per output in the epilogue
 #pragma unroll
     for (int s = 0; s < T::SPW; ++s)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[s][r] = bv[r];
     ref2_compute<DIL, TW, 0>(lds + (g0 % 3) * T::BUF + lane_off, wf, acc);
 
     // ---- phase g0+1 (channels 16..31) ----
@@ -984,24 +1030,21 @@ __global__ __launch_bounds__(256, 2) void k_ref_conv_f16_v2(const uint4* __restr
     // residual: NSTORE 8-byte loads issued as inline asm BEFORE the next DMA group, so they are older
     // than it and the counted wait below (all but the newest KW ops) retires them without draining
     // the ring.  hipcc does not track asm loads: the "+v" wait statement is what orders their use.
-    char* obase[T::SPW];
+    const unsigned tb = tile_base(img, y0, x0);
     uint2 rres[RES ? T::NSTORE : 1];
+    if (RES) {
 #pragma unroll
-    for (int s = 0; s < T::SPW; ++s) {
-      const int seg = seg0 + s;
-      const int y = y0 + seg / T::CSEG, x = x0 + (seg % T::CSEG) * 32 + j;
-      const size_t slot0 = ((size_t)img * 4 * g.Hs + (y + kRefPad)) * g.Ws + (x + kRefPad);
-      obase[s] = reinterpret_cast<char*>(out) + slot0 * 16 + gh * 8;
-      if (RES) {
+      for (int q = 0; q < 4; ++q) {
+        const char* rq = reinterpret_cast<const char*>(res) + (tb + (unsigned)q * plane_b);    // uniform
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const char* rp = reinterpret_cast<const char*>(res) + (slot0 + (size_t)q * g.Hs * g.Ws) * 16 + gh * 8;
+        for (int s = 0; s < T::SPW; ++s) {
+          const char* rp = rq + io_voff[s];
           asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rres[RES ? s * 4 + q : 0]) : "v"(rp) : "memory");
         }
       }
     }
     const bool more = g0 + 3 < G;
-    if (more) issue(g0 + 3);
+    if (more) issue(g0 + 3, nimg_, ny0, nx0);
     ref2_compute<DIL, TW, 1>(lds + ((g0 + 1) % 3) * T::BUF + lane_off, wf, acc);
     if (RES) {
       if (more) wait_vmcnt<T::KW>(); else wait_vmcnt<0>();
@@ -1009,33 +1052,41 @@ __global__ __launch_bounds__(256, 2) void k_ref_conv_f16_v2(const uint4* __restr
       for (int i = 0; i < T::NSTORE; ++i) asm volatile("" : "+v"(rres[i]));
     }
 
-    // ---- epilogue: exactly NSTORE stores per wave; out-of-image pixels store zeros ----
+    // ---- epilogue: exactly NSTORE stores per wave; out-of-image pixels store zeros.  Tiles that lie
+    // completely inside the image (all of them at 1280x720) skip the per-element masking. ----
+    const bool interior = y0 + T::TH <= g.H && x0 + T::TW <= g.W;            // wave-uniform
 #pragma unroll
-    for (int s = 0; s < T::SPW; ++s) {
-      const int seg = seg0 + s;
-      const int y = y0 + seg / T::CSEG, x = x0 + (seg % T::CSEG) * 32 + j;
-      const bool ok = y < g.H && x < g.W;
+    for (int q = 0; q < 4; ++q) {
+      char* oq = reinterpret_cast<char*>(out) + (tb + (unsigned)q * plane_b);                  // uniform
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int s = 0; s < T::SPW; ++s) {
         float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[s][4 * q + e] + bv[4 * q + e];
+        for (int e = 0; e < 4; ++e) v[e] = acc[s][4 * q + e];
         if (RES) {
           const uint2 rw = rres[RES ? s * 4 + q : 0];
           const half4 rv = *reinterpret_cast<const half4*>(&rw);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
         }
+        if (lrelu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = lrelu_fast(v[e]);
+        }
         half4 hv;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float u = v[e];
-          if (lrelu) u = u > 0.f ? u : u * kSlope;
-          hv[e] = ok ? (_Float16)u : (_Float16)0.f;
+        for (int e = 0; e < 4; ++e) hv[e] = (_Float16)v[e];
+        if (!interior) {
+          const int seg = seg0 + s;
+          const int y = y0 + seg / T::CSEG, x = x0 + (seg % T::CSEG) * 32 + j;
+          if (!(y < g.H && x < g.W)) hv = half4{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
         }
-        *reinterpret_cast<half4*>(obase[s] + (size_t)q * g.Hs * g.Ws * 16) = hv;
+        *reinterpret_cast<half4*>(oq + io_voff[s]) = hv;
       }
     }
+    img = nimg_;
+    y0 = ny0;
+    x0 = nx0;
   }
 }
 
