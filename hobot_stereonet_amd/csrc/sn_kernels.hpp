@@ -84,7 +84,7 @@ struct LoadF32 {            // plain NCHW fp32 tensor [nimg][C][H][W]
   int C, H, W;
   __device__ __forceinline__ float operator()(int img, int c, int y, int x) const {
     if ((unsigned)y >= (unsigned)H || (unsigned)x >= (unsigned)W || c >= C) return 0.f;
-    return p[(((size_t)img * C + c) * H + y) * W + x];
+    return p[(((unsigned)img * C + c) * H + y) * W + x];      // 32-bit index: tensors are < 2^32 elements (host check)
   }
 };
 
@@ -94,7 +94,7 @@ struct LoadI8Eye {          // model input int8 [n][6][H][W]; image = n*2 + eye;
   __device__ __forceinline__ float operator()(int img, int c, int y, int x) const {
     if ((unsigned)y >= (unsigned)H || (unsigned)x >= (unsigned)W || c >= 3) return 0.f;
     const int n = img >> 1, eye = img & 1;
-    return (float)p[(((size_t)n * 6 + eye * 3 + c) * H + y) * W + x] * (1.0f / 128.0f);
+    return (float)p[(((unsigned)n * 6 + eye * 3 + c) * H + y) * W + x] * (1.0f / 128.0f);
   }
 };
 
@@ -109,7 +109,7 @@ struct LoadVol3D {
     const int dd = d + dz - 1;
     if ((unsigned)dd >= (unsigned)Dl || (unsigned)y >= (unsigned)H || (unsigned)x >= (unsigned)W)
       return 0.f;
-    return p[((((size_t)n * Dl + dd) * kC + ci) * H + y) * W + x];
+    return p[((((unsigned)n * Dl + dd) * kC + ci) * H + y) * W + x];
   }
 };
 
@@ -125,10 +125,9 @@ struct LoadCostVol {
     if ((unsigned)dd >= (unsigned)Dl || (unsigned)y >= (unsigned)H || (unsigned)x >= (unsigned)W ||
         x < dd)
       return 0.f;
-    const size_t plane = (size_t)H * W;
-    const float* l = feat + ((size_t)(2 * n) * kC + ci) * plane + (size_t)y * W;
-    const float* r = l + (size_t)kC * plane;
-    return l[x] - r[x - dd];
+    const unsigned plane = (unsigned)H * W;
+    const unsigned li = ((unsigned)(2 * n) * kC + ci) * plane + (unsigned)y * W + x;
+    return feat[li] - feat[li + kC * plane - dd];
   }
 };
 

@@ -876,6 +876,16 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
   h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (h->refine_chunk > h->max_batch) h->refine_chunk = h->max_batch;
 
+  // the kernels use 32-bit element / byte offsets inside one tensor: keep every tensor below 2^32
+  {
+    const double low_elems = 2.0 * (h->piece < h->max_batch ? h->piece : h->max_batch) * kC * (h->Hp / 2.0) * (h->Wp / 2.0);
+    const double ref_bytes = (double)h->refine_chunk * 4.0 * h->rg.Hs * h->rg.Ws * 16.0;
+    const double vol_elems = (double)(h->piece < h->max_batch ? h->piece : h->max_batch) * h->Dl * kC * h->hl * h->wl;
+    if (low_elems >= 4.0e9 || ref_bytes >= 4.0e9 || vol_elems >= 4.0e9) {
+      delete h;
+      return SN_ERR_ARG;
+    }
+  }
   int rc = check_device(h);
   auto fail = [&](int code) {
     sn_destroy(h);
