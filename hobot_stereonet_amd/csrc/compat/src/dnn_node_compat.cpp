@@ -112,7 +112,7 @@ int DnnNode::Init() {
   cfg.max_batch = 1;
   cfg.task_num = dnn_node_para_ptr_->task_num;
   const char* prec = getenv("STEREONET_PRECISION");   // knob kept out of the ROS parameter surface
-  cfg.precision = (prec && !strcmp(prec, "fp32")) ? SN_PREC_FP32 : SN_PREC_F16;
+  cfg.precision = (prec && !strcmp(prec, "fp32")) ? SN_PREC_FP32 : (prec && !strcmp(prec, "f16x3")) ? SN_PREC_F16X3 : SN_PREC_F16;
   const int rc = sn_create(dnn_node_para_ptr_->model_file.c_str(), &cfg, &engine_);
   if (rc != SN_OK) {
     RCLCPP_ERROR(rclcpp::get_logger("dnn"), "load model %s failed: %s", dnn_node_para_ptr_->model_file.c_str(),

@@ -106,7 +106,6 @@ struct sn_handle {
   bool profiling = false;
   hipEvent_t ev[8] = {};
   float stage_ms[SN_STAGE_COUNT] = {};
-  int dom_launches = 0;
   mutable std::string err;
 };
 
@@ -436,7 +435,7 @@ hipError_t launch_ref_f16(hipStream_t st, const RefLayerF16& L, const RefGeom& g
 
 template <int DIL, int TW>
 hipError_t launch_ref_f16_v2(hipStream_t st, const RefLayerF16& L, const RefGeom& g, int num_cu, const uint4* in,
-                             uint4* out, const uint4* res, int nimg, bool lrelu) {
+                             uint4* out, const uint4* res, int nimg, bool lrelu, int per_cu_cap) {
   using T = RefTile2<DIL, TW>;
   auto kern = res ? k_ref_conv_f16_v2<DIL, TW, true> : k_ref_conv_f16_v2<DIL, TW, false>;
   if (T::LDS_BYTES > 64 * 1024) {
@@ -447,7 +446,10 @@ hipError_t launch_ref_f16_v2(hipStream_t st, const RefLayerF16& L, const RefGeom
   RefGeom gt = g;                      // tile grid of this variant (the buffer geometry is for 8x64 tiles)
   gt.tiles_x = (g.W + TW - 1) / TW;
   const int total = gt.tiles_x * gt.tiles_y * nimg;
-  const int per_cu = T::LDS_BYTES * 2 <= 160 * 1024 ? 2 : 1;
+  // per_cu_cap = 1 while the low-resolution branch of the next piece runs on the other stream: one tower
+  // workgroup per CU leaves half of the register file / LDS for those kernels to co-reside (+2-3 %)
+  int per_cu = T::LDS_BYTES * 2 <= 160 * 1024 ? 2 : 1;
+  if (per_cu_cap > 0 && per_cu_cap < per_cu) per_cu = per_cu_cap;
   // persistent grid: 8 XCD bands; pick the block count per band so that every block walks the same number
   // of tiles (e.g. 225 tiles per band -> 57 blocks x 4 tiles, not 64 blocks x 3.5)
   const int band = (total + 7) / 8;
@@ -525,13 +527,13 @@ bool use_ref_v1() {
 }
 
 hipError_t ref_conv_f16(hipStream_t st, const RefLayerF16& L, const RefGeom& g, int num_cu, int dil, const uint4* in,
-                        uint4* out, const uint4* res, int nimg, bool lrelu) {
+                        uint4* out, const uint4* res, int nimg, bool lrelu, int per_cu_cap = 0) {
   if (!use_ref_v1()) {
     switch (dil) {
-      case 1: return launch_ref_f16_v2<1, 64>(st, L, g, num_cu, in, out, res, nimg, lrelu);
-      case 2: return launch_ref_f16_v2<2, 64>(st, L, g, num_cu, in, out, res, nimg, lrelu);
-      case 4: return launch_ref_f16_v2<4, 64>(st, L, g, num_cu, in, out, res, nimg, lrelu);
-      case 8: return launch_ref_f16_v2<8, 32>(st, L, g, num_cu, in, out, res, nimg, lrelu);
+      case 1: return launch_ref_f16_v2<1, 64>(st, L, g, num_cu, in, out, res, nimg, lrelu, per_cu_cap);
+      case 2: return launch_ref_f16_v2<2, 64>(st, L, g, num_cu, in, out, res, nimg, lrelu, per_cu_cap);
+      case 4: return launch_ref_f16_v2<4, 64>(st, L, g, num_cu, in, out, res, nimg, lrelu, per_cu_cap);
+      case 8: return launch_ref_f16_v2<8, 32>(st, L, g, num_cu, in, out, res, nimg, lrelu, per_cu_cap);
       default: return hipErrorInvalidValue;
     }
   }
@@ -545,7 +547,7 @@ hipError_t ref_conv_f16(hipStream_t st, const RefLayerF16& L, const RefGeom& g, 
 }
 
 hipError_t ref_block_f16(hipStream_t st, const RefLayerF16& L1, const RefLayerF16& L2, const RefGeom& g, int num_cu,
-                         int dil, uint4** cur, uint4** oth, int nimg) {
+                         int dil, uint4** cur, uint4** oth, int nimg, int per_cu_cap = 0) {
   if (const int fm = use_fused_block(dil)) {
     hipError_t e = fm == 2 ? launch_ref_block_f16_ws<1>(st, L1, L2, g, num_cu, *cur, *oth, nimg)
                            : launch_ref_block_f16<1>(st, L1, L2, g, num_cu, *cur, *oth, nimg);
@@ -554,9 +556,9 @@ hipError_t ref_block_f16(hipStream_t st, const RefLayerF16& L1, const RefLayerF1
     *oth = t;
     return e;
   }
-  hipError_t e = ref_conv_f16(st, L1, g, num_cu, dil, *cur, *oth, nullptr, nimg, true);
+  hipError_t e = ref_conv_f16(st, L1, g, num_cu, dil, *cur, *oth, nullptr, nimg, true, per_cu_cap);
   if (e != hipSuccess) return e;
-  return ref_conv_f16(st, L2, g, num_cu, dil, *oth, *cur, *cur, nimg, true);   // in-place residual
+  return ref_conv_f16(st, L2, g, num_cu, dil, *oth, *cur, *cur, nimg, true, per_cu_cap);   // in-place residual
 }
 
 // ---- workspace -----------------------------------------------------------------------------------
@@ -659,7 +661,7 @@ int lowres(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, const int
 
 // Refinement of pairs [p0, p0+m), `rb` pairs per tower launch.
 int refine(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, const int8_t* in6, float* out_disp,
-           int32_t* out_raw, bool prof) {
+           int32_t* out_raw, bool prof, bool overlapped = false) {
   const int Hp = h->Hp, Wp = h->Wp, hl = h->hl, wl = h->wl;
   const size_t HW = (size_t)h->H * h->W;
   const float inv_q = (float)(1.0 / ((double)h->D * (double)kOutScale));
@@ -714,7 +716,8 @@ int refine(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, const int
           HIP_TRY(h, ref_conv_f16x3(st, h->rres16[i][0], g, h->num_cu, kRefDil[i], rx, rt, nullptr, lo_slots, c, true));
           HIP_TRY(h, ref_conv_f16x3(st, h->rres16[i][1], g, h->num_cu, kRefDil[i], rt, rx, rx, lo_slots, c, true));
         } else {
-          HIP_TRY(h, ref_block_f16(st, h->rres16[i][0], h->rres16[i][1], g, h->num_cu, kRefDil[i], &rx, &rt, c));
+          HIP_TRY(h, ref_block_f16(st, h->rres16[i][0], h->rres16[i][1], g, h->num_cu, kRefDil[i], &rx, &rt, c,
+                                   overlapped ? 1 : 0));
         }
       }
       if (pe) HIP_TRY(h, hipEventRecord(h->ev[5], st));
@@ -762,7 +765,7 @@ int forward(sn_handle* h, Workspace& ws, hipStream_t st, int n, const int8_t* in
     hipEvent_t e = h->ev_piece[k % kMaxPieceEvents];
     HIP_TRY(h, hipEventRecord(e, h->s_low));
     HIP_TRY(h, hipStreamWaitEvent(h->s_ref, e, 0));
-    if ((rc = refine(h, ws, h->s_ref, p0, m, in6, out_disp, out_raw, false))) return rc;
+    if ((rc = refine(h, ws, h->s_ref, p0, m, in6, out_disp, out_raw, false, true))) return rc;
   }
   HIP_TRY(h, hipEventRecord(h->ev_join, h->s_ref));
   HIP_TRY(h, hipStreamWaitEvent(st, h->ev_join, 0));
