@@ -133,5 +133,10 @@ def test_stereonet_node_end_to_end(hostlib, oracle, weights_blob, tmp_path):
         assert np.abs(disp - odisp).mean() < 1e-3
         jpg = Image.open(io.BytesIO(payload[w * h * 4:].tobytes()))
         assert jpg.size == (w, h)
+        # the render node's twin consumes the message as is (it hard-codes the 16*12 of the reference model)
+        from hobot_stereonet_amd import render
+        rdisp, rdepth, joint = render.render(payload.tobytes(), w, h)
+        assert joint.shape == (2 * h, w, 3)
+        assert np.abs(rdisp * (d / 192.0) - odisp).mean() < 1e-3
         y = np.asarray(jpg.convert("YCbCr"), np.float32)[..., 0]
         assert np.abs(y - left[:w * h].reshape(h, w)).mean() < 6.0
