@@ -72,7 +72,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="pairs per GPU per step")
     ap.add_argument("--refine-chunk", type=int, default=2)
     ap.add_argument("--precision", choices=["fp32", "f16", "f16x3"], default="f16",
-                    help="arithmetic of the refinement-tower contractions (the low-res branch is always fp32)")
+                    help="fp32 = exact-fp32 MFMA everywhere; f16 = fp16 tower + 22-bit split low-res convs; f16x3 = split operands everywhere")
     ap.add_argument("--piece", type=int, default=8, help="pairs per low-res piece of the two-stream pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -200,6 +200,8 @@ def main():
             "gflop_per_pair": eng.flops_per_pair / 1e9,
             "model_tflops": value * eng.flops_per_pair / 1e12 / world,
             "stage_ms_per_step": stage,
+            "stage_note": "serialised profiling pass; features/aggregate = first piece of `piece` pairs only, "
+                          "refine_conv = the 12 tower launches of the first refine chunk, refine/total = whole batch",
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:
@@ -209,6 +211,7 @@ def main():
         print(json.dumps(out))
     eng.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 
