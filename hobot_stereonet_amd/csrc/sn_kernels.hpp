@@ -868,6 +868,14 @@ __device__ __forceinline__ float lrelu_fast(float v) {
   return r;
 }
 
+// Workgroup barrier for the hand-synchronised kernels: a bare s_barrier (no vmcnt drain, unlike __syncthreads())
+// fenced on both sides so that hipcc cannot move LDS / global accesses across it.
+__device__ __forceinline__ void block_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -1012,7 +1020,7 @@ __global__ __launch_bounds__(256, 2) void k_ref_conv_f16_v2(const uint4* __restr
     // ---- phase g0 (channels 0..15) ----
     if (ti == 0) wait_vmcnt<T::KW>();                         // younger than group 0: group 1
     else wait_vmcnt<T::KW + T::NSTORE>();                     // ... plus the previous tile's stores
-    __builtin_amdgcn_s_barrier();
+    block_barrier();
     if (g0 + 2 < G) issue(g0 + 2, nimg_, ny0, nx0);
     // accumulators start at the bias: saves one add per output in the epilogue
 #pragma unroll
@@ -1024,7 +1032,7 @@ __global__ __launch_bounds__(256, 2) void k_ref_conv_f16_v2(const uint4* __restr
     // ---- phase g0+1 (channels 16..31) ----
     if (g0 + 2 < G) wait_vmcnt<T::KW>();                      // younger than group g0+1: group g0+2
     else wait_vmcnt<0>();                                     // last phase of this block
-    __builtin_amdgcn_s_barrier();
+    block_barrier();
 
     // residual: NSTORE 8-byte loads issued as inline asm BEFORE the next DMA group, so they are older
     // than it and the counted wait below (all but the newest KW ops) retires them without draining
@@ -1210,7 +1218,7 @@ __global__ __launch_bounds__(256, 1) void k_ref_block_f16(const uint4* __restric
     tile_xy(ti, img, y0, x0);
     if (ti == 0) wait_vmcnt<0>();
     else wait_vmcnt<T::NSTORE>();                 // younger than this tile's x: the previous tile's stores
-    __builtin_amdgcn_s_barrier();                 // x tile visible; everyone is done with the previous tile
+    block_barrier();                 // x tile visible; everyone is done with the previous tile
     if (ti + 1 < ntiles) issue_x(ti + 1);
     const uint4* xa = xbuf + (2 * (ti & 1)) * T::XBUF;
     const uint4* xb = xa + T::XBUF;
@@ -1259,7 +1267,7 @@ __global__ __launch_bounds__(256, 1) void k_ref_block_f16(const uint4* __restric
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                 // t tile complete
+    block_barrier();                 // t tile complete
 
     // ---- stage 2: y = lrelu(x + conv2(t) + b2) on 8 x TWO, S2 segments per wave ----
     {
@@ -1374,7 +1382,7 @@ __global__ __launch_bounds__(512, 2) void k_ref_block_f16_ws(const uint4* __rest
   if (tid < 32) bl[tid] = bias1[tid];
   else if (tid < 64) bl[tid] = bias2[tid - 32];
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
+  block_barrier();
   const float* bmine0 = bl + (s1 ? 0 : 32);
   (void)bsrc;
 #pragma unroll
@@ -1445,7 +1453,7 @@ __global__ __launch_bounds__(512, 2) void k_ref_block_f16_ws(const uint4* __rest
     if (a1) {
       if (g0 + 1 < G) wait_vmcnt<T::KW>(); else wait_vmcnt<0>();     // group g0 landed (g0+1 may fly)
     }
-    __builtin_amdgcn_s_barrier();
+    block_barrier();
     if (a1) {
       if (g0 + 2 < G) issue(g0 + 2);
 #pragma unroll
@@ -1503,7 +1511,7 @@ __global__ __launch_bounds__(512, 2) void k_ref_block_f16_ws(const uint4* __rest
     if (a1) {
       if (g0 + 2 < G) wait_vmcnt<T::KW>(); else wait_vmcnt<0>();     // group g0+1 landed (g0+2 may fly)
     }
-    __builtin_amdgcn_s_barrier();
+    block_barrier();
     if (a1) {
       if (g0 + 3 < G) issue(g0 + 3);
       const uint4* base = xring + ((g0 + 1) % 3) * T::XBUF + gh * T::PX + j;
@@ -1715,7 +1723,7 @@ __global__ __launch_bounds__(256, 1) void k_ref_conv_f16x3(const uint4* __restri
     } else {
       if (ti == 0) wait_vmcnt<0>(); else wait_vmcnt<NST>();
     }
-    __builtin_amdgcn_s_barrier();
+    block_barrier();
     if (g0 + NBUF - 1 < G) issue(g0 + NBUF - 1);
 #pragma unroll
     for (int s = 0; s < T::SPW; ++s)
@@ -1732,7 +1740,7 @@ __global__ __launch_bounds__(256, 1) void k_ref_conv_f16x3(const uint4* __restri
     } else {
       wait_vmcnt<0>();
     }
-    __builtin_amdgcn_s_barrier();
+    block_barrier();
     char* obase[T::SPW];
     uint2 rres[RES ? 2 * T::NSTORE : 1];
 #pragma unroll
