@@ -1,37 +1,42 @@
-// stereonet_node.h — hobot::stereonet::StereonetNode with the reference's public surface
-// (stereonet_infer/include/stereonet_node.h:40-126): same class, constructor signature, ROS parameters
-// (config_file, model_file, sub_hbmem_topic_name, ros_img_topic_name), topics and output wire format, so the
-// reference's launch files keep working; the inference behind DnnNode::Run is libstereonet_hip.so.
+// stereonet_node.h — the ROS 2 node of this repo's host mirror.
+//
+// Public contract kept identical to the reference node so that launch files and downstream nodes need no
+// change (reference: stereonet_infer/include/stereonet_node.h:61-71 for the class surface, :97,:106,:120-121
+// for the parameter defaults):
+//   class hobot::stereonet::StereonetNode : public hobot::dnn_node::DnnNode
+//   StereonetNode(node_name = "stereonet_node", options)
+//   overrides SetNodePara() / PostProcess(output)
+//   parameters config_file, model_file, sub_hbmem_topic_name, ros_img_topic_name
+// Everything private is this implementation's own: settings are grouped in one struct, per-frame scratch is
+// reused across frames, and the inference behind DnnNode::Run is libstereonet_hip.so.
 #pragma once
+
+#include <cstdint>
 #include <memory>
 #include <string>
 #include <vector>
 
-#include "ai_msgs/msg/perception_targets.hpp"
-#include "dnn_node/dnn_node.h"
-#include "hbm_img_msgs/msg/hbm_msg1080_p.hpp"
-#include "preprocess.h"
 #include "rclcpp/rclcpp.hpp"
 #include "sensor_msgs/msg/image.hpp"
+#include "ai_msgs/msg/perception_targets.hpp"
+#include "hbm_img_msgs/msg/hbm_msg1080_p.hpp"
+
+#include "dnn_node/dnn_node.h"
+#include "preprocess.h"
 
 namespace hobot {
 namespace stereonet {
 
-using hobot::dnn_node::DNNTensor;
-using hobot::dnn_node::DnnNodeOutput;
-using hobot::dnn_node::Model;
-
+// JPEG of the left eye that travels with a request from FeedImg to PostProcess.
 struct BinDataType {
-  char* data = nullptr;
-  int len = 0;
+  std::vector<uint8_t> jpeg;
   int w = 1280;
   int h = 720;
-  std::vector<uint8_t> jpeg;
 };
 
+// Per-request context handed through DnnNode::Run.
 struct StereonetNodeOutput : public hobot::dnn_node::DnnNodeOutput {
-  float ratio = 1.0;
-  std::shared_ptr<BinDataType> sp_left_nv12 = nullptr;   // carries the JPEG of the left eye to PostProcess
+  std::shared_ptr<BinDataType> sp_left_nv12;
   int preprocess_time_ms = 0;
 };
 
@@ -40,31 +45,38 @@ class StereonetNode : public hobot::dnn_node::DnnNode {
   StereonetNode(const std::string& node_name = "stereonet_node",
                 const rclcpp::NodeOptions& options = rclcpp::NodeOptions());
 
-  bool IsReady() const { return model_ != nullptr; }
+  // true once the model is loaded and the subscription exists (the harness checks it; the reference shuts
+  // rclcpp down instead, which this node does as well)
+  bool IsReady() const { return ready_; }
 
  protected:
   int SetNodePara() override;
   int PostProcess(const std::shared_ptr<hobot::dnn_node::DnnNodeOutput>& node_output) override;
 
  private:
-  void FeedImg(const hbm_img_msgs::msg::HbmMsg1080P::ConstSharedPtr msg);
+  struct Settings {
+    std::string config_file = "config/hobot_stereonet_config.json";   // declared, never opened (as in the reference)
+    std::string model_file = "config/hobot_stereonet.hbm";
+    std::string image_topic = "hbmem_stereo_img";
+    std::string output_topic = "/stereonet_node_output";
+    bool publish_output = true;
+    int jpeg_quality = 95;
+  };
 
-  Model* model_ = nullptr;
-  int model_input_width_ = -1;
-  int model_input_height_ = -1;
-  std::vector<hbDNNTensorProperties> input_model_info_;
-  std::vector<hbDNNTensorProperties> output_model_info_;
+  void DeclareAndReadParameters();
+  void LogModelIo();
+  void OnStereoFrame(const hbm_img_msgs::msg::HbmMsg1080P::ConstSharedPtr frame);   // the FeedImg role
 
-  rclcpp::Subscription<hbm_img_msgs::msg::HbmMsg1080P>::ConstSharedPtr subscription_hbmem_img_ = nullptr;
-  std::string sub_hbmem_topic_name_ = "hbmem_stereo_img";
-  rclcpp::Publisher<ai_msgs::msg::PerceptionTargets>::SharedPtr msg_publisher_ = nullptr;
-  rclcpp::Publisher<sensor_msgs::msg::Image>::SharedPtr ros_img_publisher_ = nullptr;
-  std::string ros_img_topic_name_ = "/stereonet_node_output";
-  bool enable_pub_output_ = true;
+  Settings cfg_;
+  bool ready_ = false;
+  int net_w_ = -1, net_h_ = -1;
+  hobot::dnn_node::Model* net_ = nullptr;
+  std::unique_ptr<PreProcess> pre_;
+  std::vector<unsigned char> eye_l_, eye_r_;     // split NV12 eyes, reused across frames
 
-  std::string config_file_ = "config/hobot_stereonet_config.json";
-  std::string model_file_ = "config/hobot_stereonet.hbm";
-  std::shared_ptr<PreProcess> sp_preprocess_ = nullptr;
+  rclcpp::Subscription<hbm_img_msgs::msg::HbmMsg1080P>::ConstSharedPtr frames_in_;
+  rclcpp::Publisher<sensor_msgs::msg::Image>::SharedPtr disparity_out_;
+  rclcpp::Publisher<ai_msgs::msg::PerceptionTargets>::SharedPtr targets_out_;   // created for parity, never used
 };
 
 }  // namespace stereonet

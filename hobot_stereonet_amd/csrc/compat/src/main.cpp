@@ -1,9 +1,21 @@
-// main.cpp — same entry point as stereonet_infer/src/main.cpp:17-22.
+// Entry point of the `hobot_stereonet` executable (same role as stereonet_infer/src/main.cpp): bring ROS up,
+// run one StereonetNode until shutdown.  A node that failed to initialise has already requested shutdown, so
+// spin() returns at once and the process exits non-zero.
+#include <cstdio>
+
 #include "stereonet_node.h"
 
 int main(int argc, char** argv) {
   rclcpp::init(argc, argv);
-  rclcpp::spin(std::make_shared<hobot::stereonet::StereonetNode>());
+  int rc = 0;
+  {
+    auto node = std::make_shared<hobot::stereonet::StereonetNode>();
+    if (!node->IsReady()) {
+      fprintf(stderr, "hobot_stereonet: node did not initialise (model file / GPU), exiting\n");
+      rc = 1;
+    }
+    rclcpp::spin(node);
+  }
   rclcpp::shutdown();
-  return 0;
+  return rc;
 }

@@ -1,9 +1,10 @@
-// stereonet_node.cpp — behaviour of the reference node's live path, re-implemented:
-//   constructor / parameters / Init      stereonet_infer/src/stereonet_node.cpp:24-127
-//   SetNodePara                          :129-147
-//   FeedImg                              :657-818
-//   PostProcess                          :980-1089
-// The reference's disabled offline feeders and dump helpers (:149-655, :820-976) are out of scope.
+// stereonet_node.cpp — live path of the stereo node, implemented over the dnn_node compat layer.
+// Behavioural reference (what must stay observable from outside): stereonet_infer/src/stereonet_node.cpp
+//   :24-127  parameters, Init, subscription + publishers      -> StereonetNode(), DeclareAndReadParameters()
+//   :129-147 SetNodePara (model file must exist, task_num 4)  -> SetNodePara()
+//   :657-818 FeedImg (validate, split eyes, tensor, JPEG, async Run) -> OnStereoFrame()
+//   :980-1089 PostProcess (payload = raw tensor || JPEG, fps log)    -> PostProcess()
+// The reference's disabled offline feeders and dump helpers (:149-655, :820-976) are not reproduced.
 #include "stereonet_node.h"
 
 #include <unistd.h>
@@ -16,170 +17,181 @@
 namespace hobot {
 namespace stereonet {
 
+namespace {
+const rclcpp::Logger kLog = rclcpp::get_logger("stereonet_node");
+
+int elapsed_ms(std::chrono::steady_clock::time_point since) {
+  return (int)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - since).count();
+}
+}  // namespace
+
 StereonetNode::StereonetNode(const std::string& node_name, const rclcpp::NodeOptions& options)
     : hobot::dnn_node::DnnNode(node_name, options) {
-  this->declare_parameter<std::string>("config_file", config_file_);
-  this->declare_parameter<std::string>("model_file", model_file_);
-  this->declare_parameter<std::string>("sub_hbmem_topic_name", sub_hbmem_topic_name_);
-  this->declare_parameter<std::string>("ros_img_topic_name", ros_img_topic_name_);
-  this->get_parameter<std::string>("config_file", config_file_);
-  this->get_parameter<std::string>("model_file", model_file_);
-  this->get_parameter<std::string>("sub_hbmem_topic_name", sub_hbmem_topic_name_);
-  this->get_parameter<std::string>("ros_img_topic_name", ros_img_topic_name_);
+  DeclareAndReadParameters();
 
-  RCLCPP_WARN_STREAM(rclcpp::get_logger("stereonet_node"),
-                     "\n config_file: " << config_file_ << "\n model_file: " << model_file_
-                                        << "\n sub_hbmem_topic_name: " << sub_hbmem_topic_name_
-                                        << "\n ros_img_topic_name: " << ros_img_topic_name_);
-
-  if (Init() != 0 || GetModelInputSize(0, model_input_width_, model_input_height_) < 0) {
-    RCLCPP_ERROR(rclcpp::get_logger("stereonet_node"), "Node init fail!");
+  // Init() calls SetNodePara() and loads the model; any failure ends the process the way the reference does
+  if (Init() != 0 || GetModelInputSize(0, net_w_, net_h_) < 0) {
+    RCLCPP_ERROR(kLog, "Node init fail!");
     rclcpp::shutdown();
     return;
   }
-  model_ = GetModel();
-  if (!model_) {
-    RCLCPP_ERROR(rclcpp::get_logger(""), "Invalid model");
+  net_ = GetModel();
+  if (net_ == nullptr) {
+    RCLCPP_ERROR(kLog, "Invalid model");
     rclcpp::shutdown();
     return;
   }
-  RCLCPP_WARN_STREAM(rclcpp::get_logger("stereonet_node"),
-                     "model_input_count: " << model_->GetInputCount() << ", model_input_width: " << model_input_width_
-                                           << ", model_input_height: " << model_input_height_);
-  hbDNNHandle_t handle = model_->GetDNNHandle();
-  input_model_info_.resize(model_->GetInputCount());
-  for (int i = 0; i < model_->GetInputCount(); ++i) {
-    hbDNNGetInputTensorProperties(&input_model_info_[i], handle, i);
-    RCLCPP_INFO_STREAM(rclcpp::get_logger(""), "input_idx: " << i << ", tensorType = " << input_model_info_[i].tensorType
-                                                             << ", tensorLayout = " << input_model_info_[i].tensorLayout);
-  }
-  output_model_info_.resize(model_->GetOutputCount());
-  for (int i = 0; i < model_->GetOutputCount(); ++i) {
-    hbDNNGetOutputTensorProperties(&output_model_info_[i], handle, i);
-    RCLCPP_WARN_STREAM(rclcpp::get_logger(""), "output_idx: " << i << ", tensorType = " << output_model_info_[i].tensorType
-                                                              << ", tensorLayout = " << output_model_info_[i].tensorLayout);
-  }
+  LogModelIo();
 
-  sp_preprocess_ = std::make_shared<PreProcess>("");
-  subscription_hbmem_img_ = this->create_subscription<hbm_img_msgs::msg::HbmMsg1080P>(
-      sub_hbmem_topic_name_, 10, std::bind(&StereonetNode::FeedImg, this, std::placeholders::_1));
-  msg_publisher_ = this->create_publisher<ai_msgs::msg::PerceptionTargets>("/Stereonet_node_sample", 10);
-  ros_img_publisher_ = this->create_publisher<sensor_msgs::msg::Image>(ros_img_topic_name_, 10);
+  pre_.reset(new PreProcess(""));
+  frames_in_ = create_subscription<hbm_img_msgs::msg::HbmMsg1080P>(
+      cfg_.image_topic, 10, [this](hbm_img_msgs::msg::HbmMsg1080P::ConstSharedPtr m) { OnStereoFrame(m); });
+  targets_out_ = create_publisher<ai_msgs::msg::PerceptionTargets>("/Stereonet_node_sample", 10);
+  disparity_out_ = create_publisher<sensor_msgs::msg::Image>(cfg_.output_topic, 10);
+  ready_ = true;
+}
+
+void StereonetNode::DeclareAndReadParameters() {
+  struct Item {
+    const char* name;
+    std::string* value;
+  };
+  const Item items[] = {{"config_file", &cfg_.config_file},
+                        {"model_file", &cfg_.model_file},
+                        {"sub_hbmem_topic_name", &cfg_.image_topic},
+                        {"ros_img_topic_name", &cfg_.output_topic}};
+  for (const Item& it : items) {
+    declare_parameter<std::string>(it.name, *it.value);
+    get_parameter<std::string>(it.name, *it.value);
+  }
+  RCLCPP_WARN_STREAM(kLog, "\n config_file: " << cfg_.config_file << "\n model_file: " << cfg_.model_file
+                                              << "\n sub_hbmem_topic_name: " << cfg_.image_topic
+                                              << "\n ros_img_topic_name: " << cfg_.output_topic);
+}
+
+void StereonetNode::LogModelIo() {
+  RCLCPP_WARN_STREAM(kLog, "model_input_count: " << net_->GetInputCount() << ", model_input_width: " << net_w_
+                                                 << ", model_input_height: " << net_h_);
+  hbDNNTensorProperties p;
+  for (int i = 0; i < net_->GetInputCount(); ++i)
+    if (hbDNNGetInputTensorProperties(&p, net_->GetDNNHandle(), i) == 0)
+      RCLCPP_INFO_STREAM(kLog, "input_idx: " << i << ", tensorType = " << p.tensorType << ", tensorLayout = "
+                                             << p.tensorLayout << ", shape " << p.validShape.dimensionSize[0] << "x"
+                                             << p.validShape.dimensionSize[1] << "x" << p.validShape.dimensionSize[2]
+                                             << "x" << p.validShape.dimensionSize[3]);
+  for (int i = 0; i < net_->GetOutputCount(); ++i)
+    if (hbDNNGetOutputTensorProperties(&p, net_->GetDNNHandle(), i) == 0)
+      RCLCPP_WARN_STREAM(kLog, "output_idx: " << i << ", tensorType = " << p.tensorType
+                                              << ", tensorLayout = " << p.tensorLayout);
 }
 
 int StereonetNode::SetNodePara() {
   if (!dnn_node_para_ptr_) return -1;
-  if (access(model_file_.c_str(), F_OK) != 0) {
-    RCLCPP_ERROR_STREAM(rclcpp::get_logger("hobot_stereonet"), "File is not exist! model_file: " << model_file_);
+  if (access(cfg_.model_file.c_str(), F_OK) != 0) {
+    RCLCPP_ERROR_STREAM(rclcpp::get_logger("hobot_stereonet"), "File is not exist! model_file: " << cfg_.model_file);
     return -1;
   }
-  dnn_node_para_ptr_->model_file = model_file_;
+  dnn_node_para_ptr_->model_file = cfg_.model_file;
   dnn_node_para_ptr_->model_task_type = hobot::dnn_node::ModelTaskType::ModelInferType;
-  dnn_node_para_ptr_->task_num = 4;
+  dnn_node_para_ptr_->task_num = 4;   // requests in flight
   return 0;
 }
 
-void StereonetNode::FeedImg(const hbm_img_msgs::msg::HbmMsg1080P::ConstSharedPtr img_msg) {
-  if (!rclcpp::ok() || !img_msg) return;
-  // 1. only NV12 is handled
-  if ("nv12" != std::string(reinterpret_cast<const char*>(img_msg->encoding.data()))) {
-    RCLCPP_ERROR(rclcpp::get_logger("stereonet_node"), "Only support nv12 img encoding!");
+void StereonetNode::OnStereoFrame(const hbm_img_msgs::msg::HbmMsg1080P::ConstSharedPtr frame) {
+  if (!rclcpp::ok() || !frame) return;
+
+  // accept only NV12 frames that hold both eyes side by side at the model's resolution
+  const char* enc = reinterpret_cast<const char*>(frame->encoding.data());
+  if (strncmp(enc, "nv12", frame->encoding.size()) != 0) {
+    RCLCPP_ERROR(kLog, "Only support nv12 img encoding!");
     return;
   }
-  // side-by-side frame: width = 2 * model width, height = model height
-  if (img_msg->height != static_cast<uint32_t>(model_input_height_) ||
-      img_msg->width != static_cast<uint32_t>(model_input_width_) * 2) {
-    RCLCPP_ERROR_STREAM(rclcpp::get_logger("stereonet_node"),
-                        "recved img msg h: " << img_msg->height << ", w: " << img_msg->width
-                                             << " is unmatch with model_input_width: " << model_input_width_
-                                             << ", model_input_height: " << model_input_height_);
+  if ((int)frame->height != net_h_ || (int)frame->width != 2 * net_w_) {
+    RCLCPP_ERROR_STREAM(kLog, "recved img msg h: " << frame->height << ", w: " << frame->width
+                                                   << " is unmatch with model_input_width: " << net_w_
+                                                   << ", model_input_height: " << net_h_);
     return;
   }
-  const int w = img_msg->width / 2, h = img_msg->height, pitch = img_msg->width;
-  if (img_msg->data.size() < (size_t)pitch * h * 3 / 2) return;
+  const int w = net_w_, h = net_h_, pitch = 2 * w, rows = h + h / 2;
+  if (frame->data.size() < (size_t)pitch * rows) return;
 
-  // 2. output holder: header carries the frame index and the camera time stamp
-  auto dnn_output = std::make_shared<StereonetNodeOutput>();
-  dnn_output->msg_header = std::make_shared<std_msgs::msg::Header>();
-  dnn_output->msg_header->set__frame_id(std::to_string(img_msg->index));
-  dnn_output->msg_header->set__stamp(img_msg->time_stamp);
+  auto request = std::make_shared<StereonetNodeOutput>();
+  request->msg_header = std::make_shared<std_msgs::msg::Header>();
+  request->msg_header->frame_id = std::to_string(frame->index);
+  request->msg_header->stamp = frame->time_stamp;
 
-  // 3. pre-processing: split the eyes (h luma rows then h/2 chroma rows each), build the model input
-  const auto tp_start = std::chrono::system_clock::now();
-  const size_t eye = (size_t)w * h * 3 / 2;
-  std::vector<unsigned char> left(eye), right(eye);
-  const unsigned char* src = img_msg->data.data();
-  for (int r = 0; r < h + h / 2; ++r) {
-    memcpy(&left[(size_t)r * w], src + (size_t)r * pitch, w);
-    memcpy(&right[(size_t)r * w], src + (size_t)r * pitch + w, w);
+  const auto t_pre = std::chrono::steady_clock::now();
+  // de-interleave the eyes: every source row carries w bytes of the left eye, then w bytes of the right eye
+  eye_l_.resize((size_t)w * rows);
+  eye_r_.resize((size_t)w * rows);
+  const unsigned char* row = frame->data.data();
+  for (int r = 0; r < rows; ++r, row += pitch) {
+    memcpy(eye_l_.data() + (size_t)r * w, row, w);
+    memcpy(eye_r_.data() + (size_t)r * w, row + w, w);
   }
-  std::vector<std::shared_ptr<DNNTensor>> input_tensors;
-  if (sp_preprocess_->CvtNV12Data2Tensors(input_tensors, model_, left.data(), right.data()) < 0) {
-    RCLCPP_ERROR(rclcpp::get_logger("stereonet_node"), "Preprocess fail");
+  std::vector<std::shared_ptr<DNNTensor>> tensors;
+  if (pre_->CvtNV12Data2Tensors(tensors, net_, eye_l_.data(), eye_r_.data()) < 0) {
+    RCLCPP_ERROR(kLog, "Preprocess fail");
     rclcpp::shutdown();
     return;
   }
-  if (enable_pub_output_) {   // JPEG of the left eye rides along with the model output
-    auto bin = std::make_shared<BinDataType>();
-    bin->w = w;
-    bin->h = h;
-    if (!EncodeNv12ToJpeg(left.data(), w, h, w, 95, bin->jpeg)) {
-      RCLCPP_ERROR(rclcpp::get_logger("stereonet_node"), "invalid sp_left_nv12");
+  if (cfg_.publish_output) {
+    auto left = std::make_shared<BinDataType>();
+    left->w = w;
+    left->h = h;
+    if (!EncodeNv12ToJpeg(eye_l_.data(), w, h, w, cfg_.jpeg_quality, left->jpeg)) {
+      RCLCPP_ERROR(kLog, "invalid sp_left_nv12");
       rclcpp::shutdown();
       return;
     }
-    dnn_output->sp_left_nv12 = bin;
+    request->sp_left_nv12 = left;
   }
-  const auto interval =
-      std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now() - tp_start).count();
-  RCLCPP_INFO(rclcpp::get_logger("stereonet_node"), "Preprocess done, time cost %d ms", (int)interval);
-  dnn_output->preprocess_time_ms = (int)interval;
+  request->preprocess_time_ms = elapsed_ms(t_pre);
+  RCLCPP_INFO(kLog, "Preprocess done, time cost %d ms", request->preprocess_time_ms);
 
-  if (Run(input_tensors, dnn_output, false, -1, -1) < 0) {
-    RCLCPP_ERROR(rclcpp::get_logger("stereonet_node"), "Run infer fail!");
+  if (Run(tensors, request, /*is_sync_mode=*/false, -1, -1) < 0) {
+    RCLCPP_ERROR(kLog, "Run infer fail!");
     return;
   }
-  RCLCPP_INFO(rclcpp::get_logger("stereonet_node"), "Run infer done");
+  RCLCPP_INFO(kLog, "Run infer done");
 }
 
 int StereonetNode::PostProcess(const std::shared_ptr<hobot::dnn_node::DnnNodeOutput>& node_output) {
   if (!rclcpp::ok()) return 0;
-  const auto tp_start = std::chrono::system_clock::now();
-  auto out = std::dynamic_pointer_cast<StereonetNodeOutput>(node_output);
-  if (!out) {
-    RCLCPP_ERROR(rclcpp::get_logger("stereonet_node"), "Cast dnn node output fail!");
+  auto request = std::dynamic_pointer_cast<StereonetNodeOutput>(node_output);
+  if (!request) {
+    RCLCPP_ERROR(kLog, "Cast dnn node output fail!");
     return -1;
   }
-  int interval = 0;
-  if (enable_pub_output_ && out->sp_left_nv12 && !out->output_tensors.empty()) {
-    // wire format: sensor_msgs/Image, encoding "jpeg", data = raw int32 tensor bytes || JPEG(left), step = len
+  const auto t_pub = std::chrono::steady_clock::now();
+  int pack_ms = 0;
+  if (cfg_.publish_output && request->sp_left_nv12 && !request->output_tensors.empty()) {
+    // wire format consumed by the render node: sensor_msgs/Image, encoding "jpeg",
+    // data = the raw int32 output tensor followed by the JPEG of the left eye, step = total length
+    const hbSysMem& out = request->output_tensors[0]->sysMem[0];
+    const std::vector<uint8_t>& jpeg = request->sp_left_nv12->jpeg;
     sensor_msgs::msg::Image msg;
-    msg.height = out->sp_left_nv12->h;
-    msg.width = out->sp_left_nv12->w;
+    msg.header = *request->msg_header;
+    msg.width = request->sp_left_nv12->w;
+    msg.height = request->sp_left_nv12->h;
     msg.encoding = "jpeg";
-    msg.header = *out->msg_header;
-    const char* infer = reinterpret_cast<const char*>(out->output_tensors[0]->sysMem[0].virAddr);
-    const size_t infer_len = out->output_tensors[0]->sysMem[0].memSize;
-    const auto& jpeg = out->sp_left_nv12->jpeg;
-    msg.step = (uint32_t)(infer_len + jpeg.size());
-    msg.data.resize(infer_len + jpeg.size());
-    memcpy(msg.data.data(), infer, infer_len);
-    memcpy(msg.data.data() + infer_len, jpeg.data(), jpeg.size());
-    interval = (int)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now() - tp_start)
-                   .count();
-    RCLCPP_INFO(rclcpp::get_logger("stereonet_node"), "publish output with msg index: %s, topic: %s, time cost ms: %d",
-                out->msg_header->frame_id.data(), ros_img_topic_name_.data(), interval);
-    ros_img_publisher_->publish(std::move(msg));
+    msg.data.resize(out.memSize + jpeg.size());
+    msg.step = (uint32_t)msg.data.size();
+    memcpy(msg.data.data(), out.virAddr, out.memSize);
+    memcpy(msg.data.data() + out.memSize, jpeg.data(), jpeg.size());
+    pack_ms = elapsed_ms(t_pub);
+    RCLCPP_INFO(kLog, "publish output with msg index: %s, topic: %s, time cost ms: %d",
+                request->msg_header->frame_id.c_str(), cfg_.output_topic.c_str(), pack_ms);
+    disparity_out_->publish(std::move(msg));
   } else {
-    RCLCPP_INFO(rclcpp::get_logger("stereonet_node"), "publish is unable");
+    RCLCPP_INFO(kLog, "publish is unable");
   }
-  if (node_output->rt_stat && node_output->rt_stat->fps_updated) {
-    RCLCPP_WARN(rclcpp::get_logger("stereonet_node"),
+  const auto& st = node_output->rt_stat;
+  if (st && st->fps_updated)
+    RCLCPP_WARN(kLog,
                 "input fps: %.2f, out fps: %.2f, preprocess time ms: %d, infer time ms: %d, msg preparation for pub "
                 "time cost ms: %d",
-                node_output->rt_stat->input_fps, node_output->rt_stat->output_fps, out->preprocess_time_ms,
-                node_output->rt_stat->infer_time_ms, interval);
-  }
+                st->input_fps, st->output_fps, request->preprocess_time_ms, st->infer_time_ms, pack_ms);
   return 0;
 }
 
