@@ -14,6 +14,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/stereonet_hip.h"
@@ -80,6 +81,10 @@ struct Slot {                // async request slot (sn_submit / sn_wait)
   int32_t* user_raw = nullptr;
   float* user_disp = nullptr;
   uint64_t ticket = 0;       // 0 = free
+  // hipGraph of {H2D, forward, D2H} per output mask (1 = int32, 2 = float, 3 = both): the second request with a
+  // given mask is captured, later ones replay it (the ~45 launches of a single-pair forward are launch-bound)
+  hipGraphExec_t gexec[4] = {nullptr, nullptr, nullptr, nullptr};
+  int uses[4] = {0, 0, 0, 0};
 };
 
 }  // namespace
@@ -92,6 +97,7 @@ struct sn_handle {
   hipStream_t s_low = nullptr, s_ref = nullptr;     // low-res branch / refinement tower (piece pipeline)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_piece[kMaxPieceEvents] = {};
   bool overlap = true;
+  bool use_graphs = true;    // hipGraph replay for the async single-pair path (SN_NO_GRAPH disables)
   ConvLayer down[kNDown], fres[kNFeatRes][2], fout, agg[kNAgg], rin, rres[kNRefRes][2];
   HeadLayer aout, rout;
   RefLayerF16 rres16[kNRefRes][2];
@@ -255,6 +261,24 @@ int upload_head(sn_handle* h, const HostLayer& l, HeadLayer* out) {   // [1][32]
   return SN_OK;
 }
 
+// Raise a kernel's dynamic-LDS limit once per (kernel, device) — not per launch: launches may happen inside a
+// stream capture.  Keyed by the kernel's address (different instantiations can share one function type).
+template <class K>
+hipError_t ensure_lds_attr(K kern, int bytes) {
+  static std::mutex mu;
+  static std::unordered_map<const void*, unsigned long long> done;     // kernel -> bitmask of device ordinals
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  const unsigned long long bit = 1ull << (dev & 63);
+  const void* key = reinterpret_cast<const void*>(kern);
+  std::lock_guard<std::mutex> lk(mu);
+  unsigned long long& m = done[key];
+  if (m & bit) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) m |= bit;
+  return e;
+}
+
 // ---- convolution launcher ------------------------------------------------------------------------
 template <int KS, int STRIDE, int DIL, int CH, int TR, int TC, class Loader, int OUTF = 0, bool PF = true, int MINW = 1>
 hipError_t launch_conv(hipStream_t st, const ConvLayer& L, const Loader& ld, int nimg, int Ho, int Wo,
@@ -284,8 +308,7 @@ hipError_t launch_conv(hipStream_t st, const ConvLayer& L, const Loader& ld, int
   const size_t lds = ((size_t)CH * KS * KS * 32 + (size_t)CH * rows_in * pitch) * sizeof(float);
   auto kern = k_conv_c32_mfma<KS, STRIDE, DIL, CH, TR, TC, Loader, OUTF, PF, MINW>;
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = ensure_lds_attr(kern, (int)lds);
     if (e != hipSuccess) return e;
   }
   const int nwg = a.tiles_x * a.tiles_y * nimg;
@@ -384,8 +407,7 @@ hipError_t launch_ref_f16x3(hipStream_t st, const RefLayerF16& L, const RefGeom&
   using T = RefTile2<DIL, TW>;
   constexpr int lds_bytes = NBUF * 2 * T::BUF * 16;
   auto kern = res ? k_ref_conv_f16x3<DIL, TW, NBUF, true> : k_ref_conv_f16x3<DIL, TW, NBUF, false>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     lds_bytes);
+  hipError_t e = ensure_lds_attr(kern, lds_bytes);
   if (e != hipSuccess) return e;
   RefGeom gt = g;
   gt.tiles_x = (g.W + TW - 1) / TW;
@@ -418,8 +440,7 @@ hipError_t launch_ref_f16(hipStream_t st, const RefLayerF16& L, const RefGeom& g
   auto kern = k_ref_conv_f16<DIL>;
   static bool attr_done = false;
   if (!attr_done && T::LDS_BYTES > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
+    hipError_t e = ensure_lds_attr(kern, T::LDS_BYTES);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
@@ -439,8 +460,7 @@ hipError_t launch_ref_f16_v2(hipStream_t st, const RefLayerF16& L, const RefGeom
   using T = RefTile2<DIL, TW>;
   auto kern = res ? k_ref_conv_f16_v2<DIL, TW, true> : k_ref_conv_f16_v2<DIL, TW, false>;
   if (T::LDS_BYTES > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
+    hipError_t e = ensure_lds_attr(kern, T::LDS_BYTES);
     if (e != hipSuccess) return e;
   }
   RefGeom gt = g;                      // tile grid of this variant (the buffer geometry is for 8x64 tiles)
@@ -469,8 +489,7 @@ hipError_t launch_ref_block_f16(hipStream_t st, const RefLayerF16& L1, const Ref
                                 int num_cu, const uint4* x, uint4* y, int nimg) {
   using T = FusedTile<DIL>;
   auto kern = k_ref_block_f16<DIL>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     T::LDS_BYTES);
+  hipError_t e = ensure_lds_attr(kern, T::LDS_BYTES);
   if (e != hipSuccess) return e;
   RefGeom gt = g;
   gt.tiles_x = (g.W + T::TWO - 1) / T::TWO;
@@ -490,8 +509,7 @@ hipError_t launch_ref_block_f16_ws(hipStream_t st, const RefLayerF16& L1, const 
                                    int num_cu, const uint4* x, uint4* y, int nimg) {
   using T = FusedWsTile<DIL>;
   auto kern = k_ref_block_f16_ws<DIL>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     T::LDS_BYTES);
+  hipError_t e = ensure_lds_attr(kern, T::LDS_BYTES);
   if (e != hipSuccess) return e;
   RefGeom gt = g;
   gt.tiles_x = (g.W + T::TWO - 1) / T::TWO;
@@ -906,6 +924,7 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
   for (auto& e : h->ev_piece)
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(SN_ERR_DEVICE);
   h->overlap = getenv("SN_NO_OVERLAP") == nullptr;
+  h->use_graphs = getenv("SN_NO_GRAPH") == nullptr;
 
   BlobWalker bw{blob.data()};
   const bool low_x3 = h->precision != SN_PREC_FP32 && getenv("SN_LOW_FP32") == nullptr;
@@ -988,6 +1007,8 @@ int sn_destroy(sn_handle* h) {
     if (s.pin_in) hipHostFree(s.pin_in);
     if (s.pin_raw) hipHostFree(s.pin_raw);
     if (s.pin_disp) hipHostFree(s.pin_disp);
+    for (auto& g : s.gexec)
+      if (g) hipGraphExecDestroy(g);
     if (s.ev0) hipEventDestroy(s.ev0);
     if (s.ev1) hipEventDestroy(s.ev1);
     if (s.stream) hipStreamDestroy(s.stream);
@@ -1190,19 +1211,46 @@ int sn_submit(sn_handle* h, const int8_t* in, int32_t* out_i32, float* out_disp,
   s->user_disp = out_disp;
   *ticket = s->ticket;
   memcpy(s->pin_in, in, 6 * HW);   // the caller may release its tensor as soon as we return
-  HIP_TRY(h, hipEventRecord(s->ev0, s->stream));
-  HIP_TRY(h, hipMemcpyAsync(s->ws.in6, s->pin_in, 6 * HW, hipMemcpyHostToDevice, s->stream));
-  const bool prof = h->profiling;
-  h->profiling = false;   // stage events belong to the synchronous path
-  rc = forward(h, s->ws, s->stream, 1, s->ws.in6, out_disp ? s->ws.out_disp : nullptr,
-               out_i32 ? s->ws.out_raw : nullptr, false);
-  h->profiling = prof;
-  if (rc) {
-    s->ticket = 0;
-    return rc;
+  const int mask = (out_i32 ? 1 : 0) | (out_disp ? 2 : 0);
+  auto enqueue = [&]() -> int {
+    HIP_TRY(h, hipMemcpyAsync(s->ws.in6, s->pin_in, 6 * HW, hipMemcpyHostToDevice, s->stream));
+    const bool prof = h->profiling;
+    h->profiling = false;   // stage events belong to the synchronous path
+    const int r = forward(h, s->ws, s->stream, 1, s->ws.in6, out_disp ? s->ws.out_disp : nullptr,
+                          out_i32 ? s->ws.out_raw : nullptr, false);
+    h->profiling = prof;
+    if (r) return r;
+    if (out_i32) HIP_TRY(h, hipMemcpyAsync(s->pin_raw, s->ws.out_raw, 4 * HW, hipMemcpyDeviceToHost, s->stream));
+    if (out_disp) HIP_TRY(h, hipMemcpyAsync(s->pin_disp, s->ws.out_disp, 4 * HW, hipMemcpyDeviceToHost, s->stream));
+    return SN_OK;
+  };
+  if (h->use_graphs && !s->gexec[mask] && s->uses[mask] >= 1) {
+    // capture on the second use (the first, un-captured run has done every one-time initialisation)
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+      const int r = enqueue();
+      const hipError_t e = hipStreamEndCapture(s->stream, &graph);
+      if (r == SN_OK && e == hipSuccess && graph &&
+          hipGraphInstantiate(&s->gexec[mask], graph, nullptr, nullptr, 0) != hipSuccess)
+        s->gexec[mask] = nullptr;
+      if (graph) hipGraphDestroy(graph);
+    }
+    if (!s->gexec[mask]) {
+      (void)hipGetLastError();
+      h->use_graphs = false;          // capture unsupported here: keep issuing plain launches (same kernels)
+    }
   }
-  if (out_i32) HIP_TRY(h, hipMemcpyAsync(s->pin_raw, s->ws.out_raw, 4 * HW, hipMemcpyDeviceToHost, s->stream));
-  if (out_disp) HIP_TRY(h, hipMemcpyAsync(s->pin_disp, s->ws.out_disp, 4 * HW, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(h, hipEventRecord(s->ev0, s->stream));
+  if (s->gexec[mask]) {
+    HIP_TRY(h, hipGraphLaunch(s->gexec[mask], s->stream));
+  } else {
+    rc = enqueue();
+    if (rc) {
+      s->ticket = 0;
+      return rc;
+    }
+    ++s->uses[mask];
+  }
   HIP_TRY(h, hipEventRecord(s->ev1, s->stream));
   return SN_OK;
 }
