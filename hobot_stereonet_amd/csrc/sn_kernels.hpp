@@ -1618,7 +1618,7 @@ __global__ __launch_bounds__(256, 1) void k_ref_conv_f16x3(const uint4* __restri
   extern __shared__ __attribute__((aligned(16))) uint4 lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int j_ = lane & 31, gh_ = lane >> 5;
+  const int j = lane & 31, gh = lane >> 5;
 
   half8 wh[18], wl[18];
 #pragma unroll
@@ -1629,7 +1629,7 @@ __global__ __launch_bounds__(256, 1) void k_ref_conv_f16x3(const uint4* __restri
   }
   float bv[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) bv[r] = bias[(r & 3) + 8 * (r >> 2) + 4 * gh_];
+  for (int r = 0; r < 16; ++r) bv[r] = bias[(r & 3) + 8 * (r >> 2) + 4 * gh];
 #pragma unroll
   for (int i = 0; i < 18; ++i) {
     asm volatile("" : "+v"(wh[i]));
@@ -1648,6 +1648,32 @@ __global__ __launch_bounds__(256, 1) void k_ref_conv_f16x3(const uint4* __restri
   const int G = 2 * ntiles;
 
   const int seg0 = wave * T::SPW;
+  // addressing as in k_ref_conv_f16_v2: uniform 32-bit tile offset + fixed per-lane 32-bit offsets; the lo tensor
+  // sits lo_slots*16 bytes behind the hi tensor (folded into the uniform base pointers)
+  const unsigned plane_b = (unsigned)g.Hs * (unsigned)g.Ws * 16u;
+  unsigned dma_voff[T::KW];
+#pragma unroll
+  for (int k = 0; k < T::KW; ++k) {
+    int i = wave + 4 * k;
+    i = i < T::NINST ? i : T::NINST - 1;
+    int s = i * 64 + lane;
+    s = s < T::HALF ? s : T::HALF - 1;
+    const int pc = s / T::PLANE;
+    const int rem = s - pc * T::PLANE;
+    const int r = rem / T::COLS;
+    const int c = rem - r * T::COLS;
+    dma_voff[k] = (unsigned)pc * plane_b + ((unsigned)r * (unsigned)g.Ws + (unsigned)c) * 16u;
+  }
+  unsigned io_voff[T::SPW];
+#pragma unroll
+  for (int s = 0; s < T::SPW; ++s) {
+    const int seg = seg0 + s;
+    io_voff[s] = ((unsigned)(seg / T::CSEG) * (unsigned)g.Ws + (unsigned)((seg % T::CSEG) * 32 + j)) * 16u + gh * 8u;
+  }
+  const char* in_lo = reinterpret_cast<const char*>(in) + lo_slots * 16;
+  const char* res_lo = reinterpret_cast<const char*>(res) + lo_slots * 16;
+  char* out_lo = reinterpret_cast<char*>(out) + lo_slots * 16;
+
   auto tile_xy = [&](int ti, int& img, int& y0, int& x0) {
     const int t = t0 + ti * nlb;
     img = t / per_img;
@@ -1656,35 +1682,26 @@ __global__ __launch_bounds__(256, 1) void k_ref_conv_f16x3(const uint4* __restri
     y0 = ty * T::TH;
     x0 = (rem - ty * g.tiles_x) * T::TW;
   };
-  auto issue = [&](int gp) {                   // hi and lo half-tiles of phase gp -> ring entry gp % NBUF
-    int img, y0, x0;
-    tile_xy(gp >> 1, img, y0, x0);
-    const int kk = gp & 1;
-    int lq = lane;
-    asm volatile("" : "+v"(lq));
+  auto tile_base = [&](int img, int y, int x) -> unsigned {
+    return (((unsigned)img * 4u * (unsigned)g.Hs + (unsigned)(y + kRefPad)) * (unsigned)g.Ws + (unsigned)(x + kRefPad)) * 16u;
+  };
+  auto issue = [&](int gp, int img, int y0, int x0) {        // hi and lo half-tiles of phase gp -> ring entry gp % NBUF
+    const unsigned sb = tile_base(img, y0 - DIL, x0 - DIL) + 2u * (gp & 1) * plane_b;
 #pragma unroll
     for (int part = 0; part < 2; ++part) {
       uint4* dst = lds + (gp % NBUF) * RING + part * T::BUF;
-      const uint4* src = in + (size_t)part * lo_slots;
+      const char* src = (part ? in_lo : reinterpret_cast<const char*>(in)) + sb;
 #pragma unroll
       for (int k = 0; k < T::KW; ++k) {
         int i = wave + 4 * k;
         i = i < T::NINST ? i : T::NINST - 1;
-        int s = i * 64 + lq;
-        s = s < T::HALF ? s : T::HALF - 1;
-        const int pc = s / T::PLANE;
-        const int rem = s - pc * T::PLANE;
-        const int r = rem / T::COLS;
-        const int c = rem - r * T::COLS;
-        const size_t slot = (((size_t)img * 4 + (2 * kk + pc)) * g.Hs + (y0 + r - DIL + kRefPad)) * g.Ws +
-                            (x0 + c - DIL + kRefPad);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + slot),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + dma_voff[k]),
                                          (__attribute__((address_space(3))) void*)(dst + i * 64), 16, 0, 0);
       }
     }
   };
   // three MFMAs per (tap, segment): hi*hi -> acc0; hi*lo and lo*hi -> acc1
-  auto compute = [&](const uint4* ring, auto kkc, f32x16 (&a0)[T::SPW], f32x16 (&a1)[T::SPW], int j, int gh) {
+  auto compute = [&](const uint4* ring, auto kkc, f32x16 (&a0)[T::SPW], f32x16 (&a1)[T::SPW]) {
     constexpr int kk = decltype(kkc)::value;
     const uint4* bh = ring + gh * T::PLANE + (seg0 / T::CSEG) * T::COLS + j;
     const uint4* bl = bh + T::BUF;
@@ -1696,27 +1713,24 @@ __global__ __launch_bounds__(256, 1) void k_ref_conv_f16x3(const uint4* __restri
         const int off = ((s / T::CSEG) + ky * DIL) * T::COLS + (s % T::CSEG) * 32 + kx * DIL;
         const half8 xh = *reinterpret_cast<const half8*>(bh + off);
         const half8 xl = *reinterpret_cast<const half8*>(bl + off);
-        const half8 whi = wh[tap * 2 + kk];
-        const half8 wlo = wl[tap * 2 + kk];
-        a0[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, xh, a0[s], 0, 0, 0);
-        a1[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, xh, a1[s], 0, 0, 0);
-        a1[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, xl, a1[s], 0, 0, 0);
+        a0[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[tap * 2 + kk], xh, a0[s], 0, 0, 0);
+        a1[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[tap * 2 + kk], xh, a1[s], 0, 0, 0);
+        a1[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[tap * 2 + kk], xl, a1[s], 0, 0, 0);
       }
     }
   };
 
   wait_vmcnt<0>();
-#pragma unroll
-  for (int gp = 0; gp < NBUF - 1; ++gp)
-    if (gp < G) issue(gp);
+  int img, y0, x0, nimg_ = 0, ny0 = 0, nx0 = 0;
+  tile_xy(0, img, y0, x0);
+  // prologue: groups 0 .. NBUF-2 (group 1 belongs to tile 0 as well)
+  issue(0, img, y0, x0);
+  if (NBUF == 3) issue(1, img, y0, x0);
 
   f32x16 acc0[T::SPW], acc1[T::SPW];
   for (int ti = 0; ti < ntiles; ++ti) {
-    int img, y0, x0;
-    tile_xy(ti, img, y0, x0);
     const int g0 = 2 * ti;
-    int j = j_, gh = gh_;
-    asm volatile("" : "+v"(j), "+v"(gh));
+    if (ti + 1 < ntiles) tile_xy(ti + 1, nimg_, ny0, nx0);
     // ---- phase g0: ops younger than group g0 = groups g0+1 .. g0+NBUF-2 (+ the previous tile's stores) ----
     if (NBUF == 3) {
       if (ti == 0) wait_vmcnt<KW2>(); else wait_vmcnt<KW2 + NST>();     // group g0+1 always exists
@@ -1724,15 +1738,19 @@ __global__ __launch_bounds__(256, 1) void k_ref_conv_f16x3(const uint4* __restri
       if (ti == 0) wait_vmcnt<0>(); else wait_vmcnt<NST>();
     }
     block_barrier();
-    if (g0 + NBUF - 1 < G) issue(g0 + NBUF - 1);
+    if (NBUF == 3) {
+      if (g0 + 2 < G) issue(g0 + 2, nimg_, ny0, nx0);
+    } else {
+      issue(g0 + 1, img, y0, x0);
+    }
 #pragma unroll
     for (int s = 0; s < T::SPW; ++s)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        acc0[s][r] = 0.f;
+        acc0[s][r] = bv[r];
         acc1[s][r] = 0.f;
       }
-    compute(lds + (g0 % NBUF) * RING, std::integral_constant<int, 0>{}, acc0, acc1, j, gh);
+    compute(lds + (g0 % NBUF) * RING, std::integral_constant<int, 0>{}, acc0, acc1);
 
     // ---- phase g0+1 ----
     if (NBUF == 3) {
@@ -1741,60 +1759,74 @@ __global__ __launch_bounds__(256, 1) void k_ref_conv_f16x3(const uint4* __restri
       wait_vmcnt<0>();
     }
     block_barrier();
-    char* obase[T::SPW];
+    const unsigned tb = tile_base(img, y0, x0);
     uint2 rres[RES ? 2 * T::NSTORE : 1];
+    if (RES) {
 #pragma unroll
-    for (int s = 0; s < T::SPW; ++s) {
-      const int seg = seg0 + s;
-      const int y = y0 + seg / T::CSEG, x = x0 + (seg % T::CSEG) * 32 + j;
-      const size_t slot0 = ((size_t)img * 4 * g.Hs + (y + kRefPad)) * g.Ws + (x + kRefPad);
-      obase[s] = reinterpret_cast<char*>(out) + slot0 * 16 + gh * 8;
-      if (RES) {
+      for (int q = 0; q < 4; ++q) {
+        const char* rq = reinterpret_cast<const char*>(res) + (tb + (unsigned)q * plane_b);
+        const char* rql = res_lo + (tb + (unsigned)q * plane_b);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const char* rp = reinterpret_cast<const char*>(res) + (slot0 + (size_t)q * g.Hs * g.Ws) * 16 + gh * 8;
-          const char* rq = rp + lo_slots * 16;
+        for (int s = 0; s < T::SPW; ++s) {
+          const char* rp = rq + io_voff[s];
+          const char* rl = rql + io_voff[s];
           asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rres[RES ? 2 * (s * 4 + q) : 0]) : "v"(rp) : "memory");
-          asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rres[RES ? 2 * (s * 4 + q) + 1 : 0]) : "v"(rq) : "memory");
+          asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rres[RES ? 2 * (s * 4 + q) + 1 : 0]) : "v"(rl) : "memory");
         }
       }
     }
-    const bool more = g0 + 1 + NBUF - 1 < G;
-    if (more) issue(g0 + 1 + NBUF - 1);
-    compute(lds + ((g0 + 1) % NBUF) * RING, std::integral_constant<int, 1>{}, acc0, acc1, j, gh);
+    bool more;
+    if (NBUF == 3) {
+      more = g0 + 3 < G;
+      if (more) issue(g0 + 3, nimg_, ny0, nx0);
+    } else {
+      more = g0 + 2 < G;
+      if (more) issue(g0 + 2, nimg_, ny0, nx0);
+    }
+    compute(lds + ((g0 + 1) % NBUF) * RING, std::integral_constant<int, 1>{}, acc0, acc1);
     if (RES) {
       if (more) wait_vmcnt<KW2>(); else wait_vmcnt<0>();
 #pragma unroll
       for (int i = 0; i < 2 * T::NSTORE; ++i) asm volatile("" : "+v"(rres[i]));
     }
-    // ---- epilogue: v = acc0 + acc1 * 2^-11 + bias (+ residual), LeakyReLU, split, 2 * NSTORE stores ----
+    // ---- epilogue: v = acc0 + acc1 * 2^-11 (+ residual), LeakyReLU, split, 2 * NSTORE stores ----
+    const bool interior = y0 + T::TH <= g.H && x0 + T::TW <= g.W;
 #pragma unroll
-    for (int s = 0; s < T::SPW; ++s) {
-      const int seg = seg0 + s;
-      const int y = y0 + seg / T::CSEG, x = x0 + (seg % T::CSEG) * 32 + j;
-      const bool ok = y < g.H && x < g.W;
+    for (int q = 0; q < 4; ++q) {
+      char* oq = reinterpret_cast<char*>(out) + (tb + (unsigned)q * plane_b);
+      char* oql = out_lo + (tb + (unsigned)q * plane_b);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int s = 0; s < T::SPW; ++s) {
         half4 hh, hl;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float v = acc0[s][4 * q + e] + acc1[s][4 * q + e] * kSplitInv + bv[4 * q + e];
+          float v = acc0[s][4 * q + e] + acc1[s][4 * q + e] * kSplitInv;
           if (RES) {
             const uint2 rh = rres[RES ? 2 * (s * 4 + q) : 0], rl = rres[RES ? 2 * (s * 4 + q) + 1 : 0];
             const half4 vh = *reinterpret_cast<const half4*>(&rh);
             const half4 vl = *reinterpret_cast<const half4*>(&rl);
             v += (float)vh[e] + (float)vl[e] * kSplitInv;
           }
-          if (lrelu) v = fmaxf(v, v * kSlope);
+          if (lrelu) v = lrelu_fast(v);
           const _Float16 hi = (_Float16)v;
-          hh[e] = ok ? hi : (_Float16)0.f;
-          hl[e] = ok ? (_Float16)((v - (float)hi) * kSplitScale) : (_Float16)0.f;
+          hh[e] = hi;
+          hl[e] = (_Float16)((v - (float)hi) * kSplitScale);
         }
-        char* p0 = obase[s] + (size_t)q * g.Hs * g.Ws * 16;
-        *reinterpret_cast<half4*>(p0) = hh;
-        *reinterpret_cast<half4*>(p0 + lo_slots * 16) = hl;
+        if (!interior) {
+          const int seg = seg0 + s;
+          const int y = y0 + seg / T::CSEG, x = x0 + (seg % T::CSEG) * 32 + j;
+          if (!(y < g.H && x < g.W)) {
+            hh = half4{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+            hl = hh;
+          }
+        }
+        *reinterpret_cast<half4*>(oq + io_voff[s]) = hh;
+        *reinterpret_cast<half4*>(oql + io_voff[s]) = hl;
       }
     }
+    img = nimg_;
+    y0 = ny0;
+    x0 = nx0;
   }
 }
 
