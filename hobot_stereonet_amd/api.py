@@ -50,6 +50,14 @@ def load_library(path: Optional[str] = None):
     if _lib is not None:
         return _lib
     path = path or _build.LIB
+    # One HIP runtime per process: the PyTorch wheel bundles its own libamdhip64/libhsa-runtime64.  If this library
+    # came in first it would bind the system ROCm copies, torch would later add its own, and whichever runtime
+    # opened the device second would report "no ROCm-capable device".  Importing torch first makes both share
+    # torch's copy (same SONAME); without torch installed the system runtime is the only one.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(path) or (os.path.exists(_build.HIPCC) and _build.is_stale()):
         _build.build()
     lib = C.CDLL(path)
@@ -106,7 +114,8 @@ class StereoNetHIP:
         rc = self._lib.sn_create(model_file.encode(), C.byref(cfg), C.byref(self._h))
         if rc != 0:
             self._h = C.c_void_p()
-            raise StereoNetError(rc, f"sn_create({model_file!r})")
+            detail = self._lib.sn_last_error(None)
+            raise StereoNetError(rc, f"sn_create({model_file!r})", detail.decode() if detail else "")
         info = SnIoInfo()
         self._check(self._lib.sn_get_io_info(self._h, C.byref(info)), "sn_get_io_info")
         self.info = info

@@ -23,6 +23,12 @@ class Tools {
   // Y plane copied; the chroma 2x2-replicated while indexing `inbuf + w*h` as planar I420
   // ("U" = first w*h/4 bytes, "V" = next w*h/4 bytes) exactly as the reference does.
   static void YUV420TOYUV444(const unsigned char* inbuf, unsigned char* outbuf, int w, int h);
+
+  // Offline feeders only (reference: preprocess.h:56-96, cv::cvtColor(COLOR_BGR2YUV_I420) + UV interleave).
+  // 8-bit BGR (interleaved, top row first) -> NV12: BT.601 studio-range luma for every pixel, chroma taken
+  // from the top-left pixel of each 2x2 block (no averaging), 20-bit fixed point with round-half-up — the
+  // arithmetic OpenCV 4.x documents for its RGB->YUV420p path.  -1 when w or h is odd (as the reference).
+  static int32_t BGRToNv12(const unsigned char* bgr, int w, int h, std::vector<unsigned char>& nv12);
 };
 
 class PreProcess {

@@ -49,6 +49,13 @@ class StereonetNode : public hobot::dnn_node::DnnNode {
   // rclcpp down instead, which this node does as well)
   bool IsReady() const { return ready_; }
 
+  // Offline feeder (reference: stereonet_node.h:118, stereonet_node.cpp:820-976, disabled in its constructor):
+  // two text files with one image path per line; frame i = (left[i], right[i]) -> BGR -> NV12 -> model tensor,
+  // synchronous Run with frame_id = i, result published like a live frame.  Any unreadable list or image, a
+  // length mismatch, or an image that is not the model's size ends the run with rclcpp::shutdown(), as the
+  // reference does.  Returns the number of frames that went through PostProcess.
+  int RunImglistFeedInfer(std::string left_img_list, std::string right_img_list);
+
  protected:
   int SetNodePara() override;
   int PostProcess(const std::shared_ptr<hobot::dnn_node::DnnNodeOutput>& node_output) override;
@@ -61,6 +68,8 @@ class StereonetNode : public hobot::dnn_node::DnnNode {
     std::string output_topic = "/stereonet_node_output";
     bool publish_output = true;
     int jpeg_quality = 95;
+    int feed_start_pause_ms = 1000;   // the reference waits for the viewer before / between offline frames
+    int feed_frame_pause_ms = 300;    // (stereonet_node.cpp:890,974); STEREONET_FEED_PAUSE_MS overrides both
   };
 
   void DeclareAndReadParameters();

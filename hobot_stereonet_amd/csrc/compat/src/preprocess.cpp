@@ -26,6 +26,35 @@ void Tools::YUV420TOYUV444(const unsigned char* inbuf, unsigned char* outbuf, in
   }
 }
 
+int32_t Tools::BGRToNv12(const unsigned char* bgr, int w, int h, std::vector<unsigned char>& nv12) {
+  if (!bgr || w <= 0 || h <= 0 || (w & 1) || (h & 1)) {
+    RCLCPP_ERROR_STREAM(rclcpp::get_logger("hobot_stereonet"), "input img height and width must aligned by 2!");
+    return -1;
+  }
+  // BT.601 studio range in Q20 (round(2^20 * {0.257, 0.504, 0.098 | -0.148, -0.291, 0.439 | 0.439, -0.368, -0.071}))
+  constexpr int kQ = 20, kHalf = 1 << (kQ - 1);
+  constexpr int kYR = 269484, kYG = 528482, kYB = 102760;
+  constexpr int kUR = -155188, kUG = -305135, kUB = 460324;
+  constexpr int kVR = 460324, kVG = -385875, kVB = -74448;
+  auto clamp8 = [](int v) { return (unsigned char)(v < 0 ? 0 : v > 255 ? 255 : v); };
+  nv12.resize((size_t)w * h * 3 / 2);
+  unsigned char* yp = nv12.data();
+  unsigned char* cp = yp + (size_t)w * h;
+  for (int r = 0; r < h; ++r) {
+    const unsigned char* s = bgr + (size_t)r * w * 3;
+    for (int x = 0; x < w; ++x, s += 3) {
+      const int b = s[0], g = s[1], rr = s[2];
+      yp[(size_t)r * w + x] = clamp8((kYR * rr + kYG * g + kYB * b + kHalf + (16 << kQ)) >> kQ);
+      if (!(r & 1) && !(x & 1)) {
+        unsigned char* c = cp + (size_t)(r / 2) * w + x;   // interleaved U,V
+        c[0] = clamp8((kUR * rr + kUG * g + kUB * b + kHalf + (128 << kQ)) >> kQ);
+        c[1] = clamp8((kVR * rr + kVG * g + kVB * b + kHalf + (128 << kQ)) >> kQ);
+      }
+    }
+  }
+  return 0;
+}
+
 PreProcess::PreProcess(const std::string&) {}   // the reference ignores its config_file too (preprocess.cpp:35-36)
 
 int8_t PreProcess::Quantize(float32_t value, float32_t const scale, float32_t const zero_point, float32_t const min,

@@ -4,14 +4,18 @@
 //   :129-147 SetNodePara (model file must exist, task_num 4)  -> SetNodePara()
 //   :657-818 FeedImg (validate, split eyes, tensor, JPEG, async Run) -> OnStereoFrame()
 //   :980-1089 PostProcess (payload = raw tensor || JPEG, fps log)    -> PostProcess()
-// The reference's disabled offline feeders and dump helpers (:149-655, :820-976) are not reproduced.
+//   :820-976 RunImglistFeedInfer (offline file-list feeder)          -> RunImglistFeedInfer()
+// The reference's other disabled feeders and dump helpers (:149-655) are not reproduced.
 #include "stereonet_node.h"
 
 #include <unistd.h>
 
 #include <chrono>
 #include <cstring>
+#include <fstream>
+#include <thread>
 
+#include "image_io.h"
 #include "jpeg_nv12.h"
 
 namespace hobot {
@@ -154,6 +158,99 @@ void StereonetNode::OnStereoFrame(const hbm_img_msgs::msg::HbmMsg1080P::ConstSha
     return;
   }
   RCLCPP_INFO(kLog, "Run infer done");
+}
+
+namespace {
+// one path per line; every entry must exist (stereonet_node.cpp:832-878)
+bool read_list(const std::string& list_file, std::vector<std::string>& out) {
+  std::ifstream in(list_file);
+  if (!in.good()) {
+    RCLCPP_ERROR_STREAM(kLog, "Open file failed: " << list_file);
+    return false;
+  }
+  std::string line;
+  while (std::getline(in, line)) {
+    while (!line.empty() && (line.back() == '\r' || line.back() == ' ')) line.pop_back();
+    if (access(line.c_str(), F_OK) != 0) {
+      RCLCPP_ERROR_STREAM(kLog, "File is not exist! img_name: " << line);
+      return false;
+    }
+    out.push_back(line);
+  }
+  return true;
+}
+}  // namespace
+
+int StereonetNode::RunImglistFeedInfer(std::string left_img_list, std::string right_img_list) {
+  if (!rclcpp::ok() || !ready_) return 0;
+  RCLCPP_INFO_STREAM(kLog, "Feedback with left_img_list: " << left_img_list << " right_img_list: " << right_img_list);
+  std::vector<std::string> left, right;
+  if (!read_list(left_img_list, left) || !read_list(right_img_list, right)) {
+    rclcpp::shutdown();
+    return 0;
+  }
+  if (left.size() != right.size()) {
+    RCLCPP_ERROR_STREAM(kLog, "Imgs size error! left_imgs.size: " << left.size() << ", right_imgs.size: " << right.size());
+    rclcpp::shutdown();
+    return 0;
+  }
+  int start_ms = cfg_.feed_start_pause_ms, frame_ms = cfg_.feed_frame_pause_ms;
+  if (const char* e = getenv("STEREONET_FEED_PAUSE_MS")) start_ms = frame_ms = atoi(e);
+  std::this_thread::sleep_for(std::chrono::milliseconds(start_ms));
+
+  int done = 0;
+  std::vector<uint8_t> bgr;
+  std::vector<unsigned char> nv12[2];
+  for (size_t idx = 0; idx < left.size(); ++idx) {
+    RCLCPP_WARN_STREAM(kLog, "Feed " << idx << "/" << left.size());
+    if (!rclcpp::ok()) return done;
+    const std::string* path[2] = {&left[idx], &right[idx]};
+    for (int eye = 0; eye < 2; ++eye) {
+      int w = 0, h = 0;
+      std::string why;
+      if (!ReadImageBGR(*path[eye], w, h, bgr, &why)) {
+        RCLCPP_ERROR_STREAM(kLog, "BGRToNv12 Fail: " << why);
+        rclcpp::shutdown();
+        return done;
+      }
+      // the reference feeds whatever imread returned; a size other than the model's would read out of bounds
+      // there, so it is an error here
+      if (w != net_w_ || h != net_h_ || Tools::BGRToNv12(bgr.data(), w, h, nv12[eye]) != 0) {
+        RCLCPP_ERROR_STREAM(kLog, "BGRToNv12 Fail: " << *path[eye] << " is " << w << "x" << h << ", model input is "
+                                                     << net_w_ << "x" << net_h_);
+        rclcpp::shutdown();
+        return done;
+      }
+    }
+    auto request = std::make_shared<StereonetNodeOutput>();
+    request->msg_header = std::make_shared<std_msgs::msg::Header>();
+    request->msg_header->frame_id = std::to_string(idx);
+    std::vector<std::shared_ptr<DNNTensor>> tensors;
+    if (pre_->CvtNV12Data2Tensors(tensors, net_, nv12[0].data(), nv12[1].data()) < 0) {
+      RCLCPP_ERROR(kLog, "Preprocess fail");
+      rclcpp::shutdown();
+      return done;
+    }
+    if (cfg_.publish_output) {
+      auto jpg = std::make_shared<BinDataType>();
+      jpg->w = net_w_;
+      jpg->h = net_h_;
+      if (!EncodeNv12ToJpeg(nv12[0].data(), net_w_, net_h_, net_w_, cfg_.jpeg_quality, jpg->jpeg)) {
+        RCLCPP_ERROR(kLog, "invalid sp_left_nv12");
+        rclcpp::shutdown();
+        return done;
+      }
+      request->sp_left_nv12 = jpg;
+    }
+    if (Run(tensors, request, /*is_sync_mode=*/true, -1, -1) < 0) {
+      RCLCPP_ERROR(kLog, "Run infer fail!");
+      return done;
+    }
+    ++done;
+    RCLCPP_INFO(kLog, "Run infer done");
+    std::this_thread::sleep_for(std::chrono::milliseconds(frame_ms));
+  }
+  return done;
 }
 
 int StereonetNode::PostProcess(const std::shared_ptr<hobot::dnn_node::DnnNodeOutput>& node_output) {

@@ -2,6 +2,7 @@
 // functions through ctypes without a GPU or ROS (tests/test_host_mirror.py).
 #include <cstring>
 
+#include "image_io.h"
 #include "jpeg_nv12.h"
 #include "parser.h"
 #include "preprocess.h"
@@ -14,6 +15,31 @@ void snhost_yuv420_to_yuv444(const unsigned char* in, unsigned char* out, int w,
 
 int snhost_quantize_byte(int b) {
   return hobot::stereonet::PreProcess::Quantize(((float)b - 128.0) / 128.0);   // preprocess.cpp:1038 call-site form
+}
+
+int snhost_bgr_to_nv12(const unsigned char* bgr, int w, int h, unsigned char* nv12) {
+  std::vector<unsigned char> out;
+  if (hobot::stereonet::Tools::BGRToNv12(bgr, w, h, out) != 0) return -1;
+  memcpy(nv12, out.data(), out.size());
+  return 0;
+}
+
+// decodes an image file; returns 0 and w/h, copying at most cap bytes of BGR (call once with cap 0 for the size)
+int snhost_read_image_bgr(const char* path, int* w, int* h, unsigned char* bgr, long cap) {
+  std::vector<uint8_t> px;
+  std::string err;
+  if (!hobot::stereonet::ReadImageBGR(path, *w, *h, px, &err)) return -1;
+  if (bgr && cap > 0) memcpy(bgr, px.data(), (size_t)cap < px.size() ? (size_t)cap : px.size());
+  return 0;
+}
+
+int snhost_pfm_roundtrip(const char* path, const float* in, int w, int h, float* out) {
+  if (!hobot::stereonet::WritePFM(path, in, w, h)) return -1;
+  int rw = 0, rh = 0;
+  std::vector<float> d;
+  if (!hobot::stereonet::ReadPFM(path, rw, rh, d) || rw != w || rh != h) return -2;
+  memcpy(out, d.data(), sizeof(float) * d.size());
+  return 0;
 }
 
 // returns the JPEG size (<= cap) or -1

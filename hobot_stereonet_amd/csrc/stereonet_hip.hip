@@ -833,7 +833,15 @@ const char* sn_strerror(int code) {
   }
 }
 
-const char* sn_last_error(const sn_handle* h) { return h ? h->err.c_str() : ""; }
+// detail of the last failed sn_create on this thread (there is no handle to carry it)
+static thread_local std::string g_create_err;
+static int create_fail(int code, const char* what) {
+  const hipError_t e = hipGetLastError();
+  g_create_err = std::string(what) + (e != hipSuccess ? std::string(": ") + hipGetErrorString(e) : std::string());
+  return code;
+}
+
+const char* sn_last_error(const sn_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
 int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
   if (!model_file || !out) return SN_ERR_ARG;
@@ -866,12 +874,13 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
   if (c.precision != SN_PREC_FP32 && c.precision != SN_PREC_F16 && c.precision != SN_PREC_F16X3) return SN_ERR_ARG;
 
   int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SN_ERR_DEVICE;
+  g_create_err.clear();
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return create_fail(SN_ERR_DEVICE, "hipGetDeviceCount");
   int dev = c.device;
-  if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return SN_ERR_DEVICE;
+  if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return create_fail(SN_ERR_DEVICE, "hipGetDevice");
   if (dev >= ndev) return SN_ERR_ARG;
   hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return SN_ERR_DEVICE;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return create_fail(SN_ERR_DEVICE, "hipGetDeviceProperties");
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
     fprintf(stderr, "stereonet_hip: device %d is %s, this library is built for gfx950 only\n", dev,
             prop.gcnArchName);
@@ -909,6 +918,7 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
   }
   int rc = check_device(h);
   auto fail = [&](int code) {
+    create_fail(code, h->err.empty() ? "engine set-up" : h->err.c_str());
     sn_destroy(h);
     return code;
   };

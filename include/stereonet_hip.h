@@ -93,7 +93,8 @@ int sn_create(const char *model_file, const sn_config *cfg, sn_handle **out);
 int sn_destroy(sn_handle *h);
 int sn_get_io_info(const sn_handle *h, sn_io_info *info);
 const char *sn_strerror(int code);
-const char *sn_last_error(const sn_handle *h);   /* detail of the last failure on this handle */
+const char *sn_last_error(const sn_handle *h);   /* detail of the last failure on this handle; h = NULL: of the
+                                                  * last failed sn_create on the calling thread */
 
 /* DnnNode::Run, synchronous form (stereonet_node.cpp:968) ----------------------------------- */
 /* out_i32 and out_disp may each be NULL (but not both). */

@@ -87,6 +87,16 @@ def preprocess_nv12(left: np.ndarray, right: np.ndarray, w: int, h: int) -> np.n
     return out.reshape(6, h, w)
 
 
+def bgr_to_nv12(bgr: np.ndarray) -> np.ndarray:
+    """(h, w, 3) uint8 B,G,R -> flat NV12 (w*h*3/2 bytes)."""
+    bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+    h, w = bgr.shape[:2]
+    out = np.empty(w * h * 3 // 2, np.uint8)
+    if lib().so_bgr_to_nv12(_p(bgr), C.c_int(w), C.c_int(h), _p(out)) != 0:
+        raise ValueError("width and height must be even")
+    return out
+
+
 def dequant_depth(raw: np.ndarray, scale: float, dmax: float):
     raw = np.ascontiguousarray(raw, dtype=np.int32)
     disp = np.empty(raw.shape, np.float32)

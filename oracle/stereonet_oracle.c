@@ -81,6 +81,43 @@ void so_preprocess_nv12(const uint8_t *img_l, const uint8_t *img_r, int w, int h
   free(tmp);
 }
 
+/* preprocess.h:56-96: step 1 = planar I420 the way OpenCV's BGR2YUV_I420 fills it, step 2 = the reference's
+ * own interleave loop (:91-94). */
+static uint8_t so_sat8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+int so_bgr_to_nv12(const uint8_t *bgr, int w, int h, uint8_t *nv12) {
+  if ((w % 2) || (h % 2)) return -1;
+  const int SH = 20;
+  const int RND = 1 << (SH - 1);
+  const size_t ysz = (size_t)w * h, csz = ysz / 4;
+  uint8_t *i420 = (uint8_t *)malloc(ysz + 2 * csz);
+  uint8_t *yp = i420, *up = i420 + ysz, *vp = up + csz;
+  for (int by = 0; by < h / 2; ++by) {
+    for (int bx = 0; bx < w / 2; ++bx) {
+      for (int dy = 0; dy < 2; ++dy) {
+        for (int dx = 0; dx < 2; ++dx) {
+          const uint8_t *px = bgr + ((size_t)(2 * by + dy) * w + (2 * bx + dx)) * 3;
+          const int B = px[0], G = px[1], R = px[2];
+          yp[(size_t)(2 * by + dy) * w + 2 * bx + dx] =
+              so_sat8((269484 * R + 528482 * G + 102760 * B + RND + (16 << SH)) >> SH);
+          if (dy == 0 && dx == 0) {
+            up[(size_t)by * (w / 2) + bx] = so_sat8((-155188 * R - 305135 * G + 460324 * B + RND + (128 << SH)) >> SH);
+            vp[(size_t)by * (w / 2) + bx] = so_sat8((460324 * R - 385875 * G - 74448 * B + RND + (128 << SH)) >> SH);
+          }
+        }
+      }
+    }
+  }
+  memcpy(nv12, yp, ysz);
+  uint8_t *o = nv12 + ysz;
+  for (size_t i = 0; i < csz; ++i) {
+    *o++ = up[i];
+    *o++ = vp[i];
+  }
+  free(i420);
+  return 0;
+}
+
 /* parser.cpp:84-86 (C++, int32 view) == render.py:65-81 (uint32 view; equal
  * because the output is non-negative).  f, B: parser.cpp:70-71. */
 void so_dequant_depth(const int32_t *raw, int n, float scale, float dmax,

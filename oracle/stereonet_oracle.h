@@ -53,6 +53,15 @@ int8_t so_quantize(float value, float scale, float zero_point, float mn, float m
 /* preprocess.cpp:975-1056 — two NV12 eyes → int8 NCHW 1x6xhxw tensor */
 void so_preprocess_nv12(const uint8_t *img_l, const uint8_t *img_r, int w, int h, int8_t *out6);
 
+/* preprocess.h:56-96 (Tools::BGRToNv12, offline feeders only): cv::cvtColor(COLOR_BGR2YUV_I420) into a planar
+ * I420 buffer, then U/V interleaved into NV12.  OpenCV is an un-vendored dependency of the reference
+ * (stereonet_infer/CMakeLists.txt find_package(OpenCV)); its RGB->YUV420p arithmetic is restated from the
+ * published source (imgproc color_yuv: BT.601 studio range, Q20 coefficients 269484/528482/102760,
+ * -155188/-305135/460324, 460324/-385875/-74448, + half, >> 20, chroma from the top-left pixel of each 2x2).
+ * PARITY UNPINNED against OpenCV itself (not in this image); pinned to the BT.601 known answers in
+ * tests/test_filelist.py.  Returns -1 for odd w or h. */
+int so_bgr_to_nv12(const uint8_t *bgr, int w, int h, uint8_t *nv12);
+
 /* parser.cpp:79-94 / render.py:72-81 — dequant + metric depth */
 void so_dequant_depth(const int32_t *raw, int n, float scale, float dmax,
                       float *disp_px, float *depth_m);

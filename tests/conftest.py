@@ -2,6 +2,7 @@ import os
 import sys
 
 import pytest
+import torch  # noqa: F401  first HIP-linked import of the session: one HIP runtime per process (api.load_library)
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "golden")):

@@ -19,6 +19,7 @@ def hostlib():
     from hobot_stereonet_amd import build
     build.build()
     subprocess.check_call(["make", "-C", COMPAT, "-s"])
+    import torch  # noqa: F401  (before anything that links HIP: one HIP runtime per process, see api.load_library)
     lib = C.CDLL(os.path.join(COMPAT, "build", "libhobot_stereonet_node.so"))
     vp, ci = C.c_void_p, C.c_int
     lib.snhost_yuv420_to_yuv444.argtypes = [vp, vp, ci, ci]
