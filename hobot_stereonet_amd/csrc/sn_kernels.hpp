@@ -855,7 +855,7 @@ struct RefTile2 {
   static constexpr int KW = (NINST + 3) / 4;            // DMA instructions per wave per group (constant)
   static constexpr int BUF = NINST * 64;
   static constexpr int NBUF = 3;
-  static constexpr int LDS_BYTES = NBUF * BUF * 16;
+  static constexpr int LDS_BYTES = NBUF * BUF * 16 + 16;   // + the two tile-queue words of the dynamic schedule
   static constexpr int NSTORE = 4 * SPW;
 };
 
@@ -918,11 +918,19 @@ __device__ __forceinline__ void ref2_compute(const uint4* lds_lane, const half8 
   }
 }
 
-template <int DIL, int TW, bool RES>
+// DYN = true: tiles beyond the first two rounds are handed out by one device-scope counter per XCD band
+// (tile_ctr[16 * xcd], zeroed by the host before the launch) instead of the static stride.  When the
+// low-resolution branch runs on the other stream the hardware places the tower's workgroups unevenly (two on one
+// CU, none on a CU that is full of other kernels' waves); a static partition then waits for the slowest CU.
+// Wave 0 fetches tile ti+2 during tile ti: the returning atomic is issued right after the phase-g0 barrier,
+// i.e. it is OLDER than every DMA group / store the counted waits below leave in flight, so the existing
+// vmcnt immediates stay valid (they only ever name the youngest ops); the value crosses to the other waves
+// through two LDS words behind the ring.
+template <int DIL, int TW, bool RES, bool DYN>
 __global__ __launch_bounds__(256, 2) void k_ref_conv_f16_v2(const uint4* __restrict__ in, uint4* out,
                                                             const uint4* res, const uint4* __restrict__ wfrag,
                                                             const float* __restrict__ bias, RefGeom g, int nimg,
-                                                            int lrelu) {
+                                                            int lrelu, unsigned* tile_ctr) {
   using T = RefTile2<DIL, TW>;
   extern __shared__ __attribute__((aligned(16))) uint4 lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -952,8 +960,6 @@ __global__ __launch_bounds__(256, 2) void k_ref_conv_f16_v2(const uint4* __restr
   const int t_begin = (int)((long)xcd * total / 8), t_end = (int)((long)(xcd + 1) * total / 8);
   const int t0 = t_begin + lb;
   if (t0 >= t_end) return;
-  const int ntiles = (t_end - t0 + nlb - 1) / nlb;
-  const int G = 2 * ntiles;                                  // phases of this block
 
   const int seg0 = wave * T::SPW;
   const int lane_off = gh * T::PLANE + (seg0 / T::CSEG) * T::COLS + j;
@@ -983,8 +989,7 @@ __global__ __launch_bounds__(256, 2) void k_ref_conv_f16_v2(const uint4* __restr
     io_voff[s] = ((unsigned)(seg / T::CSEG) * (unsigned)g.Ws + (unsigned)((seg % T::CSEG) * 32 + j)) * 16u + gh * 8u;
   }
 
-  auto tile_xy = [&](int ti, int& img, int& y0, int& x0) {
-    const int t = t0 + ti * nlb;
+  auto tile_xy = [&](int t, int& img, int& y0, int& x0) {      // t = global tile index
     img = t / per_img;
     const int rem = t - img * per_img;
     const int ty = rem / g.tiles_x;
@@ -1009,19 +1014,40 @@ __global__ __launch_bounds__(256, 2) void k_ref_conv_f16_v2(const uint4* __restr
 
   wait_vmcnt<0>();
   int img, y0, x0, nimg_ = 0, ny0 = 0, nx0 = 0;
-  tile_xy(0, img, y0, x0);
+  tile_xy(t0, img, y0, x0);
   issue(0, img, y0, x0);
   issue(1, img, y0, x0);
+  int t_next = t0 + nlb;                                      // tile ti+1 (second round is static as well)
+  int t_next2 = t0 + 2 * nlb;                                 // tile ti+2 (static schedule; DYN overwrites it)
+  unsigned* tile_slot = reinterpret_cast<unsigned*>(lds + 3 * T::BUF);   // not volatile: that would drain vmcnt
+  unsigned* const my_ctr = tile_ctr + 16 * xcd;
 
   f32x16 acc[T::SPW];
-  for (int ti = 0; ti < ntiles; ++ti) {
+  for (int ti = 0;; ++ti) {
     const int g0 = 2 * ti;
-    if (ti + 1 < ntiles) tile_xy(ti + 1, nimg_, ny0, nx0);   // one coordinate decode per tile
+    const bool has_next = t_next < t_end;                     // wave-uniform
+    if (has_next) tile_xy(t_next, nimg_, ny0, nx0);           // one coordinate decode per tile
     // ---- phase g0 (channels 0..15) ----
     if (ti == 0) wait_vmcnt<T::KW>();                         // younger than group 0: group 1
     else wait_vmcnt<T::KW + T::NSTORE>();                     // ... plus the previous tile's stores
     block_barrier();
-    if (g0 + 2 < G) issue(g0 + 2, nimg_, ny0, nx0);
+    // `fetched` is written asynchronously by the returning atomic: it is defined opaquely up front and tied
+    // read-write into the asm so that hipcc keeps it in one register and never copies it before the wait below.
+    unsigned fetched;
+    asm volatile("" : "=v"(fetched));
+    if (DYN && has_next && wave == 0) {                       // wave-uniform branch; lane 0 only inside the asm
+      unsigned one = 1;
+      unsigned long long saved_exec;
+      asm volatile(
+          "s_mov_b64 %1, exec\n\t"
+          "s_mov_b64 exec, 1\n\t"
+          "global_atomic_add %0, %2, %3, off sc0\n\t"
+          "s_mov_b64 exec, %1"
+          : "+v"(fetched), "=&s"(saved_exec)
+          : "v"(my_ctr), "v"(one)
+          : "memory");
+    }
+    if (has_next) issue(g0 + 2, nimg_, ny0, nx0);
     // accumulators start at the bias: saves one add per output in the epilogue
 #pragma unroll
     for (int s = 0; s < T::SPW; ++s)
@@ -1030,9 +1056,20 @@ __global__ __launch_bounds__(256, 2) void k_ref_conv_f16_v2(const uint4* __restr
     ref2_compute<DIL, TW, 0>(lds + (g0 % 3) * T::BUF + lane_off, wf, acc);
 
     // ---- phase g0+1 (channels 16..31) ----
-    if (g0 + 2 < G) wait_vmcnt<T::KW>();                      // younger than group g0+1: group g0+2
+    if (has_next) wait_vmcnt<T::KW>();                        // younger than group g0+1: group g0+2
     else wait_vmcnt<0>();                                     // last phase of this block
+    if (DYN && has_next && wave == 0) {                       // the atomic is older than group g0+2: it has returned
+      asm volatile("" : "+v"(fetched));
+      if (lane == 0) tile_slot[ti & 1] = fetched;
+      // block_barrier() is a bare s_barrier: an ordinary LDS write has to be retired by its own wave first
+      // (the ring itself is filled by LDS-DMA and ordered by vmcnt)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     block_barrier();
+    if (DYN) {
+      if (has_next) t_next2 = t_begin + 2 * nlb + (int)__builtin_amdgcn_readfirstlane(tile_slot[ti & 1]);
+      else t_next2 = t_end;
+    }
 
     // residual: NSTORE 8-byte loads issued as inline asm BEFORE the next DMA group, so they are older
     // than it and the counted wait below (all but the newest KW ops) retires them without draining
@@ -1050,7 +1087,7 @@ __global__ __launch_bounds__(256, 2) void k_ref_conv_f16_v2(const uint4* __restr
         }
       }
     }
-    const bool more = g0 + 3 < G;
+    const bool more = has_next;
     if (more) issue(g0 + 3, nimg_, ny0, nx0);
     ref2_compute<DIL, TW, 1>(lds + ((g0 + 1) % 3) * T::BUF + lane_off, wf, acc);
     if (RES) {
@@ -1091,9 +1128,12 @@ __global__ __launch_bounds__(256, 2) void k_ref_conv_f16_v2(const uint4* __restr
         *reinterpret_cast<half4*>(oq + io_voff[s]) = hv;
       }
     }
+    if (!has_next) break;
     img = nimg_;
     y0 = ny0;
     x0 = nx0;
+    t_next = t_next2;
+    t_next2 = DYN ? t_end : t_next2 + nlb;
   }
 }
 

@@ -55,6 +55,9 @@ struct HeadLayer {          // C -> 1 layers (VALU kernels)
   float bias = 0.f;
 };
 
+constexpr int kTileCtrStride = 8 * 16;                       // uints per tower launch (one 64-B line per XCD)
+constexpr size_t kTileCtrBytes = (size_t)2 * 6 * kTileCtrStride * sizeof(unsigned);   // 2 * kNRefRes launches
+
 struct Workspace {          // activations for up to `nb` pairs
   int nb = 0, rb = 0, pb = 0;   // batch capacity, pairs per tower launch, pairs per low-res piece
   int8_t* in6 = nullptr;
@@ -66,6 +69,8 @@ struct Workspace {          // activations for up to `nb` pairs
   float* disp_low = nullptr;
   float* ref[2] = {nullptr, nullptr};
   uint4* ref16[2] = {nullptr, nullptr};   // fp16 NCHW8c padded (SN_PREC_F16)
+  int n_chunks = 0;
+  unsigned* tile_ctr = nullptr;           // dynamic tile queues of the fp16 tower: [12 launches][8 XCDs][16] uints
   float* out_disp = nullptr;
   int32_t* out_raw = nullptr;
   uint8_t* nv12 = nullptr;   // staging for NV12 inputs (2 eyes or one side-by-side frame)
@@ -97,6 +102,8 @@ struct sn_handle {
   hipStream_t s_low = nullptr, s_ref = nullptr;     // low-res branch / refinement tower (piece pipeline)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_piece[kMaxPieceEvents] = {};
   bool overlap = true;
+  int ovl_cap = 1;           // tower workgroups per CU while the low-res branch runs beside it (SN_OVL_CAP)
+  bool ref_dyn = true;       // dynamic tile queue in the fp16 tower (SN_REF_DYN=0: static stride)
   bool use_graphs = true;    // hipGraph replay for the async single-pair path (SN_NO_GRAPH disables)
   ConvLayer down[kNDown], fres[kNFeatRes][2], fout, agg[kNAgg], rin, rres[kNRefRes][2];
   HeadLayer aout, rout;
@@ -456,9 +463,11 @@ hipError_t launch_ref_f16(hipStream_t st, const RefLayerF16& L, const RefGeom& g
 
 template <int DIL, int TW>
 hipError_t launch_ref_f16_v2(hipStream_t st, const RefLayerF16& L, const RefGeom& g, int num_cu, const uint4* in,
-                             uint4* out, const uint4* res, int nimg, bool lrelu, int per_cu_cap) {
+                             uint4* out, const uint4* res, int nimg, bool lrelu, int per_cu_cap, unsigned* tile_ctr) {
   using T = RefTile2<DIL, TW>;
-  auto kern = res ? k_ref_conv_f16_v2<DIL, TW, true> : k_ref_conv_f16_v2<DIL, TW, false>;
+  // tile_ctr != nullptr: dynamic tile queue (8 zeroed counters, 64 B apart); nullptr: static stride
+  auto kern = tile_ctr ? (res ? k_ref_conv_f16_v2<DIL, TW, true, true> : k_ref_conv_f16_v2<DIL, TW, false, true>)
+                       : (res ? k_ref_conv_f16_v2<DIL, TW, true, false> : k_ref_conv_f16_v2<DIL, TW, false, false>);
   if (T::LDS_BYTES > 64 * 1024) {
     hipError_t e = ensure_lds_attr(kern, T::LDS_BYTES);
     if (e != hipSuccess) return e;
@@ -476,10 +485,11 @@ hipError_t launch_ref_f16_v2(hipStream_t st, const RefLayerF16& L, const RefGeom
   int cap = num_cu * per_cu / 8;
   if (cap < 1) cap = 1;
   const int rounds = (band + cap - 1) / cap;
-  const int nlb = (band + rounds - 1) / rounds;
+  int nlb = (band + rounds - 1) / rounds;
+  if (tile_ctr) nlb = cap < band ? cap : band;     // dynamic queue: fill every slot, the counter balances
   const int blocks = nlb * 8;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), T::LDS_BYTES, st, in, out, res, L.wfrag, L.bias, gt, nimg,
-                     lrelu ? 1 : 0);
+                     lrelu ? 1 : 0, tile_ctr);
   return hipGetLastError();
 }
 
@@ -545,13 +555,14 @@ bool use_ref_v1() {
 }
 
 hipError_t ref_conv_f16(hipStream_t st, const RefLayerF16& L, const RefGeom& g, int num_cu, int dil, const uint4* in,
-                        uint4* out, const uint4* res, int nimg, bool lrelu, int per_cu_cap = 0) {
+                        uint4* out, const uint4* res, int nimg, bool lrelu, int per_cu_cap = 0,
+                        unsigned* tile_ctr = nullptr) {
   if (!use_ref_v1()) {
     switch (dil) {
-      case 1: return launch_ref_f16_v2<1, 64>(st, L, g, num_cu, in, out, res, nimg, lrelu, per_cu_cap);
-      case 2: return launch_ref_f16_v2<2, 64>(st, L, g, num_cu, in, out, res, nimg, lrelu, per_cu_cap);
-      case 4: return launch_ref_f16_v2<4, 64>(st, L, g, num_cu, in, out, res, nimg, lrelu, per_cu_cap);
-      case 8: return launch_ref_f16_v2<8, 32>(st, L, g, num_cu, in, out, res, nimg, lrelu, per_cu_cap);
+      case 1: return launch_ref_f16_v2<1, 64>(st, L, g, num_cu, in, out, res, nimg, lrelu, per_cu_cap, tile_ctr);
+      case 2: return launch_ref_f16_v2<2, 64>(st, L, g, num_cu, in, out, res, nimg, lrelu, per_cu_cap, tile_ctr);
+      case 4: return launch_ref_f16_v2<4, 64>(st, L, g, num_cu, in, out, res, nimg, lrelu, per_cu_cap, tile_ctr);
+      case 8: return launch_ref_f16_v2<8, 32>(st, L, g, num_cu, in, out, res, nimg, lrelu, per_cu_cap, tile_ctr);
       default: return hipErrorInvalidValue;
     }
   }
@@ -565,7 +576,7 @@ hipError_t ref_conv_f16(hipStream_t st, const RefLayerF16& L, const RefGeom& g, 
 }
 
 hipError_t ref_block_f16(hipStream_t st, const RefLayerF16& L1, const RefLayerF16& L2, const RefGeom& g, int num_cu,
-                         int dil, uint4** cur, uint4** oth, int nimg, int per_cu_cap = 0) {
+                         int dil, uint4** cur, uint4** oth, int nimg, int per_cu_cap = 0, unsigned* tile_ctr = nullptr) {
   if (const int fm = use_fused_block(dil)) {
     hipError_t e = fm == 2 ? launch_ref_block_f16_ws<1>(st, L1, L2, g, num_cu, *cur, *oth, nimg)
                            : launch_ref_block_f16<1>(st, L1, L2, g, num_cu, *cur, *oth, nimg);
@@ -574,9 +585,10 @@ hipError_t ref_block_f16(hipStream_t st, const RefLayerF16& L1, const RefLayerF1
     *oth = t;
     return e;
   }
-  hipError_t e = ref_conv_f16(st, L1, g, num_cu, dil, *cur, *oth, nullptr, nimg, true, per_cu_cap);
+  hipError_t e = ref_conv_f16(st, L1, g, num_cu, dil, *cur, *oth, nullptr, nimg, true, per_cu_cap, tile_ctr);
   if (e != hipSuccess) return e;
-  return ref_conv_f16(st, L2, g, num_cu, dil, *oth, *cur, *cur, nimg, true, per_cu_cap);   // in-place residual
+  return ref_conv_f16(st, L2, g, num_cu, dil, *oth, *cur, *cur, nimg, true, per_cu_cap,   // in-place residual
+                      tile_ctr ? tile_ctr + kTileCtrStride : nullptr);
 }
 
 // ---- workspace -----------------------------------------------------------------------------------
@@ -604,6 +616,9 @@ int alloc_ws(sn_handle* h, Workspace* ws, int nb, int rb) {
       HIP_TRY(h, dalloc(&ws->ref16[k], slots));
       HIP_TRY(h, hipMemset(ws->ref16[k], 0, slots * sizeof(uint4)));   // the zero border is never written again
     }
+    // fine-grained: the queue words must be coherent across the 8 XCD L2s at device scope and with the memset
+    ws->n_chunks = (nb + rb - 1) / rb;
+    HIP_TRY(h, hipExtMallocWithFlags(reinterpret_cast<void**>(&ws->tile_ctr), kTileCtrBytes * ws->n_chunks, hipDeviceMallocFinegrained));
   }
   HIP_TRY(h, dalloc(&ws->out_disp, (size_t)nb * HW));
   HIP_TRY(h, dalloc(&ws->out_raw, (size_t)nb * HW));
@@ -613,6 +628,7 @@ int alloc_ws(sn_handle* h, Workspace* ws, int nb, int rb) {
 
 void free_ws(Workspace* ws) {
   hipFree(ws->in6);
+  hipFree(ws->tile_ctr);
   for (auto p : ws->down) hipFree(p);
   for (auto p : ws->low) hipFree(p);
   hipFree(ws->feat);
@@ -729,13 +745,15 @@ int refine(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, const int
         HIP_TRY(h, (launch_conv<3, 1, 1, 4, 8, 64, LoadRefineIn, 1>(st, h->rin, ld, c, Hp, Wp, reinterpret_cast<float*>(rx),
                                                                   nullptr, true, g.Hs, g.Ws)));
       if (pe) HIP_TRY(h, hipEventRecord(h->ev[4], st));
+      const bool dyn = !x3 && h->ref_dyn && ws.tile_ctr != nullptr;
+      unsigned* const chunk_ctr = dyn ? ws.tile_ctr + (size_t)(q0 / ws.rb) * (kTileCtrBytes / sizeof(unsigned)) : nullptr;
       for (int i = 0; i < kNRefRes; ++i) {
         if (x3) {
           HIP_TRY(h, ref_conv_f16x3(st, h->rres16[i][0], g, h->num_cu, kRefDil[i], rx, rt, nullptr, lo_slots, c, true));
           HIP_TRY(h, ref_conv_f16x3(st, h->rres16[i][1], g, h->num_cu, kRefDil[i], rt, rx, rx, lo_slots, c, true));
         } else {
           HIP_TRY(h, ref_block_f16(st, h->rres16[i][0], h->rres16[i][1], g, h->num_cu, kRefDil[i], &rx, &rt, c,
-                                   overlapped ? 1 : 0));
+                                   overlapped ? h->ovl_cap : 0, dyn ? chunk_ctr + 2 * i * kTileCtrStride : nullptr));
         }
       }
       if (pe) HIP_TRY(h, hipEventRecord(h->ev[5], st));
@@ -761,6 +779,7 @@ int forward(sn_handle* h, Workspace& ws, hipStream_t st, int n, const int8_t* in
   const bool prof = h->profiling && (&ws == &h->ws);
   const bool overlap = !prof && (&ws == &h->ws) && h->overlap && n > ws.pb;
   int rc;
+  if (ws.tile_ctr && h->ref_dyn) HIP_TRY(h, hipMemsetAsync(ws.tile_ctr, 0, kTileCtrBytes * ws.n_chunks, st));
   if (!overlap) {
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[0], st));
     for (int p0 = 0; p0 < n; p0 += ws.pb) {
@@ -935,6 +954,11 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(SN_ERR_DEVICE);
   h->overlap = getenv("SN_NO_OVERLAP") == nullptr;
   h->use_graphs = getenv("SN_NO_GRAPH") == nullptr;
+  {
+    const char* e = getenv("SN_REF_DYN");     // dynamic tile queue of the fp16 tower (default on)
+    h->ref_dyn = e ? atoi(e) != 0 : true;
+    if (const char* c = getenv("SN_OVL_CAP")) h->ovl_cap = atoi(c);
+  }
 
   BlobWalker bw{blob.data()};
   const bool low_x3 = h->precision != SN_PREC_FP32 && getenv("SN_LOW_FP32") == nullptr;
@@ -1458,7 +1482,9 @@ int sn_dbg_ref_conv_f16(sn_handle* h, const float* in, int h_px, int w, const fl
   } else {
     HIP_TRY(h, hipMemset(dout, 0, slots * 16));
   }
-  HIP_TRY(h, ref_conv_f16(h->stream, L, g, h->num_cu, dil, din, dout, dres, 1, lrelu != 0));
+  unsigned* ctr = h->ref_dyn ? h->ws.tile_ctr : nullptr;
+  if (ctr) HIP_TRY(h, hipMemsetAsync(ctr, 0, kTileCtrBytes, h->stream));
+  HIP_TRY(h, ref_conv_f16(h->stream, L, g, h->num_cu, dil, din, dout, dres, 1, lrelu != 0, 0, ctr));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   std::vector<_Float16> hout(slots * 8);
   HIP_TRY(h, hipMemcpy(hout.data(), dout, slots * 16, hipMemcpyDeviceToHost));
@@ -1614,6 +1640,7 @@ int sn_dbg_read(sn_handle* h, const char* what, float* dst, size_t cap, size_t* 
   else if (!strcmp(what, "feat_r")) { src = h->ws.feat + kC * hw; cnt = kC * hw; }
   else if (!strcmp(what, "cost")) { src = h->ws.cost; cnt = h->Dl * hw; }
   else if (!strcmp(what, "disp_low")) { src = h->ws.disp_low; cnt = hw; }
+  else if (!strcmp(what, "tile_ctr") && h->ws.tile_ctr) { src = reinterpret_cast<const float*>(h->ws.tile_ctr); cnt = kTileCtrBytes / 4 * h->ws.n_chunks; }
   else if (!strcmp(what, "refine_x") && h->precision == SN_PREC_FP32) { src = h->ws.ref[0]; cnt = (size_t)kC * h->Hp * h->Wp; }
   else return SN_ERR_ARG;
   *n = cnt;
