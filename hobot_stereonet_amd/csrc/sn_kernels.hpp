@@ -391,8 +391,6 @@ __global__ __launch_bounds__(256) void k_conv_c32_x3(ConvArgs a, Loader ld) {
   constexpr int HALF = (COLS_IN + 1) / 2;
   constexpr int PITCH = STRIDE == 1 ? COLS_IN : 2 * HALF;   // stride 2: columns split by parity, as in the fp32 kernel
   constexpr int PLANE = ROWS_IN * PITCH;               // slots per channel block
-  constexpr int NELEM = CH * ROWS_IN * COLS_IN;
-  constexpr int EPT = (NELEM + 255) / 256;
   constexpr int NW4 = TAPS * 2 * 64;                   // weight slots per chunk
   constexpr int WPT = WLDS ? (NW4 + 255) / 256 : 1;
 
@@ -420,19 +418,25 @@ __global__ __launch_bounds__(256) void k_conv_c32_x3(ConvArgs a, Loader ld) {
     }
   const int gh = lane >> 5, j = lane & 31;
 
-  float pre[EPT];
+  // Staging unit = one pixel of one 8-channel block: eight coalesced 4-byte loads (one per channel plane), split
+  // into (hi, lo) in registers and committed as ONE 16-byte LDS write each -- the per-element 2-byte writes this
+  // replaces were 8-way bank conflicted and cost more LDS time than the MFMAs of the chunk.
+  constexpr int NSLOT = 2 * ROWS_IN * COLS_IN;
+  constexpr int SPT = (NSLOT + 255) / 256;
+  float pre[SPT][8];
   uint4 wpre[WPT];
   auto fetch = [&](int c0) {
     int tq = tid;
     asm volatile("" : "+v"(tq));
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) {
+    for (int e = 0; e < SPT; ++e) {
       const int idx = e * 256 + tq;
-      const int c = idx / (ROWS_IN * COLS_IN);
-      const int rem = idx - c * (ROWS_IN * COLS_IN);
+      const int cb = idx / (ROWS_IN * COLS_IN);
+      const int rem = idx - cb * (ROWS_IN * COLS_IN);
       const int r = rem / COLS_IN;
       const int cc = rem - r * COLS_IN;
-      pre[e] = idx < NELEM ? ld(img, c0 + c, iy0 + r, ix0 + cc) : 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) pre[e][k] = idx < NSLOT ? ld(img, c0 + cb * 8 + k, iy0 + r, ix0 + cc) : 0.f;
     }
     if (WLDS) {
       const uint4* wsrc = reinterpret_cast<const uint4*>(a.wpk) + (size_t)(c0 / CH) * NW4;
@@ -447,20 +451,24 @@ __global__ __launch_bounds__(256) void k_conv_c32_x3(ConvArgs a, Loader ld) {
     int tq = tid;
     asm volatile("" : "+v"(tq));
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) {
+    for (int e = 0; e < SPT; ++e) {
       const int idx = e * 256 + tq;
-      const int c = idx / (ROWS_IN * COLS_IN);
-      const int rem = idx - c * (ROWS_IN * COLS_IN);
+      const int cb = idx / (ROWS_IN * COLS_IN);
+      const int rem = idx - cb * (ROWS_IN * COLS_IN);
       const int r = rem / COLS_IN;
       const int cc = rem - r * COLS_IN;
-      if (idx < NELEM) {
-        const float v = pre[e];
-        const _Float16 hi = (_Float16)v;
-        const _Float16 lo = (_Float16)((v - (float)hi) * kSplitScale);
+      if (idx < NSLOT) {
+        half8 hi, lo;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float v = pre[e][k];
+          hi[k] = (_Float16)v;
+          lo[k] = (_Float16)((v - (float)hi[k]) * kSplitScale);
+        }
         const int di = STRIDE == 1 ? cc : (cc & 1) * HALF + (cc >> 1);
-        const int off = ((c >> 3) * PLANE + r * PITCH + di) * 8 + (c & 7);      // in halves
-        reinterpret_cast<_Float16*>(s_xh)[off] = hi;
-        reinterpret_cast<_Float16*>(s_xl)[off] = lo;
+        const int off = cb * PLANE + r * PITCH + di;
+        s_xh[off] = *reinterpret_cast<const uint4*>(&hi);
+        s_xl[off] = *reinterpret_cast<const uint4*>(&lo);
       }
     }
     if (WLDS) {
