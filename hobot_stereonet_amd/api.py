@@ -81,6 +81,7 @@ def load_library(path: Optional[str] = None):
     lib.sn_get_dominant_kernel.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(ip), C.POINTER(C.c_double),
                                            C.POINTER(C.c_double)]
     lib.sn_dbg_conv2d.argtypes = [vp, fp, ip, ip, ip, fp, fp, ip, ip, ip, ip, fp, fp]
+    lib.sn_dbg_down0.argtypes = [vp, i8p, ip, ip, fp, fp, ip, fp]
     lib.sn_dbg_conv3d.argtypes = [vp, fp, ip, ip, ip, fp, fp, ip, fp]
     lib.sn_dbg_ref_conv_f16.argtypes = [vp, fp, ip, ip, fp, fp, ip, ip, fp, fp]
     lib.sn_dbg_ref_conv_f16x3.argtypes = [vp, fp, ip, ip, fp, fp, ip, ip, fp, fp]
@@ -88,7 +89,7 @@ def load_library(path: Optional[str] = None):
     lib.sn_dbg_read.argtypes = [vp, C.c_char_p, fp, C.c_size_t, C.POINTER(C.c_size_t)]
     for name in ("sn_create", "sn_destroy", "sn_get_io_info", "sn_infer_i8", "sn_infer_batch", "sn_preprocess_nv12",
                  "sn_infer_sbs_nv12", "sn_submit", "sn_wait", "sn_synchronize", "sn_set_profiling",
-                 "sn_get_stage_ms", "sn_get_dominant_kernel", "sn_dbg_conv2d", "sn_dbg_conv3d", "sn_dbg_ref_conv_f16", "sn_dbg_ref_conv_f16x3", "sn_dbg_ref_block_f16", "sn_dbg_read"):
+                 "sn_get_stage_ms", "sn_get_dominant_kernel", "sn_dbg_conv2d", "sn_dbg_down0", "sn_dbg_conv3d", "sn_dbg_ref_conv_f16", "sn_dbg_ref_conv_f16x3", "sn_dbg_ref_block_f16", "sn_dbg_read"):
         getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
@@ -235,6 +236,18 @@ class StereoNetHIP:
         self._check(self._lib.sn_dbg_conv2d(self._h, x.ctypes.data, cin, h, w, wt.ctypes.data, bias.ctypes.data, k,
                                             stride, dil, int(lrelu) | (2 if x3 else 0), _np_ptr(res), out.ctypes.data),
                     "sn_dbg_conv2d")
+        return out
+
+    def dbg_down0(self, in6, wt, bias, tc=32):
+        """in6 int8 (6,h,w) -> float32 (2, 32, ho, wo): first down-conv of both eyes on the fp16 MFMA."""
+        x = np.ascontiguousarray(in6, np.int8)
+        wt = np.ascontiguousarray(wt, np.float32)
+        bias = np.ascontiguousarray(bias, np.float32)
+        _, h, w = x.shape
+        ho, wo = (h + 15) // 16 * 8, (w + 15) // 16 * 8
+        out = np.empty((2, 32, ho, wo), np.float32)
+        self._check(self._lib.sn_dbg_down0(self._h, x.ctypes.data, h, w, wt.ctypes.data, bias.ctypes.data, tc,
+                                           out.ctypes.data), "sn_dbg_down0")
         return out
 
     def dbg_conv3d(self, x, wt, bias, lrelu=False, x3=False):

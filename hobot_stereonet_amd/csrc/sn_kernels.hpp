@@ -540,6 +540,175 @@ __global__ __launch_bounds__(256) void k_conv_c32_x3(ConvArgs a, Loader ld) {
 }
 
 // ------------------------------------------------------------------------------------------
+// K1a: first down-conv (3 -> 32, 5x5, stride 2) straight from the int8 model input, fp16 modes.
+// With three input channels the generic implicit GEMM spends 50 exact-fp32 MFMAs (64 cycles each) per 32 output
+// pixels on K = 4 (padded) x 25.  The int8 input / 128 is EXACT in fp16, so only the weights need the hi/lo split
+// (two fp16 MFMAs per K step), and K is packed densely as  (ci, ky) rows x kx[0..7]:
+//   k = 8 * rho + kx,  rho = ci * 5 + ky in 0..14 (row 15 and kx 5..7 carry zero weights)  ->  8 K-steps of 16
+//   = 16 MFMAs of 32 cycles per 32 pixels (6.25x fewer matrix cycles).
+// The B fragment of lane (pixel j, k-group g) at K-step t is 8 CONSECUTIVE input columns of row rho = 2t + g,
+// starting at column 2*ox - 2: 16 bytes at a 4-byte aligned LDS address -> four ds_read_b32 (or two
+// ds_read2_b32), no packing VALU.  The three extra columns read under the zero weights are real neighbouring
+// pixels (finite), never uninitialised LDS.
+// Persistent workgroups (static stride over 8 x TC output tiles), both weight fragment sets (16 x half8) in
+// registers, LDS tile double buffered: the next tile's int8 dwords are in flight during the MFMAs.
+// Output fp32 NCHW [2n][32][Ho][Wo], exactly what the generic kernel writes.
+// ------------------------------------------------------------------------------------------
+template <int TC>
+struct Down0Tile {
+  static constexpr int TR = 8;
+  static constexpr int ROWS = 2 * TR + 3;            // input rows of a tile
+  static constexpr int NDW = (2 * TC + 3 + 3 + 2 + 3) / 4;   // staged dwords per row: window starts 2 px left of ix0 (4-aligned)
+  static constexpr int PITCH = NDW * 4 + 4;          // halves per LDS row (+4: keeps rows 8-byte aligned, staggers banks)
+  static constexpr int BUF = 3 * ROWS * PITCH;       // halves per buffer
+  static constexpr int LDS_BYTES = 2 * BUF * 2;
+  static constexpr int NLOAD = (3 * ROWS * NDW + 255) / 256;
+  static constexpr int CSEG = TC / 32, SPW = TR * CSEG / 4;
+};
+
+template <int TC>
+__global__ __launch_bounds__(256) void k_down0_f16(const int8_t* __restrict__ in6, int H, int W,
+                                                   const uint4* __restrict__ wfrag,   // [8][hi|lo][64]
+                                                   const float* __restrict__ bias, float* __restrict__ out, int Ho,
+                                                   int Wo, int tiles_x, int tiles_y, int nimg, int lrelu,
+                                                   int al4) {   // W % 4 == 0 and in6 4-byte aligned: dword loads
+  using T = Down0Tile<TC>;
+  extern __shared__ __attribute__((aligned(16))) _Float16 s_x[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, g = lane >> 5;
+
+  half8 wh[8], wl[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const uint4 a = wfrag[(2 * t) * 64 + lane], b = wfrag[(2 * t + 1) * 64 + lane];
+    wh[t] = *reinterpret_cast<const half8*>(&a);
+    wl[t] = *reinterpret_cast<const half8*>(&b);
+  }
+  float bv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bv[r] = bias[(r & 3) + 8 * (r >> 2) + 4 * g];
+
+  // per-lane LDS offset (halves) of K-step t: row rho = 2t + g  ->  (ci, ky); rho = 15 re-reads row 0 (zero weights)
+  int koff[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    int rho = 2 * t + g;
+    rho = rho < 15 ? rho : 0;
+    koff[t] = ((rho / 5) * T::ROWS + (rho % 5)) * T::PITCH;
+  }
+
+  const int total = tiles_x * tiles_y * nimg;
+  uint32_t pre[T::NLOAD];
+  auto fetch = [&](int tile) {
+    const int tx = tile % tiles_x, t2 = tile / tiles_x;
+    const int ty = t2 % tiles_y, img = t2 / tiles_y;
+    const int n = img >> 1, eye = img & 1;
+    const int iy0 = 2 * ty * T::TR - 2, xs = 2 * tx * TC - 4;          // staged window origin (xs % 4 == 0)
+    int tq = tid;
+    asm volatile("" : "+v"(tq));
+#pragma unroll
+    for (int e = 0; e < T::NLOAD; ++e) {
+      const int idx = e * 256 + tq;
+      const int c = idx / (T::ROWS * T::NDW);
+      const int rem = idx - c * (T::ROWS * T::NDW);
+      const int r = rem / T::NDW, q = rem - r * T::NDW;
+      const int y = iy0 + r, x = xs + 4 * q;
+      uint32_t v = 0;
+      if (idx < 3 * T::ROWS * T::NDW && (unsigned)y < (unsigned)H) {
+        const int8_t* row = in6 + (((size_t)n * 6 + eye * 3 + c) * H + y) * (size_t)W;
+        if (al4) {
+          if (x >= 0 && x + 3 < W) v = *reinterpret_cast<const uint32_t*>(row + x);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if ((unsigned)(x + k) < (unsigned)W) v |= (uint32_t)(uint8_t)row[x + k] << (8 * k);
+        }
+      }
+      pre[e] = v;
+    }
+  };
+  auto commit = [&](_Float16* buf) {
+    int tq = tid;
+    asm volatile("" : "+v"(tq));
+#pragma unroll
+    for (int e = 0; e < T::NLOAD; ++e) {
+      const int idx = e * 256 + tq;
+      const int c = idx / (T::ROWS * T::NDW);
+      const int rem = idx - c * (T::ROWS * T::NDW);
+      const int r = rem / T::NDW, q = rem - r * T::NDW;
+      if (idx < 3 * T::ROWS * T::NDW) {
+        half4 hv;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) hv[k] = (_Float16)((float)(int8_t)(pre[e] >> (8 * k)) * (1.0f / 128.0f));
+        *reinterpret_cast<half4*>(buf + (c * T::ROWS + r) * T::PITCH + 4 * q) = hv;
+      }
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile >= total) return;
+  fetch(tile);
+  commit(s_x);
+  __syncthreads();
+  int cur = 0;
+  for (; tile < total; tile += gridDim.x) {
+    const int nxt = tile + gridDim.x;
+    if (nxt < total) fetch(nxt);
+    const _Float16* buf = s_x + cur * T::BUF;
+    f32x16 acc0[T::SPW], acc1[T::SPW];
+#pragma unroll
+    for (int s = 0; s < T::SPW; ++s)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc0[s][r] = bv[r];
+        acc1[s][r] = 0.f;
+      }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+#pragma unroll
+      for (int s = 0; s < T::SPW; ++s) {
+        const int seg = wave * T::SPW + s;
+        const int srow = seg / T::CSEG, scol = (seg % T::CSEG) * 32;
+        // input row 2*srow + ky, first column 2*(scol + j) + 2 of the staged window (= ix0 + 2*ox_local)
+        const uint32_t* px = reinterpret_cast<const uint32_t*>(buf + koff[t] + 2 * srow * T::PITCH + 2 * (scol + j) + 2);
+        uint4 xv;
+        xv.x = px[0];
+        xv.y = px[1];
+        xv.z = px[2];
+        xv.w = px[3];
+        const half8 xb = *reinterpret_cast<const half8*>(&xv);
+        acc0[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t], xb, acc0[s], 0, 0, 0);
+        acc1[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[t], xb, acc1[s], 0, 0, 0);
+      }
+    }
+    {
+      const int tx = tile % tiles_x, t2 = tile / tiles_x;
+      const int ty = t2 % tiles_y, img = t2 / tiles_y;
+      const size_t plane_o = (size_t)Ho * Wo;
+#pragma unroll
+      for (int s = 0; s < T::SPW; ++s) {
+        const int seg = wave * T::SPW + s;
+        const int y = ty * T::TR + seg / T::CSEG, x = tx * TC + (seg % T::CSEG) * 32 + j;
+        if (y < Ho && x < Wo) {
+          float* o = out + (size_t)img * kC * plane_o + (size_t)y * Wo + x;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int co = (r & 3) + 8 * (r >> 2) + 4 * g;
+            float v = acc0[s][r] + acc1[s][r] * kSplitInv;
+            if (lrelu) v = v > 0.f ? v : v * kSlope;
+            o[(size_t)co * plane_o] = v;
+          }
+        }
+      }
+    }
+    if (nxt < total) commit(s_x + (cur ^ 1) * T::BUF);
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // K6: final 3x3x3 conv 32->1 fused with soft-argmin.
 //   cost[d] = b + sum_{ci,dz,ky,kx} w[ci][dz][ky][kx] * vol[n][d+dz-1][ci][y+ky-1][x+kx-1]
 //   disp    = sum_d d * softmax_d(-cost)

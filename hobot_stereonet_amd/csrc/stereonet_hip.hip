@@ -45,6 +45,10 @@ struct ConvLayer {
   int cin = 0, cin_pad = 0, taps = 0;
 };
 
+struct Down0F16 {           // first down-conv on the fp16 MFMA (k_down0_f16): 8 K-steps x (hi, lo) A-fragments
+  uint4* wfrag = nullptr;   // device [8][2][64] slots
+};
+
 struct RefLayerF16 {        // fp16 tower layer: 18 MFMA A-fragments + fp32 bias
   uint4* wfrag = nullptr;   // device [9][2][64] slots
   float* bias = nullptr;
@@ -106,6 +110,7 @@ struct sn_handle {
   bool ref_dyn = true;       // dynamic tile queue in the fp16 tower (SN_REF_DYN=0: static stride)
   bool use_graphs = true;    // hipGraph replay for the async single-pair path (SN_NO_GRAPH disables)
   ConvLayer down[kNDown], fres[kNFeatRes][2], fout, agg[kNAgg], rin, rres[kNRefRes][2];
+  Down0F16 down0;
   HeadLayer aout, rout;
   RefLayerF16 rres16[kNRefRes][2];
   RefGeom rg{};
@@ -226,6 +231,38 @@ int upload_x3(sn_handle* h, int cin_virtual, WV wv, ConvLayer* out, int taps = 9
   HIP_TRY(h, dalloc(&out->wx3, pk.size() / 8));
   HIP_TRY(h, hipMemcpy(out->wx3, pk.data(), pk.size() * sizeof(_Float16), hipMemcpyHostToDevice));
   return SN_OK;
+}
+
+// A-fragments of k_down0_f16: K = 8 * rho + kx, rho = ci * 5 + ky (row 15 and kx >= 5 are zero)
+int upload_down0_f16(sn_handle* h, const HostLayer& l, Down0F16* out) {
+  std::vector<_Float16> pk((size_t)8 * 2 * 64 * 8);
+  for (int t = 0; t < 8; ++t)
+    for (int lane = 0; lane < 64; ++lane)
+      for (int e = 0; e < 8; ++e) {
+        const int co = lane & 31, rho = 2 * t + (lane >> 5);
+        const float w = (rho < 15 && e < 5) ? l.w[((size_t)co * 3 + rho / 5) * 25 + (rho % 5) * 5 + e] : 0.f;
+        const _Float16 hi = (_Float16)w;
+        const size_t base = ((size_t)(2 * t) * 64 + lane) * 8 + e;
+        pk[base] = hi;
+        pk[base + 64 * 8] = (_Float16)((w - (float)hi) * kSplitScale);
+      }
+  HIP_TRY(h, dalloc(&out->wfrag, pk.size() / 8));
+  HIP_TRY(h, hipMemcpy(out->wfrag, pk.data(), pk.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+  return SN_OK;
+}
+
+template <int TC>
+hipError_t launch_down0_f16(hipStream_t st, const Down0F16& L, const float* bias, const int8_t* in6, int H, int W,
+                            int nimg, int Ho, int Wo, float* out, int num_cu) {
+  using T = Down0Tile<TC>;
+  const int tiles_x = (Wo + TC - 1) / TC, tiles_y = (Ho + T::TR - 1) / T::TR;
+  const int total = tiles_x * tiles_y * nimg;
+  int blocks = (TC == 64 ? 1 : 2) * num_cu;      // register budget: one (TC = 64) or two workgroups per CU
+  if (blocks > total) blocks = total;
+  const int al4 = (W % 4 == 0) && (reinterpret_cast<uintptr_t>(in6) % 4 == 0);
+  hipLaunchKernelGGL(k_down0_f16<TC>, dim3(blocks), dim3(256), T::LDS_BYTES, st, in6, H, W, L.wfrag, bias, out, Ho, Wo,
+                     tiles_x, tiles_y, nimg, 0, al4);
+  return hipGetLastError();
 }
 
 template <int KS, int STRIDE, int DIL, int TR, int TC, class Loader>
@@ -654,7 +691,13 @@ int lowres(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, const int
   {
     LoadI8Eye ld{in, h->H, h->W};
     const int Ho = Hp / 2, Wo = Wp / 2;
-    if (Ho * Wo <= 64 * 128)
+    if (h->down0.wfrag) {
+      static const bool tc64 = getenv("SN_DOWN0_TC64") != nullptr;     // 8 x 64 tiles: one workgroup per CU
+      if (!tc64)
+        HIP_TRY(h, launch_down0_f16<32>(st, h->down0, h->down[0].bias, in, h->H, h->W, 2 * m, Ho, Wo, ws.down[0], h->num_cu));
+      else
+        HIP_TRY(h, launch_down0_f16<64>(st, h->down0, h->down[0].bias, in, h->H, h->W, 2 * m, Ho, Wo, ws.down[0], h->num_cu));
+    } else if (Ho * Wo <= 64 * 128)
       HIP_TRY(h, (launch_conv<5, 2, 1, 4, 4, 32>(st, h->down[0], ld, 2 * m, Ho, Wo, ws.down[0], nullptr, false)));
     else
       HIP_TRY(h, (launch_conv<5, 2, 1, 4, 8, 64>(st, h->down[0], ld, 2 * m, Ho, Wo, ws.down[0], nullptr, false)));
@@ -965,6 +1008,7 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
   for (int i = 0; i < kNDown; ++i) {
     const HostLayer hl_ = bw.next(kC, i == 0 ? 3 : kC, 25);
     if ((rc = upload_conv2d(h, hl_, 4, &h->down[i]))) return fail(rc);
+    if (low_x3 && i == 0 && getenv("SN_DOWN0_FP32") == nullptr && (rc = upload_down0_f16(h, hl_, &h->down0))) return fail(rc);
     if (low_x3 && i > 0 && getenv("SN_DOWN_FP32") == nullptr &&
         (rc = upload_x3(h, kC, [&](int co, int c, int tap) { return hl_.w[((size_t)co * kC + c) * 25 + tap]; },
                         &h->down[i], 25)))
@@ -1021,6 +1065,7 @@ int sn_destroy(sn_handle* h) {
     hipFree(l.bias);
   };
   for (auto& l : h->down) free_conv(l);
+  hipFree(h->down0.wfrag);
   for (auto& b : h->fres)
     for (auto& l : b) free_conv(l);
   free_conv(h->fout);
@@ -1407,6 +1452,34 @@ int sn_dbg_conv2d(sn_handle* h, const float* in, int cin, int h_px, int w, const
   hipFree(L.wx3);
   hipFree(L.wpk);
   hipFree(L.bias);
+  return SN_OK;
+}
+
+int sn_dbg_down0(sn_handle* h, const int8_t* in6, int h_px, int w, const float* wt, const float* bias, int tc,
+                 float* out) {
+  if (!h || !in6 || !wt || !bias || !out || h_px <= 0 || w <= 0 || (tc != 32 && tc != 64)) return SN_ERR_ARG;
+  int rc = check_device(h);
+  if (rc) return rc;
+  const int Hp = (h_px + 15) / 16 * 16, Wp = (w + 15) / 16 * 16, Ho = Hp / 2, Wo = Wp / 2;
+  Down0F16 L;
+  HostLayer hl{wt, bias, kC, 3, 25};
+  if ((rc = upload_down0_f16(h, hl, &L))) return rc;
+  int8_t* din = nullptr;
+  float *dout = nullptr, *dbias = nullptr;
+  const size_t nin = (size_t)6 * h_px * w, nout = (size_t)2 * kC * Ho * Wo;
+  HIP_TRY(h, dalloc(&din, nin));
+  HIP_TRY(h, dalloc(&dout, nout));
+  HIP_TRY(h, dalloc(&dbias, kC));
+  HIP_TRY(h, hipMemcpy(din, in6, nin, hipMemcpyHostToDevice));
+  HIP_TRY(h, hipMemcpy(dbias, bias, kC * 4, hipMemcpyHostToDevice));
+  HIP_TRY(h, tc == 32 ? launch_down0_f16<32>(h->stream, L, dbias, din, h_px, w, 2, Ho, Wo, dout, h->num_cu)
+                      : launch_down0_f16<64>(h->stream, L, dbias, din, h_px, w, 2, Ho, Wo, dout, h->num_cu));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, hipMemcpy(out, dout, nout * 4, hipMemcpyDeviceToHost));
+  hipFree(din);
+  hipFree(dout);
+  hipFree(dbias);
+  hipFree(L.wfrag);
   return SN_OK;
 }
 

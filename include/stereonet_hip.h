@@ -144,6 +144,11 @@ int sn_get_dominant_kernel(sn_handle *h, char *name, size_t name_cap, int *launc
 int sn_dbg_conv2d(sn_handle *h, const float *in, int cin, int h_px, int w, const float *wt,
                   const float *bias, int k, int stride, int dil, int lrelu, const float *residual,
                   float *out);
+/* the first down-conv (3->32, 5x5, stride 2, no activation) of both eyes through the fp16-MFMA kernel of the fp16
+ * modes: in6 int8 [6][h][w] (model input), wt [32][3][5][5], out [2][32][ho][wo] with ho/wo = ceil16(h|w)/2;
+ * tc = 32 or 64 selects the tile width */
+int sn_dbg_down0(sn_handle *h, const int8_t *in6, int h_px, int w, const float *wt, const float *bias, int tc,
+                 float *out);
 /* one 3x3x3 32->32 conv3d (+bias, optional LeakyReLU): in [32][d][h][w] -> out [32][d][h][w] */
 int sn_dbg_conv3d(sn_handle *h, const float *in, int d, int h_px, int w, const float *wt,
                   const float *bias, int lrelu, float *out);

@@ -180,3 +180,24 @@ def test_full_size_epe_f16x3(model_factory, oracle, weights_blob):
     epe = float(np.abs(disp[0] - odisp).mean())
     print(f"f16x3 tower EPE vs oracle: {epe:.3e} px (max {np.abs(disp[0] - odisp).max():.3e})")
     assert epe < 2e-4
+
+
+@pytest.mark.parametrize("h,w,tc", [(32, 64, 32), (64, 96, 64), (96, 160, 32), (52, 100, 32), (52, 102, 64),
+                                    (90, 130, 32), (720, 1280, 32), (720, 1280, 64)])
+def test_down0_f16_kernel(eng16, oracle, h, w, tc):
+    """First down-conv (3->32, 5x5, stride 2) on the fp16 MFMA with densely packed K: the int8 input / 128 is
+    exact in fp16 and the weights are split hi/lo (22 bits), so it must match the fp32 oracle to fp32 round-off
+    of a 75-term sum; ragged sizes exercise the byte-load path (w % 4 != 0) and the padded output region."""
+    rng = np.random.default_rng(h * 7 + w + tc)
+    x = rng.integers(-128, 128, (6, h, w), dtype=np.int8)
+    wt = (rng.standard_normal((32, 3, 5, 5)) / 8.0).astype(np.float32)
+    b = rng.standard_normal(32).astype(np.float32)
+    got = eng16.dbg_down0(x, wt, b, tc)
+    hp, wp = (h + 15) // 16 * 16, (w + 15) // 16 * 16
+    assert got.shape == (2, 32, hp // 2, wp // 2)
+    for eye in range(2):
+        xin = np.zeros((3, hp, wp), np.float32)               # the padded region is zero input (as in the pipeline)
+        xin[:, :h, :w] = x[3 * eye:3 * eye + 3].astype(np.float32) / 128.0
+        ref = oracle.conv2d(xin, wt, b, 2, 2, 1)
+        assert ref.shape == got[eye].shape
+        assert np.abs(got[eye] - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
