@@ -82,6 +82,7 @@ def load_library(path: Optional[str] = None):
                                            C.POINTER(C.c_double)]
     lib.sn_dbg_conv2d.argtypes = [vp, fp, ip, ip, ip, fp, fp, ip, ip, ip, ip, fp, fp]
     lib.sn_dbg_down0.argtypes = [vp, i8p, ip, ip, fp, fp, ip, fp]
+    lib.sn_dbg_refin.argtypes = [vp, fp, i8p, ip, ip, ip, fp, fp, ip, fp]
     lib.sn_dbg_conv3d.argtypes = [vp, fp, ip, ip, ip, fp, fp, ip, fp]
     lib.sn_dbg_ref_conv_f16.argtypes = [vp, fp, ip, ip, fp, fp, ip, ip, fp, fp]
     lib.sn_dbg_ref_conv_f16x3.argtypes = [vp, fp, ip, ip, fp, fp, ip, ip, fp, fp]
@@ -89,7 +90,7 @@ def load_library(path: Optional[str] = None):
     lib.sn_dbg_read.argtypes = [vp, C.c_char_p, fp, C.c_size_t, C.POINTER(C.c_size_t)]
     for name in ("sn_create", "sn_destroy", "sn_get_io_info", "sn_infer_i8", "sn_infer_batch", "sn_preprocess_nv12",
                  "sn_infer_sbs_nv12", "sn_submit", "sn_wait", "sn_synchronize", "sn_set_profiling",
-                 "sn_get_stage_ms", "sn_get_dominant_kernel", "sn_dbg_conv2d", "sn_dbg_down0", "sn_dbg_conv3d", "sn_dbg_ref_conv_f16", "sn_dbg_ref_conv_f16x3", "sn_dbg_ref_block_f16", "sn_dbg_read"):
+                 "sn_get_stage_ms", "sn_get_dominant_kernel", "sn_dbg_conv2d", "sn_dbg_down0", "sn_dbg_refin", "sn_dbg_conv3d", "sn_dbg_ref_conv_f16", "sn_dbg_ref_conv_f16x3", "sn_dbg_ref_block_f16", "sn_dbg_read"):
         getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
@@ -248,6 +249,20 @@ class StereoNetHIP:
         out = np.empty((2, 32, ho, wo), np.float32)
         self._check(self._lib.sn_dbg_down0(self._h, x.ctypes.data, h, w, wt.ctypes.data, bias.ctypes.data, tc,
                                            out.ctypes.data), "sn_dbg_down0")
+        return out
+
+    def dbg_refin(self, disp_low, in6, dmax, wt, bias, split=False):
+        """disp_low float32 (hp/16, wp/16), in6 int8 (6,h,w) -> float32 (32, hp, wp): refinement input conv."""
+        x = np.ascontiguousarray(in6, np.int8)
+        dl = np.ascontiguousarray(disp_low, np.float32)
+        wt = np.ascontiguousarray(wt, np.float32)
+        bias = np.ascontiguousarray(bias, np.float32)
+        _, h, w = x.shape
+        hp, wp = (h + 15) // 16 * 16, (w + 15) // 16 * 16
+        assert dl.shape == (hp // 16, wp // 16)
+        out = np.empty((32, hp, wp), np.float32)
+        self._check(self._lib.sn_dbg_refin(self._h, dl.ctypes.data, x.ctypes.data, h, w, dmax, wt.ctypes.data,
+                                           bias.ctypes.data, int(split), out.ctypes.data), "sn_dbg_refin")
         return out
 
     def dbg_conv3d(self, x, wt, bias, lrelu=False, x3=False):

@@ -2047,6 +2047,185 @@ __global__ __launch_bounds__(256, 1) void k_ref_conv_f16x3(const uint4* __restri
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// K7a: refinement input conv (4 -> 32, 3x3, LeakyReLU) for the fp16 modes, writing the tower's NCHW8c tensor.
+// Inputs are produced on the fly: channel 0 = bilinear x16 upsample of the low-resolution disparity / D (a float,
+// carried as an fp16 hi/lo pair), channels 1..3 = left-eye int8 planes / 128 (exact in fp16).  The generic
+// implicit GEMM ran this K = 36 layer on the exact-fp32 MFMA (18 x 64 cycles per 32 pixels) behind a scalar
+// per-element loader.  Here every staged pixel is ONE 16-byte LDS slot
+//     [d_hi, Y, U, V, d_lo, 0, 0, 0]                       (K packing: k = 8 * tap + slot entry)
+// so the B fragment of lane (pixel j, k-group g) at K-step t is a single aligned ds_read_b128 of the slot of tap
+// 2t + g (tap 9 = zero weights), and the layer is 5 K-steps x 2 fp16 MFMAs = 320 matrix cycles per 32 pixels:
+//     acc0 += [wh_d, wh_Y, wh_U, wh_V, 0, ...] . slot        acc1 += [wl_d, wl_Y, wl_U, wl_V, wh_d, 0, ...] . slot
+//     out   = lrelu(acc0 + acc1 / 2048 + bias)               (w = wh + wl / 2048, d = d_hi + d_lo / 2048)
+// Staging: one thread builds 4 consecutive pixels (three aligned dword loads of int8 + four upsample evaluations)
+// for the next tile while the MFMAs of the current one run; persistent workgroups, LDS double buffered.
+// SPLIT = true writes the hi/lo pair of tensors of SN_PREC_F16X3.
+// ------------------------------------------------------------------------------------------
+struct RefInTile {
+  static constexpr int TH = 8, TW = 64;
+  static constexpr int ROWS = TH + 2, COLS = TW + 8;        // staged window starts 4 px left of the tile (dword aligned)
+  static constexpr int BUF = ROWS * COLS;                   // slots per buffer
+  static constexpr int LDS_BYTES = 2 * BUF * 16;
+  static constexpr int NUNIT = ROWS * (COLS / 4);           // 4-pixel staging units per tile (180 <= 256 threads)
+  static constexpr int SPW = TH * (TW / 32) / 4;
+};
+
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void k_refin_f16(const float* __restrict__ disp_low,   // [n][hl][wl]
+                                                   const int8_t* __restrict__ in6,       // [n][6][H][W]
+                                                   int hl, int wl, int H, int W, float inv_d,
+                                                   const uint4* __restrict__ wfrag,      // [5][a|b][64]
+                                                   const float* __restrict__ bias, uint4* __restrict__ out,
+                                                   size_t lo_off_bytes, RefGeom g, int nimg, int al4) {
+  using T = RefInTile;
+  static_assert(T::NUNIT <= 256, "one staging unit per thread");
+  extern __shared__ __attribute__((aligned(16))) uint4 s_px[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, gk = lane >> 5;
+
+  half8 wa[5], wb[5];
+#pragma unroll
+  for (int t = 0; t < 5; ++t) {
+    const uint4 a = wfrag[(2 * t) * 64 + lane], b = wfrag[(2 * t + 1) * 64 + lane];
+    wa[t] = *reinterpret_cast<const half8*>(&a);
+    wb[t] = *reinterpret_cast<const half8*>(&b);
+  }
+  float bv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bv[r] = bias[(r & 3) + 8 * (r >> 2) + 4 * gk];
+  int koff[5];                               // slot offset of tap 2t + g inside the staged window
+#pragma unroll
+  for (int t = 0; t < 5; ++t) {
+    int tap = 2 * t + gk;
+    tap = tap < 9 ? tap : 0;
+    koff[t] = (tap / 3) * T::COLS + (tap % 3) + 3;
+  }
+
+  const int per_img = g.tiles_x * g.tiles_y;
+  const int total = per_img * nimg;
+  // staging unit of this thread: row ur of the window, pixels 4*uq .. 4*uq+3
+  const int ur = tid / (T::COLS / 4), uq = tid - ur * (T::COLS / 4);
+  const bool unit = tid < T::NUNIT;
+  uint32_t pimg[3];
+  float pd[4];
+  bool pval[4];
+  auto fetch = [&](int tile) {
+    const int img = tile / per_img, rem = tile - img * per_img;
+    const int ty = rem / g.tiles_x, tx = rem - ty * g.tiles_x;
+    const int y = ty * T::TH - 1 + ur, x = tx * T::TW - 4 + 4 * uq;
+    pimg[0] = pimg[1] = pimg[2] = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      pd[k] = 0.f;
+      pval[k] = false;
+    }
+    if (!unit || (unsigned)y >= (unsigned)g.H) return;
+    const float* dl = disp_low + (size_t)img * hl * wl;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      pval[k] = (unsigned)(x + k) < (unsigned)g.W;
+      if (pval[k]) pd[k] = upsample16(dl, hl, wl, y, x + k) * inv_d;
+    }
+    if (y < H) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int8_t* row = in6 + (((size_t)img * 6 + c) * H + y) * (size_t)W;
+        uint32_t v = 0;
+        if (al4) {
+          if (x >= 0 && x + 3 < W) v = *reinterpret_cast<const uint32_t*>(row + x);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if ((unsigned)(x + k) < (unsigned)W) v |= (uint32_t)(uint8_t)row[x + k] << (8 * k);
+        }
+        pimg[c] = v;
+      }
+    }
+  };
+  auto commit = [&](uint4* buf) {
+    if (!unit) return;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      half8 sl;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sl[e] = (_Float16)0.f;
+      if (pval[k]) {
+        const _Float16 dh = (_Float16)pd[k];
+        sl[0] = dh;
+        sl[4] = (_Float16)((pd[k] - (float)dh) * kSplitScale);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) sl[1 + c] = (_Float16)((float)(int8_t)(pimg[c] >> (8 * k)) * (1.0f / 128.0f));
+      }
+      buf[ur * T::COLS + 4 * uq + k] = *reinterpret_cast<const uint4*>(&sl);
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile >= total) return;
+  fetch(tile);
+  commit(s_px);
+  __syncthreads();
+  int cur = 0;
+  const unsigned plane_b = (unsigned)g.Hs * (unsigned)g.Ws * 16u;
+  for (; tile < total; tile += gridDim.x) {
+    const int nxt = tile + gridDim.x;
+    if (nxt < total) fetch(nxt);
+    const uint4* buf = s_px + cur * T::BUF;
+    f32x16 acc0[T::SPW], acc1[T::SPW];
+#pragma unroll
+    for (int s = 0; s < T::SPW; ++s)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc0[s][r] = bv[r];
+        acc1[s][r] = 0.f;
+      }
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+#pragma unroll
+      for (int s = 0; s < T::SPW; ++s) {
+        const int seg = wave * T::SPW + s;
+        const int srow = seg >> 1, scol = (seg & 1) * 32;
+        const uint4 xv = buf[koff[t] + srow * T::COLS + scol + j];
+        const half8 xb = *reinterpret_cast<const half8*>(&xv);
+        acc0[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[t], xb, acc0[s], 0, 0, 0);
+        acc1[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[t], xb, acc1[s], 0, 0, 0);
+      }
+    }
+    {
+      const int img = tile / per_img, rem = tile - img * per_img;
+      const int ty = rem / g.tiles_x, tx = rem - ty * g.tiles_x;
+#pragma unroll
+      for (int s = 0; s < T::SPW; ++s) {
+        const int seg = wave * T::SPW + s;
+        const int y = ty * T::TH + (seg >> 1), x = tx * T::TW + (seg & 1) * 32 + j;
+        if (y < g.H && x < g.W) {
+          char* o = reinterpret_cast<char*>(out) +
+                    ((((size_t)img * 4) * g.Hs + (y + kRefPad)) * g.Ws + (x + kRefPad)) * 16 + gk * 8;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            half4 hh, hl4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float v = acc0[s][4 * q + e] + acc1[s][4 * q + e] * kSplitInv;
+              v = lrelu_fast(v);
+              const _Float16 hi = (_Float16)v;
+              hh[e] = hi;
+              if (SPLIT) hl4[e] = (_Float16)((v - (float)hi) * kSplitScale);
+            }
+            *reinterpret_cast<half4*>(o + (size_t)q * plane_b) = hh;
+            if (SPLIT) *reinterpret_cast<half4*>(o + (size_t)q * plane_b + lo_off_bytes) = hl4;
+          }
+        }
+      }
+    }
+    if (nxt < total) commit(s_px + (cur ^ 1) * T::BUF);
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
 // K8 for the fp16 tower: 3x3 conv 32->1 on the NCHW8c tensor, disp = relu(up + D*r), outputs as k_head_final.
 template <bool SPLIT>
 __global__ __launch_bounds__(256) void k_head_final_f16(const uint4* __restrict__ xin, size_t lo_slots, RefGeom g,

@@ -110,7 +110,7 @@ struct sn_handle {
   bool ref_dyn = true;       // dynamic tile queue in the fp16 tower (SN_REF_DYN=0: static stride)
   bool use_graphs = true;    // hipGraph replay for the async single-pair path (SN_NO_GRAPH disables)
   ConvLayer down[kNDown], fres[kNFeatRes][2], fout, agg[kNAgg], rin, rres[kNRefRes][2];
-  Down0F16 down0;
+  Down0F16 down0, refin;
   HeadLayer aout, rout;
   RefLayerF16 rres16[kNRefRes][2];
   RefGeom rg{};
@@ -249,6 +249,45 @@ int upload_down0_f16(sn_handle* h, const HostLayer& l, Down0F16* out) {
   HIP_TRY(h, dalloc(&out->wfrag, pk.size() / 8));
   HIP_TRY(h, hipMemcpy(out->wfrag, pk.data(), pk.size() * sizeof(_Float16), hipMemcpyHostToDevice));
   return SN_OK;
+}
+
+// A-fragments of k_refin_f16: K = 8 * tap + e over the pixel slot [d_hi, Y, U, V, d_lo, 0, 0, 0];
+// fragment a = hi weights on (d_hi, Y, U, V); fragment b = lo weights on the same entries + hi(w_d) on d_lo
+int upload_refin_f16(sn_handle* h, const HostLayer& l, Down0F16* out) {
+  std::vector<_Float16> pk((size_t)5 * 2 * 64 * 8, (_Float16)0.f);
+  for (int t = 0; t < 5; ++t)
+    for (int lane = 0; lane < 64; ++lane) {
+      const int co = lane & 31, tap = 2 * t + (lane >> 5);
+      if (tap >= 9) continue;
+      _Float16* a = &pk[((size_t)(2 * t) * 64 + lane) * 8];
+      _Float16* b = a + 64 * 8;
+      for (int c = 0; c < 4; ++c) {
+        const float w = l.w[((size_t)co * 4 + c) * 9 + tap];
+        const _Float16 hi = (_Float16)w;
+        a[c] = hi;
+        b[c] = (_Float16)((w - (float)hi) * kSplitScale);
+        if (c == 0) b[4] = hi;
+      }
+    }
+  HIP_TRY(h, dalloc(&out->wfrag, pk.size() / 8));
+  HIP_TRY(h, hipMemcpy(out->wfrag, pk.data(), pk.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+  return SN_OK;
+}
+
+hipError_t launch_refin_f16(hipStream_t st, const Down0F16& L, const float* bias, const float* disp_low,
+                            const int8_t* in6, int hl, int wl, int H, int W, float inv_d, const RefGeom& g, int nimg,
+                            uint4* out, bool split, size_t lo_off_bytes, int num_cu) {
+  const int total = g.tiles_x * g.tiles_y * nimg;
+  int blocks = 2 * num_cu;
+  if (blocks > total) blocks = total;
+  const int al4 = (W % 4 == 0) && (reinterpret_cast<uintptr_t>(in6) % 4 == 0);
+  if (split)
+    hipLaunchKernelGGL(k_refin_f16<true>, dim3(blocks), dim3(256), RefInTile::LDS_BYTES, st, disp_low, in6, hl, wl, H, W,
+                       inv_d, L.wfrag, bias, out, lo_off_bytes, g, nimg, al4);
+  else
+    hipLaunchKernelGGL(k_refin_f16<false>, dim3(blocks), dim3(256), RefInTile::LDS_BYTES, st, disp_low, in6, hl, wl, H, W,
+                       inv_d, L.wfrag, bias, out, lo_off_bytes, g, nimg, al4);
+  return hipGetLastError();
 }
 
 template <int TC>
@@ -774,7 +813,10 @@ int refine(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, const int
       const RefGeom& g = h->rg;
       const bool x3 = h->precision == SN_PREC_F16X3;
       const size_t lo_slots = ref16_slots(g, ws.rb) + kRefSlack;       // hi tensor -> lo tensor (F16X3)
-      if (x3) {
+      if (h->refin.wfrag) {
+        HIP_TRY(h, launch_refin_f16(st, h->refin, h->rin.bias, ws.disp_low + (size_t)q0 * hl * wl, in6 + (size_t)q0 * 6 * HW,
+                                    hl, wl, h->H, h->W, 1.0f / (float)h->D, g, c, rx, x3, lo_slots * 16, h->num_cu));
+      } else if (x3) {
         if (Hp * Wp <= 64 * 128)
           HIP_TRY(h, (launch_conv<3, 1, 1, 4, 4, 32, LoadRefineIn, 2>(st, h->rin, ld, c, Hp, Wp, reinterpret_cast<float*>(rx),
                                                                     nullptr, true, g.Hs, g.Ws, lo_slots * 16)));
@@ -1035,7 +1077,12 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
       return fail(rc);
   }
   if ((rc = upload_head(h, bw.next(1, kC, 27), &h->aout))) return fail(rc);
-  if ((rc = upload_conv2d(h, bw.next(kC, 4, 9), 4, &h->rin))) return fail(rc);
+  {
+    const HostLayer hl_ = bw.next(kC, 4, 9);
+    if ((rc = upload_conv2d(h, hl_, 4, &h->rin))) return fail(rc);
+    if (h->precision != SN_PREC_FP32 && getenv("SN_REFIN_FP32") == nullptr && (rc = upload_refin_f16(h, hl_, &h->refin)))
+      return fail(rc);
+  }
   for (int i = 0; i < kNRefRes; ++i)
     for (int j = 0; j < 2; ++j) {
       const HostLayer hl_ = bw.next(kC, kC, 9);
@@ -1066,6 +1113,7 @@ int sn_destroy(sn_handle* h) {
   };
   for (auto& l : h->down) free_conv(l);
   hipFree(h->down0.wfrag);
+  hipFree(h->refin.wfrag);
   for (auto& b : h->fres)
     for (auto& l : b) free_conv(l);
   free_conv(h->fout);
@@ -1479,6 +1527,59 @@ int sn_dbg_down0(sn_handle* h, const int8_t* in6, int h_px, int w, const float* 
   hipFree(din);
   hipFree(dout);
   hipFree(dbias);
+  hipFree(L.wfrag);
+  return SN_OK;
+}
+
+int sn_dbg_refin(sn_handle* h, const float* disp_low, const int8_t* in6, int h_px, int w, int dmax, const float* wt,
+                 const float* bias, int split, float* out) {
+  if (!h || !disp_low || !in6 || !wt || !bias || !out || h_px <= 0 || w <= 0 || dmax <= 0) return SN_ERR_ARG;
+  int rc = check_device(h);
+  if (rc) return rc;
+  const int Hp = (h_px + 15) / 16 * 16, Wp = (w + 15) / 16 * 16, hl = Hp / 16, wl = Wp / 16;
+  const RefGeom g = make_ref_geom(Hp, Wp);
+  const size_t slots = ref16_slots(g, 1) + kRefSlack;
+  Down0F16 L;
+  HostLayer hl_{wt, bias, kC, 4, 9};
+  if ((rc = upload_refin_f16(h, hl_, &L))) return rc;
+  float *ddl = nullptr, *dbias = nullptr;
+  int8_t* din = nullptr;
+  uint4* dout = nullptr;
+  HIP_TRY(h, dalloc(&ddl, (size_t)hl * wl));
+  HIP_TRY(h, dalloc(&dbias, kC));
+  HIP_TRY(h, dalloc(&din, (size_t)6 * h_px * w));
+  HIP_TRY(h, dalloc(&dout, 2 * slots));
+  HIP_TRY(h, hipMemcpy(ddl, disp_low, (size_t)hl * wl * 4, hipMemcpyHostToDevice));
+  HIP_TRY(h, hipMemcpy(dbias, bias, kC * 4, hipMemcpyHostToDevice));
+  HIP_TRY(h, hipMemcpy(din, in6, (size_t)6 * h_px * w, hipMemcpyHostToDevice));
+  HIP_TRY(h, hipMemset(dout, 0, 2 * slots * 16));
+  HIP_TRY(h, launch_refin_f16(h->stream, L, dbias, ddl, din, hl, wl, h_px, w, 1.0f / (float)dmax, g, 1, dout, split != 0,
+                              slots * 16, h->num_cu));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  std::vector<_Float16> hout(2 * slots * 8);
+  HIP_TRY(h, hipMemcpy(hout.data(), dout, 2 * slots * 16, hipMemcpyDeviceToHost));
+  for (int c = 0; c < kC; ++c)
+    for (int y = 0; y < Hp; ++y)
+      for (int x = 0; x < Wp; ++x) {
+        const size_t i = ((((size_t)(c >> 3)) * g.Hs + y + kRefPad) * g.Ws + x + kRefPad) * 8 + (c & 7);
+        float v = (float)hout[i];
+        if (split) v += (float)hout[i + slots * 8] * kSplitInv;
+        out[((size_t)c * Hp + y) * Wp + x] = v;
+      }
+  for (int c = 0; c < 4; ++c)       // the zero border must have survived
+    for (int y = 0; y < g.Hs; ++y)
+      for (int x = 0; x < g.Ws; ++x) {
+        if (y >= kRefPad && y < kRefPad + Hp && x >= kRefPad && x < kRefPad + Wp) continue;
+        for (int e = 0; e < 8; ++e)
+          if ((float)hout[(((size_t)c * g.Hs + y) * g.Ws + x) * 8 + e] != 0.f) {
+            set_err(h, "ref.in wrote into the zero border");
+            return SN_ERR_DEVICE;
+          }
+      }
+  hipFree(ddl);
+  hipFree(dbias);
+  hipFree(din);
+  hipFree(dout);
   hipFree(L.wfrag);
   return SN_OK;
 }

@@ -149,6 +149,12 @@ int sn_dbg_conv2d(sn_handle *h, const float *in, int cin, int h_px, int w, const
  * tc = 32 or 64 selects the tile width */
 int sn_dbg_down0(sn_handle *h, const int8_t *in6, int h_px, int w, const float *wt, const float *bias, int tc,
                  float *out);
+/* the refinement input conv (4->32, 3x3, LeakyReLU) through the fp16-MFMA kernel of the fp16 modes:
+ * disp_low fp32 [hp/16][wp/16] (full-resolution px / 16 units as the soft-argmin head writes it), in6 int8 [6][h][w],
+ * wt [32][4][3][3]; out fp32 [32][hp][wp] (hp/wp = ceil16) read back from the fp16 NCHW8c tensor(s); split != 0
+ * selects the hi/lo output of SN_PREC_F16X3 */
+int sn_dbg_refin(sn_handle *h, const float *disp_low, const int8_t *in6, int h_px, int w, int dmax,
+                 const float *wt, const float *bias, int split, float *out);
 /* one 3x3x3 32->32 conv3d (+bias, optional LeakyReLU): in [32][d][h][w] -> out [32][d][h][w] */
 int sn_dbg_conv3d(sn_handle *h, const float *in, int d, int h_px, int w, const float *wt,
                   const float *bias, int lrelu, float *out);

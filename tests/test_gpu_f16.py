@@ -201,3 +201,30 @@ def test_down0_f16_kernel(eng16, oracle, h, w, tc):
         ref = oracle.conv2d(xin, wt, b, 2, 2, 1)
         assert ref.shape == got[eye].shape
         assert np.abs(got[eye] - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("h,w,split", [(32, 64, False), (64, 96, True), (52, 100, False), (90, 130, True),
+                                       (96, 160, False), (720, 1280, False), (720, 1280, True)])
+def test_refin_f16_kernel(eng16, oracle, h, w, split):
+    """Refinement input conv (4->32, 3x3, LeakyReLU) with the upsample / int8 planes produced in the loader:
+    fp16 MFMA over 16-byte pixel slots [d_hi, Y, U, V, d_lo, 0, 0, 0] with split weights -> 22-bit operands.
+    The fp16 (or hi/lo) output tensor is compared with the fp32 oracle of the same layer."""
+    rng = np.random.default_rng(h * 13 + w + int(split))
+    dmax = 96
+    hp, wp = (h + 15) // 16 * 16, (w + 15) // 16 * 16
+    x = rng.integers(-128, 128, (6, h, w), dtype=np.int8)
+    dlow = (rng.random((hp // 16, wp // 16)) * (dmax / 16.0)).astype(np.float32)
+    wt = (rng.standard_normal((32, 4, 3, 3)) / 4.0).astype(np.float32)
+    b = rng.standard_normal(32).astype(np.float32)
+    got = eng16.dbg_refin(dlow, x, dmax, wt, b, split)
+    in4 = np.zeros((4, hp, wp), np.float32)
+    in4[0] = oracle.upsample_bilinear(dlow, 16, 16.0) / np.float32(dmax)
+    in4[1:, :h, :w] = x[:3].astype(np.float32) / 128.0
+    ref = oracle.conv2d(in4, wt, b, 1, 1, 1)
+    ref = np.where(ref > 0, ref, ref * np.float32(0.2))
+    scale = max(1.0, np.abs(ref).max())
+    if split:
+        assert np.abs(got - ref).max() <= 3e-6 * scale + 1e-6      # 22-bit operands and a 22-bit output pair
+    else:
+        assert np.abs(got - q16(ref)).max() <= 1e-3 * scale        # one fp16 output rounding (+ ties)
+        assert np.abs(got - ref).mean() < 2e-4 * scale
