@@ -33,6 +33,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + idx;
 }
 
+// Workgroup barrier for persistent kernels whose waves have global stores / prefetch loads in flight:
+// __syncthreads() also drains vmcnt, i.e. every tile would wait for its predecessor's stores to be acknowledged.
+// This one only retires the wave's own LDS traffic (lgkmcnt) before the s_barrier.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 // ------------------------------------------------------------------------------------------
 // K0: NV12 pair -> int8 NCHW 6xHxW, bit-exact with preprocess.cpp:975-1056.
 // The reference indexes the chroma as planar I420 (preprocess.h:131-133): "U" = in + w*h,
@@ -86,6 +95,17 @@ struct LoadF32 {            // plain NCHW fp32 tensor [nimg][C][H][W]
     if ((unsigned)y >= (unsigned)H || (unsigned)x >= (unsigned)W || c >= C) return 0.f;
     return p[(((unsigned)img * C + c) * H + y) * W + x];      // 32-bit index: tensors are < 2^32 elements (host check)
   }
+  // vector staging (k_conv_x3s): base of the 8-channel block cb at (y, x) = (0, 0) and the channel stride;
+  // false = the whole block is zero padding
+  static constexpr bool kVec = true;
+  static constexpr bool kSlots = false;
+  __device__ __forceinline__ bool slot_base(int, int, const uint4*&) const { return false; }
+  __device__ __forceinline__ bool vec_aligned() const { return ((size_t)p & 3) == 0; }
+  __device__ __forceinline__ bool cb_base(int img, int cb, const float*& base, unsigned& cstride) const {
+    cstride = (unsigned)H * W;
+    base = p + ((size_t)img * C + 8 * cb) * cstride;
+    return 8 * cb < C;
+  }
 };
 
 struct LoadI8Eye {          // model input int8 [n][6][H][W]; image = n*2 + eye; 3 real channels
@@ -111,6 +131,17 @@ struct LoadVol3D {
       return 0.f;
     return p[((((unsigned)n * Dl + dd) * kC + ci) * H + y) * W + x];
   }
+  static constexpr bool kVec = true;
+  static constexpr bool kSlots = false;
+  __device__ __forceinline__ bool slot_base(int, int, const uint4*&) const { return false; }
+  __device__ __forceinline__ bool vec_aligned() const { return ((size_t)p & 3) == 0; }
+  __device__ __forceinline__ bool cb_base(int img, int cb, const float*& base, unsigned& cstride) const {
+    const int n = img / Dl, d = img - n * Dl;
+    const int dd = d + (cb >> 2) - 1;
+    cstride = (unsigned)H * W;
+    base = p + (((size_t)n * Dl + dd) * kC + 8 * (cb & 3)) * cstride;
+    return (unsigned)dd < (unsigned)Dl;
+  }
 };
 
 // Same, but the volume is the cost volume computed on the fly from the two feature maps:
@@ -129,7 +160,44 @@ struct LoadCostVol {
     const unsigned li = ((unsigned)(2 * n) * kC + ci) * plane + (unsigned)y * W + x;
     return feat[li] - feat[li + kC * plane - dd];
   }
+  static constexpr bool kVec = false;        // two differently aligned reads per element: scalar staging
+  static constexpr bool kSlots = false;
+  __device__ __forceinline__ bool slot_base(int, int, const uint4*&) const { return false; }
+  __device__ __forceinline__ bool vec_aligned() const { return false; }
+  __device__ __forceinline__ bool cb_base(int, int, const float*&, unsigned&) const { return false; }
 };
+
+// Split-slot activations of the low-resolution branch (fp16 modes): [image][channel block (4)][hi | lo][H][W]
+// 16-byte slots of 8 fp16 channels, v = hi + lo / 2048 (the operand format of the split-operand MFMAs, produced by
+// the previous layer's epilogue instead of being re-derived from fp32 in every consumer's staging loop).
+// Same bytes per element as fp32 NCHW, but a halo row of a tile is ONE contiguous run per (block, part) instead
+// of eight 4-byte-strided plane reads, and staging is a plain 16-byte copy.  Dl > 0: the tensor is a volume
+// [n][Dl] of such images and the virtual block vb = dz * 4 + cb reads plane d + dz - 1 (3-D convolution).
+struct SlotIn {
+  const uint4* p;
+  int Dl, H, W;
+  static constexpr bool kVec = false;
+  static constexpr bool kSlots = true;
+  __device__ __forceinline__ bool vec_aligned() const { return false; }
+  __device__ __forceinline__ float operator()(int, int, int, int) const { return 0.f; }
+  __device__ __forceinline__ bool cb_base(int, int, const float*&, unsigned&) const { return false; }
+  // hi plane of virtual block vb of image img (lo plane = hi + H * W); false = zero padding plane
+  __device__ __forceinline__ bool slot_base(int img, int vb, const uint4*& hi) const {
+    int image = img, cb = vb;
+    if (Dl > 0) {
+      const int n = img / Dl, d = img - n * Dl;
+      const int dd = d + (vb >> 2) - 1;
+      if ((unsigned)dd >= (unsigned)Dl) return false;
+      image = n * Dl + dd;
+      cb = vb & 3;
+    }
+    hi = p + ((size_t)image * 4 + cb) * 2 * ((size_t)H * W);
+    return true;
+  }
+};
+__device__ __forceinline__ size_t low_slot_index(int img, int cb, int part, int y, int x, int H, int W) {
+  return ((((size_t)img * 4 + cb) * 2 + part) * H + y) * (size_t)W + x;
+}
 
 // bilinear x16, align_corners=False, values x16 (disparity in full-res px)
 __device__ __forceinline__ float upsample16(const float* low, int hl, int wl, int y, int x) {
@@ -540,6 +608,354 @@ __global__ __launch_bounds__(256) void k_conv_c32_x3(ConvArgs a, Loader ld) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Weights-stationary split-operand implicit GEMM for the LOW-RESOLUTION layers of the fp16 modes (second
+// generation of k_conv_c32_x3; same operands, same arithmetic: three fp16 MFMAs per product on hi/lo pairs).
+// k_conv_c32_x3 re-reads the A fragments of every tap for every 32-pixel segment (5x5: 51 KB of weights per wave
+// and 16-channel chunk through L1/L2 for 75 MFMAs) and is bound by that traffic.  Here
+//   * the workgroup is persistent and each wave keeps ITS weights in registers for the whole launch: K is split
+//     across the two wave pairs by virtual channel halves (waves 0,1: channels [0, VCH/2), waves 2,3: the rest),
+//     so a wave holds TAPS * VCH/32 K-steps x (hi, lo) fragments (5x5 C=32: 200 VGPRs, 3x3x3: 216, 3x3: 72);
+//   * the whole VCH-channel halo tile is staged once per tile (fp32 loads one tile ahead in registers, split to
+//     hi/lo and committed as 16-byte pixel slots), each wave pair works on its own channel blocks of it;
+//   * the two K-halves of a segment are summed through LDS: a wave owns one of its pair-partner's two segments,
+//     writes the partial of the other one, reads the partner's, and finishes (bias, residual, LeakyReLU, store).
+// A segment is 32 output pixels = (32 / SEGW) rows x SEGW columns (SEGW = 16 tiles an 80-column map exactly).
+// Inputs/outputs stay fp32 NCHW in HBM; Loader supplies zero padding and the virtual-channel mapping.
+// ------------------------------------------------------------------------------------------
+template <int KS, int STRIDE, int VCH, int TR, int TC, int SEGW>
+struct X3sTile {
+  static constexpr int TAPS = KS * KS;
+  static constexpr int NCB = VCH / 8, HCB = NCB / 2, NKC = HCB / 2, NK = TAPS * NKC;
+  static constexpr int SEGH = 32 / SEGW;
+  static constexpr int NSEG = (TR / SEGH) * (TC / SEGW), SPW = NSEG / 2;
+  static constexpr int ROWS_IN = (TR - 1) * STRIDE + KS;
+  static constexpr int COLS_IN = (TC - 1) * STRIDE + KS;
+  static constexpr int HALF = (COLS_IN + 1) / 2;
+  static constexpr int PITCH = STRIDE == 1 ? COLS_IN : 2 * HALF;
+  static constexpr int PLANE = ROWS_IN * PITCH;
+  static constexpr int NSLOT = NCB * ROWS_IN * COLS_IN;
+  static constexpr int SPT = (NSLOT + 255) / 256;
+  // vector staging: rows are read as float4 quads from the first halo column (global_load_dwordx4 only needs
+  // 4-byte alignment); a quad that straddles the image border falls back to per-element loads
+  static constexpr int SH = 0;
+  static constexpr int NQ = (SH + COLS_IN + 3) / 4;
+  static constexpr int NU = NCB * ROWS_IN * NQ;
+  static constexpr int UPT = (NU + 255) / 256;
+  static constexpr int RED_FLOATS = 4 * 16 * 64;           // one segment partial per wave
+  static constexpr size_t LDS_BYTES = (size_t)2 * NCB * PLANE * 16 + (size_t)RED_FLOATS * 4;
+  static_assert(VCH % 32 == 0 && SPW == 2, "two segments per wave pair member");
+  static_assert(TR % SEGH == 0 && TC % SEGW == 0, "tile must be whole segments");
+};
+
+// Loader::kSlots: the input is a split-slot tensor (SlotIn) and staging is a 16-byte copy per (block, part, pixel);
+// OUTSLOT: the epilogue writes (and reads the residual from) a split-slot tensor instead of fp32 NCHW.
+template <int KS, int STRIDE, int VCH, int TR, int TC, int SEGW, int MINB, bool OUTSLOT, class Loader>
+__global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
+  using T = X3sTile<KS, STRIDE, VCH, TR, TC, SEGW>;
+  extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
+  uint4* s_xh = smem4;
+  uint4* s_xl = smem4 + T::NCB * T::PLANE;
+  float* s_red = reinterpret_cast<float*>(smem4 + 2 * T::NCB * T::PLANE);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int khalf = wave >> 1, pset = wave & 1;
+  const int gh = lane >> 5, j = lane & 31;
+
+  // this wave's A fragments: chunks [khalf * NKC, (khalf + 1) * NKC) of the host packing [chunk][tap][hi|lo][lane]
+  half8 wh[T::NK], wl[T::NK];
+  {
+    const uint4* wsrc = reinterpret_cast<const uint4*>(a.wpk) + (size_t)khalf * T::NKC * T::TAPS * 2 * 64 + lane;
+#pragma unroll
+    for (int k = 0; k < T::NK; ++k) {
+      const uint4 x = wsrc[(2 * k) * 64], y = wsrc[(2 * k + 1) * 64];
+      wh[k] = *reinterpret_cast<const half8*>(&x);
+      wl[k] = *reinterpret_cast<const half8*>(&y);
+    }
+  }
+  // per-lane slot offset of each of the wave's two segments (pixel j of the segment, channel-block parity gh)
+  // slot 0 = the segment this wave finishes (pset * 2 + khalf), slot 1 = the one whose partial it ships to its
+  // pair partner (wave ^ 2: same pixels, other K half, the roles swapped)
+  int lane_base[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int seg = pset * 2 + (s == 0 ? khalf : 1 - khalf);
+    const int srow = (seg / (TC / SEGW)) * T::SEGH + j / SEGW, scol = (seg % (TC / SEGW)) * SEGW + j % SEGW;
+    lane_base[s] = (khalf * T::HCB + gh) * T::PLANE + srow * STRIDE * T::PITCH + scol;
+  }
+  // bias of this lane's 16 output channels: loaded once (a global load in the per-tile epilogue would wait, through
+  // the in-order vmcnt, for every store of the previous tile and every prefetch load of the next one)
+  float bv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bv[r] = a.bias[(r & 3) + 8 * (r >> 2) + 4 * gh];
+  const int total = a.tiles_x * a.tiles_y * a.nimg;
+  // Staging.  Vector path (plain NCHW / 3-D volume loaders, W % 4 == 0): a unit is 8 channels x 4 consecutive
+  // columns = eight aligned 16-byte loads and four pixel slots, with ONE address / bounds computation per unit
+  // (the per-element loader costs ~40 instructions per value, which a 1-wave-per-SIMD kernel cannot hide).
+  // Scalar path (cost-volume loader, odd widths): one pixel slot = 8 loader calls, as in k_conv_c32_x3.
+  // Slot path (SlotIn): a unit is one 16-byte slot of (virtual block, part, row, column): load -> LDS, no VALU.
+  constexpr bool VEC = Loader::kVec;
+  constexpr bool SLOTS = Loader::kSlots;
+  constexpr int NSL = 2 * T::NSLOT, LPT = (NSL + 255) / 256;       // slots per tile (hi and lo) / per thread
+  constexpr int NPRE = SLOTS ? LPT * 4 : (VEC ? T::UPT * 32 : T::SPT * 8);
+  float pre[NPRE];
+  const bool vec_ok = VEC && ld.vec_aligned();
+  auto fetch = [&](int tile) {
+    const int tx = tile % a.tiles_x, t2 = tile / a.tiles_x;
+    const int ty = t2 % a.tiles_y, img = t2 / a.tiles_y;
+    const int iy0 = ty * TR * STRIDE - a.pad, ix0 = tx * TC * STRIDE - a.pad;
+    int tq = tid;
+    asm volatile("" : "+v"(tq));
+    if (SLOTS) {
+#pragma unroll
+      for (int e = 0; e < LPT; ++e) {
+        const int idx = e * 256 + tq;
+        const int vp = idx / (T::ROWS_IN * T::COLS_IN);                // virtual block * 2 + part
+        const int rem = idx - vp * (T::ROWS_IN * T::COLS_IN);
+        const int r = rem / T::COLS_IN;
+        const int cc = rem - r * T::COLS_IN;
+        const int y = iy0 + r, x = ix0 + cc;
+        const uint4* hi;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (idx < NSL && (unsigned)y < (unsigned)ld.H && (unsigned)x < (unsigned)ld.W && ld.slot_base(img, vp >> 1, hi))
+          v = hi[((size_t)(vp & 1) * ld.H + y) * ld.W + x];
+        *reinterpret_cast<uint4*>(&pre[e * 4]) = v;
+      }
+    } else if (VEC && vec_ok) {
+#pragma unroll
+      for (int u = 0; u < T::UPT; ++u) {
+        const int idx = u * 256 + tq;
+        const int cb = idx / (T::ROWS_IN * T::NQ);
+        const int rem = idx - cb * (T::ROWS_IN * T::NQ);
+        const int r = rem / T::NQ, q = rem - r * T::NQ;
+        const int y = iy0 + r, x = ix0 - T::SH + 4 * q;
+        const float* base;
+        unsigned cs;
+        const bool row_ok = idx < T::NU && ld.cb_base(img, cb, base, cs) && (unsigned)y < (unsigned)ld.H;
+        const bool inside = row_ok && x >= 0 && x + 3 < ld.W;
+        const bool edge = row_ok && !inside && x + 3 >= 0 && x < ld.W;
+        const float* src = base + (ptrdiff_t)y * ld.W + x;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (inside) {
+            v = *reinterpret_cast<const float4*>(src + (size_t)k * cs);
+          } else if (edge) {
+            const float* sk = src + (size_t)k * cs;
+            if ((unsigned)(x + 0) < (unsigned)ld.W) v.x = sk[0];
+            if ((unsigned)(x + 1) < (unsigned)ld.W) v.y = sk[1];
+            if ((unsigned)(x + 2) < (unsigned)ld.W) v.z = sk[2];
+            if ((unsigned)(x + 3) < (unsigned)ld.W) v.w = sk[3];
+          }
+          pre[u * 32 + k * 4 + 0] = v.x;
+          pre[u * 32 + k * 4 + 1] = v.y;
+          pre[u * 32 + k * 4 + 2] = v.z;
+          pre[u * 32 + k * 4 + 3] = v.w;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < T::SPT; ++e) {
+        const int idx = e * 256 + tq;
+        const int cb = idx / (T::ROWS_IN * T::COLS_IN);
+        const int rem = idx - cb * (T::ROWS_IN * T::COLS_IN);
+        const int r = rem / T::COLS_IN;
+        const int cc = rem - r * T::COLS_IN;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pre[e * 8 + k] = idx < T::NSLOT ? ld(img, cb * 8 + k, iy0 + r, ix0 + cc) : 0.f;
+      }
+    }
+  };
+  auto put_slot = [&](int cb, int r, int cc, const float* v, int vstride) {
+    half8 hi, lo;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float f = v[k * vstride];
+      hi[k] = (_Float16)f;
+      lo[k] = (_Float16)((f - (float)hi[k]) * kSplitScale);
+    }
+    const int di = STRIDE == 1 ? cc : (cc & 1) * T::HALF + (cc >> 1);
+    const int off = cb * T::PLANE + r * T::PITCH + di;
+    s_xh[off] = *reinterpret_cast<const uint4*>(&hi);
+    s_xl[off] = *reinterpret_cast<const uint4*>(&lo);
+  };
+  auto commit = [&]() {
+    int tq = tid;
+    asm volatile("" : "+v"(tq));
+    if (SLOTS) {
+#pragma unroll
+      for (int e = 0; e < LPT; ++e) {
+        const int idx = e * 256 + tq;
+        const int vp = idx / (T::ROWS_IN * T::COLS_IN);
+        const int rem = idx - vp * (T::ROWS_IN * T::COLS_IN);
+        const int r = rem / T::COLS_IN;
+        const int cc = rem - r * T::COLS_IN;
+        if (idx < NSL) {
+          const int di = STRIDE == 1 ? cc : (cc & 1) * T::HALF + (cc >> 1);
+          uint4* dst = (vp & 1) ? s_xl : s_xh;
+          dst[(vp >> 1) * T::PLANE + r * T::PITCH + di] = *reinterpret_cast<const uint4*>(&pre[e * 4]);
+        }
+      }
+    } else if (VEC && vec_ok) {
+#pragma unroll
+      for (int u = 0; u < T::UPT; ++u) {
+        const int idx = u * 256 + tq;
+        const int cb = idx / (T::ROWS_IN * T::NQ);
+        const int rem = idx - cb * (T::ROWS_IN * T::NQ);
+        const int r = rem / T::NQ, q = rem - r * T::NQ;
+        if (idx < T::NU) {
+#pragma unroll
+          for (int pp = 0; pp < 4; ++pp) {
+            const int cc = 4 * q + pp - T::SH;
+            if (cc >= 0 && cc < T::COLS_IN) put_slot(cb, r, cc, &pre[u * 32 + pp], 4);
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < T::SPT; ++e) {
+        const int idx = e * 256 + tq;
+        const int cb = idx / (T::ROWS_IN * T::COLS_IN);
+        const int rem = idx - cb * (T::ROWS_IN * T::COLS_IN);
+        const int r = rem / T::COLS_IN;
+        const int cc = rem - r * T::COLS_IN;
+        if (idx < T::NSLOT) put_slot(cb, r, cc, &pre[e * 8], 1);
+      }
+    }
+  };
+
+  // XCD-aware persistent schedule: workgroup b runs on XCD b % 8 (round-robin dispatch); each XCD walks its own
+  // contiguous band of tiles so that neighbouring tiles (shared halo rows / columns) meet in ONE L2.
+  const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, nlb = gridDim.x >> 3;
+  const int t_end = (int)((long)(xcd + 1) * total / 8);
+  int tile = (int)((long)xcd * total / 8) + lb;
+  if (tile >= t_end) return;
+  fetch(tile);
+  commit();
+  __syncthreads();
+  const size_t plane_o = (size_t)a.Ho * a.Wo;
+  for (; tile < t_end; tile += nlb) {
+    const int nxt = tile + nlb;
+    // residual of the segment this wave finishes: requested before the MFMAs, consumed in the epilogue
+    const int e_tx = tile % a.tiles_x, e_t2 = tile / a.tiles_x;
+    const int e_ty = e_t2 % a.tiles_y, e_img = e_t2 / a.tiles_y;
+    const int e_seg = pset * 2 + khalf;
+    const int e_y = e_ty * TR + (e_seg / (TC / SEGW)) * T::SEGH + j / SEGW;
+    const int e_x = e_tx * TC + (e_seg % (TC / SEGW)) * SEGW + j % SEGW;
+    const bool e_in = e_y < a.Ho && e_x < a.Wo;
+    float rv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+    if (a.res && e_in) {
+      if (OUTSLOT) {
+        const char* rs = reinterpret_cast<const char*>(a.res);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const size_t bh_ = low_slot_index(e_img, q, 0, e_y, e_x, a.Ho, a.Wo) * 16 + gh * 8;
+          const half4 rh = *reinterpret_cast<const half4*>(rs + bh_);
+          const half4 rl = *reinterpret_cast<const half4*>(rs + bh_ + plane_o * 16);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) rv[4 * q + e] = (float)rh[e] + (float)rl[e] * kSplitInv;
+        }
+      } else {
+        const size_t base = (size_t)e_img * kC * plane_o + (size_t)e_y * a.Wo + e_x;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rv[r] = a.res[base + (size_t)((r & 3) + 8 * (r >> 2) + 4 * gh) * plane_o];
+      }
+    }
+    if (nxt < t_end) fetch(nxt);
+
+    f32x16 acc0[2], acc1[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc0[s][r] = 0.f;
+        acc1[s][r] = 0.f;
+      }
+    // B operands are fetched one K-step ahead (this kernel runs one wave per SIMD: an LDS read issued right
+    // before its MFMA would expose the full LDS latency 100 times per tile); the scheduling barriers keep hipcc
+    // from sinking the reads back to their uses.
+    auto koff_of = [&](int k) {
+      const int kc = k / T::TAPS, tap = k - kc * T::TAPS;
+      const int ky = tap / KS, kx = tap - ky * KS;
+      return 2 * kc * T::PLANE + ky * T::PITCH + (STRIDE == 1 ? kx : (kx & 1) * T::HALF + (kx >> 1));
+    };
+    uint4 bh[2][2], bl[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bh[0][s] = s_xh[lane_base[s] + koff_of(0)];
+      bl[0][s] = s_xl[lane_base[s] + koff_of(0)];
+    }
+#pragma unroll
+    for (int k = 0; k < T::NK; ++k) {
+      const int cur = k & 1, nx = cur ^ 1;
+      if (k + 1 < T::NK) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          bh[nx][s] = s_xh[lane_base[s] + koff_of(k + 1)];
+          bl[nx][s] = s_xl[lane_base[s] + koff_of(k + 1)];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const half8 xh = *reinterpret_cast<const half8*>(&bh[cur][s]);
+        const half8 xl = *reinterpret_cast<const half8*>(&bl[cur][s]);
+        acc0[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[k], xh, acc0[s], 0, 0, 0);
+        acc1[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[k], xh, acc1[s], 0, 0, 0);
+        acc1[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[k], xl, acc1[s], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ship the partial of the segment the pair partner finishes
+    {
+      float* dst = s_red + (size_t)wave * 16 * 64 + lane;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[r * 64] = acc0[1][r] + acc1[1][r] * kSplitInv;
+    }
+    lds_barrier();                      // halo tile free, partials visible
+    if (nxt < t_end) commit();
+    {
+      const float* src = s_red + (size_t)(wave ^ 2) * 16 * 64 + lane;      // partner: same pixel set, other K half
+      if (e_in) {
+        if (OUTSLOT) {
+          // channel block q = r >> 2 holds couts 8q .. 8q+7; this lane owns 4gh .. 4gh+3 of it: one 8-byte store
+          // into the hi slot and one into the lo slot (the two half-waves fill the 16-byte slot together)
+          char* o = reinterpret_cast<char*>(a.out);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const size_t bh_ = low_slot_index(e_img, q, 0, e_y, e_x, a.Ho, a.Wo) * 16 + gh * 8;
+            half4 hh, hl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int r = 4 * q + e;
+              float v = acc0[0][r] + acc1[0][r] * kSplitInv + src[r * 64] + bv[r] + rv[r];
+              if (a.lrelu) v = v > 0.f ? v : v * kSlope;
+              const _Float16 hi = (_Float16)v;
+              hh[e] = hi;
+              hl[e] = (_Float16)((v - (float)hi) * kSplitScale);
+            }
+            *reinterpret_cast<half4*>(o + bh_) = hh;
+            *reinterpret_cast<half4*>(o + bh_ + plane_o * 16) = hl;
+          }
+        } else {
+          const size_t base = (size_t)e_img * kC * plane_o + (size_t)e_y * a.Wo + e_x;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int co = (r & 3) + 8 * (r >> 2) + 4 * gh;
+            float v = acc0[0][r] + acc1[0][r] * kSplitInv + src[r * 64] + bv[r] + rv[r];
+            if (a.lrelu) v = v > 0.f ? v : v * kSlope;
+            a.out[base + (size_t)co * plane_o] = v;
+          }
+        }
+      }
+    }
+    lds_barrier();                      // next tile staged; partial buffer free
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // K1a: first down-conv (3 -> 32, 5x5, stride 2) straight from the int8 model input, fp16 modes.
 // With three input channels the generic implicit GEMM spends 50 exact-fp32 MFMAs (64 cycles each) per 32 output
 // pixels on K = 4 (padded) x 25.  The int8 input / 128 is EXACT in fp16, so only the weights need the hi/lo split
@@ -566,7 +982,7 @@ struct Down0Tile {
   static constexpr int CSEG = TC / 32, SPW = TR * CSEG / 4;
 };
 
-template <int TC>
+template <int TC, bool OUTSLOT>
 __global__ __launch_bounds__(256) void k_down0_f16(const int8_t* __restrict__ in6, int H, int W,
                                                    const uint4* __restrict__ wfrag,   // [8][hi|lo][64]
                                                    const float* __restrict__ bias, float* __restrict__ out, int Ho,
@@ -691,19 +1107,38 @@ __global__ __launch_bounds__(256) void k_down0_f16(const int8_t* __restrict__ in
         const int seg = wave * T::SPW + s;
         const int y = ty * T::TR + seg / T::CSEG, x = tx * TC + (seg % T::CSEG) * 32 + j;
         if (y < Ho && x < Wo) {
-          float* o = out + (size_t)img * kC * plane_o + (size_t)y * Wo + x;
+          if (OUTSLOT) {        // split-slot tensor for the next down-conv (see SlotIn)
+            char* o = reinterpret_cast<char*>(out);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int co = (r & 3) + 8 * (r >> 2) + 4 * g;
-            float v = acc0[s][r] + acc1[s][r] * kSplitInv;
-            if (lrelu) v = v > 0.f ? v : v * kSlope;
-            o[(size_t)co * plane_o] = v;
+            for (int q = 0; q < 4; ++q) {
+              const size_t bh_ = low_slot_index(img, q, 0, y, x, Ho, Wo) * 16 + g * 8;
+              half4 hh, hl;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                float v = acc0[s][4 * q + e] + acc1[s][4 * q + e] * kSplitInv;
+                if (lrelu) v = v > 0.f ? v : v * kSlope;
+                const _Float16 hi = (_Float16)v;
+                hh[e] = hi;
+                hl[e] = (_Float16)((v - (float)hi) * kSplitScale);
+              }
+              *reinterpret_cast<half4*>(o + bh_) = hh;
+              *reinterpret_cast<half4*>(o + bh_ + plane_o * 16) = hl;
+            }
+          } else {
+            float* o = out + (size_t)img * kC * plane_o + (size_t)y * Wo + x;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int co = (r & 3) + 8 * (r >> 2) + 4 * g;
+              float v = acc0[s][r] + acc1[s][r] * kSplitInv;
+              if (lrelu) v = v > 0.f ? v : v * kSlope;
+              o[(size_t)co * plane_o] = v;
+            }
           }
         }
       }
     }
     if (nxt < total) commit(s_x + (cur ^ 1) * T::BUF);
-    __syncthreads();
+    lds_barrier();
     cur ^= 1;
   }
 }
@@ -2221,7 +2656,7 @@ __global__ __launch_bounds__(256) void k_refin_f16(const float* __restrict__ dis
       }
     }
     if (nxt < total) commit(s_px + (cur ^ 1) * T::BUF);
-    __syncthreads();
+    lds_barrier();
     cur ^= 1;
   }
 }

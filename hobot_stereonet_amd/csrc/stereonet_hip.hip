@@ -106,6 +106,7 @@ struct sn_handle {
   hipStream_t s_low = nullptr, s_ref = nullptr;     // low-res branch / refinement tower (piece pipeline)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_piece[kMaxPieceEvents] = {};
   bool overlap = true;
+  bool low_slots = false;    // low-resolution branch on split-slot activations (lowres_slots)
   int ovl_cap = 1;           // tower workgroups per CU while the low-res branch runs beside it (SN_OVL_CAP)
   bool ref_dyn = true;       // dynamic tile queue in the fp16 tower (SN_REF_DYN=0: static stride)
   bool use_graphs = true;    // hipGraph replay for the async single-pair path (SN_NO_GRAPH disables)
@@ -290,7 +291,7 @@ hipError_t launch_refin_f16(hipStream_t st, const Down0F16& L, const float* bias
   return hipGetLastError();
 }
 
-template <int TC>
+template <int TC, bool OUTSLOT = false>
 hipError_t launch_down0_f16(hipStream_t st, const Down0F16& L, const float* bias, const int8_t* in6, int H, int W,
                             int nimg, int Ho, int Wo, float* out, int num_cu) {
   using T = Down0Tile<TC>;
@@ -299,7 +300,7 @@ hipError_t launch_down0_f16(hipStream_t st, const Down0F16& L, const float* bias
   int blocks = (TC == 64 ? 1 : 2) * num_cu;      // register budget: one (TC = 64) or two workgroups per CU
   if (blocks > total) blocks = total;
   const int al4 = (W % 4 == 0) && (reinterpret_cast<uintptr_t>(in6) % 4 == 0);
-  hipLaunchKernelGGL(k_down0_f16<TC>, dim3(blocks), dim3(256), T::LDS_BYTES, st, in6, H, W, L.wfrag, bias, out, Ho, Wo,
+  hipLaunchKernelGGL((k_down0_f16<TC, OUTSLOT>), dim3(blocks), dim3(256), T::LDS_BYTES, st, in6, H, W, L.wfrag, bias, out, Ho, Wo,
                      tiles_x, tiles_y, nimg, 0, al4);
   return hipGetLastError();
 }
@@ -331,9 +332,63 @@ hipError_t launch_conv_x3g(hipStream_t st, const ConvLayer& L, const Loader& ld,
   return hipGetLastError();
 }
 
+template <class K>
+hipError_t ensure_lds_attr(K kern, int bytes);
+
+// second generation (weights-stationary, K split across wave pairs): persistent grid of MINB workgroups per CU
+template <int KS, int STRIDE, int VCH, int TR, int TC, int SEGW, int MINB, bool OUTSLOT, class Loader>
+hipError_t launch_conv_x3s(hipStream_t st, const ConvLayer& L, const Loader& ld, int nimg, int Ho, int Wo, float* out,
+                           const float* res, bool lrelu, int num_cu) {
+  using T = X3sTile<KS, STRIDE, VCH, TR, TC, SEGW>;
+  ConvArgs a{};
+  a.wpk = reinterpret_cast<const float*>(L.wx3);
+  a.bias = L.bias;
+  a.out = out;
+  a.res = res;
+  a.nimg = nimg;
+  a.cin_pad = L.cin_pad;
+  a.Ho = Ho;
+  a.Wo = Wo;
+  a.dil = 1;
+  a.pad = KS / 2;
+  a.lrelu = lrelu ? 1 : 0;
+  a.tiles_x = (Wo + TC - 1) / TC;
+  a.tiles_y = (Ho + TR - 1) / TR;
+  auto kern = k_conv_x3s<KS, STRIDE, VCH, TR, TC, SEGW, MINB, OUTSLOT, Loader>;
+  static_assert(T::LDS_BYTES <= 160 * 1024, "x3s tile does not fit the LDS");
+  if (T::LDS_BYTES > 64 * 1024) {
+    hipError_t e = ensure_lds_attr(kern, (int)T::LDS_BYTES);
+    if (e != hipSuccess) return e;
+  }
+  const int total = a.tiles_x * a.tiles_y * nimg;
+  int blocks = num_cu * MINB;                       // a multiple of 8: one band of tiles per XCD
+  if (blocks > (total + 7) / 8 * 8) blocks = (total + 7) / 8 * 8;
+  blocks = (blocks + 7) / 8 * 8;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), T::LDS_BYTES, st, a, ld);
+  return hipGetLastError();
+}
+
+inline bool use_x3s() {
+  static const bool on = getenv("SN_X3_V1") == nullptr;
+  return on;
+}
+inline int x3s_cus() {                 // CU count for the persistent grids (the launchers have no handle)
+  static const int n = [] {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 256;
+    return p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+  }();
+  return n;
+}
+
 template <int DIL, int TR, int TC, class Loader>
 hipError_t launch_conv_x3(hipStream_t st, const ConvLayer& L, const Loader& ld, int nimg, int Ho, int Wo, float* out,
                           const float* res, bool lrelu) {
+  if (DIL == 1 && use_x3s()) {
+    if (L.cin_pad == 96) return launch_conv_x3s<3, 1, 96, 8, 16, 16, 1, false, Loader>(st, L, ld, nimg, Ho, Wo, out, res, lrelu, x3s_cus());
+    if (L.cin_pad == 32) return launch_conv_x3s<3, 1, 32, 8, 16, 16, 1, false, Loader>(st, L, ld, nimg, Ho, Wo, out, res, lrelu, x3s_cus());
+  }
   return launch_conv_x3g<3, 1, DIL, TR, TC, Loader>(st, L, ld, nimg, Ho, Wo, out, res, lrelu);
 }
 
@@ -426,6 +481,7 @@ hipError_t conv5x5s2(hipStream_t st, const ConvLayer& L, const float* in, int ni
                      float* out) {
   LoadF32 ld{in, kC, Hin, Win};
   const int Ho = Hin / 2, Wo = Win / 2;
+  if (L.wx3 && use_x3s()) return launch_conv_x3s<5, 2, 32, 4, 32, 32, 1, false, LoadF32>(st, L, ld, nimg, Ho, Wo, out, nullptr, false, x3s_cus());
   if (L.wx3) return launch_conv_x3g<5, 2, 1, 4, 32>(st, L, ld, nimg, Ho, Wo, out, nullptr, false);   // fp16 modes
   if (Ho * Wo <= 64 * 128) return launch_conv<5, 2, 1, 4, 4, 32>(st, L, ld, nimg, Ho, Wo, out, nullptr, false);
   return launch_conv<5, 2, 1, 4, 8, 64>(st, L, ld, nimg, Ho, Wo, out, nullptr, false);
@@ -722,10 +778,63 @@ void free_ws(Workspace* ws) {
 // ---- the forward pass on device buffers ------------------------------------------------------------
 // Low-resolution branch for pairs [p0, p0+m): Siamese features -> cost volume -> 3-D aggregation ->
 // soft-argmin.  Intermediate buffers are piece-local; disp_low (and cost) are indexed by p0.
+// Low-resolution branch of the fp16 modes on split-slot activations (SlotIn): every layer's epilogue writes the
+// hi/lo fp16 pair its consumer's split-operand MFMAs read, the weights-stationary kernel stages them as plain
+// 16-byte copies.  Only the tensors other kernels read stay fp32 NCHW: the feature map (cost-volume loader, parity
+// hook) and the last aggregation volume (soft-argmin head).
+int lowres_slots(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, const int8_t* in6, bool want_cost,
+                 bool prof) {
+  const int Hp = h->Hp, Wp = h->Wp, hl = h->hl, wl = h->wl, Dl = h->Dl;
+  const size_t HW = (size_t)h->H * h->W;
+  const int8_t* in = in6 + (size_t)p0 * 6 * HW;
+  const int ncu = h->num_cu, ni = 2 * m;
+  auto U4 = [](float* p) { return reinterpret_cast<const uint4*>(p); };
+  HIP_TRY(h, (launch_down0_f16<32, true>(st, h->down0, h->down[0].bias, in, h->H, h->W, ni, Hp / 2, Wp / 2, ws.down[0], ncu)));
+  {
+    float* src[3] = {ws.down[0], ws.down[1], ws.down[2]};
+    float* dst[3] = {ws.down[1], ws.down[2], ws.low[0]};
+    for (int i = 0; i < 3; ++i) {
+      const int Hi = Hp >> (i + 1), Wi = Wp >> (i + 1);
+      SlotIn ld{U4(src[i]), 0, Hi, Wi};
+      HIP_TRY(h, (launch_conv_x3s<5, 2, 32, 4, 32, 32, 1, true, SlotIn>(st, h->down[i + 1], ld, ni, Hi / 2, Wi / 2, dst[i],
+                                                                       nullptr, false, ncu)));
+    }
+  }
+  float* x = ws.low[0];
+  float* t = ws.low[1];
+  for (int i = 0; i < kNFeatRes; ++i) {
+    SlotIn lx{U4(x), 0, hl, wl}, lt{U4(t), 0, hl, wl};
+    HIP_TRY(h, (launch_conv_x3s<3, 1, 32, 8, 16, 16, 2, true, SlotIn>(st, h->fres[i][0], lx, ni, hl, wl, t, nullptr, true, ncu)));
+    HIP_TRY(h, (launch_conv_x3s<3, 1, 32, 8, 16, 16, 2, true, SlotIn>(st, h->fres[i][1], lt, ni, hl, wl, x, x, true, ncu)));
+  }
+  {
+    SlotIn lx{U4(x), 0, hl, wl};
+    HIP_TRY(h, (launch_conv_x3s<3, 1, 32, 8, 16, 16, 1, false, SlotIn>(st, h->fout, lx, ni, hl, wl, ws.feat, nullptr, false, ncu)));
+  }
+  if (prof) HIP_TRY(h, hipEventRecord(h->ev[1], st));
+  LoadCostVol lc{ws.feat, Dl, hl, wl};
+  HIP_TRY(h, (launch_conv_x3s<3, 1, 96, 8, 16, 16, 1, true, LoadCostVol>(st, h->agg[0], lc, m * Dl, hl, wl, ws.vol[0], nullptr, true, ncu)));
+  for (int i = 1; i < kNAgg; ++i) {
+    SlotIn lv{U4(ws.vol[(i - 1) & 1]), Dl, hl, wl};
+    if (i + 1 < kNAgg)
+      HIP_TRY(h, (launch_conv_x3s<3, 1, 96, 8, 16, 16, 1, true, SlotIn>(st, h->agg[i], lv, m * Dl, hl, wl, ws.vol[i & 1], nullptr, true, ncu)));
+    else
+      HIP_TRY(h, (launch_conv_x3s<3, 1, 96, 8, 16, 16, 1, false, SlotIn>(st, h->agg[i], lv, m * Dl, hl, wl, ws.vol[i & 1], nullptr, true, ncu)));
+  }
+  const float* v = ws.vol[(kNAgg - 1) & 1];
+  const int npix = m * hl * wl;
+  hipLaunchKernelGGL(k_head_softargmin<16>, dim3((npix + 63) / 64), dim3(256), 0, st, v, h->aout.w, h->aout.bias, Dl,
+                     hl, wl, npix, ws.disp_low + (size_t)p0 * hl * wl,
+                     want_cost ? ws.cost + (size_t)p0 * Dl * hl * wl : nullptr);
+  HIP_TRY(h, hipGetLastError());
+  return SN_OK;
+}
+
 int lowres(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, const int8_t* in6, bool want_cost, bool prof) {
   const int Hp = h->Hp, Wp = h->Wp, hl = h->hl, wl = h->wl, Dl = h->Dl;
   const size_t HW = (size_t)h->H * h->W;
   const int8_t* in = in6 + (size_t)p0 * 6 * HW;
+  if (h->low_slots) return lowres_slots(h, ws, st, p0, m, in6, want_cost, prof);
   // --- Siamese feature tower: images = 2m (left, right interleaved), shared weights ---
   {
     LoadI8Eye ld{in, h->H, h->W};
@@ -1039,6 +1148,8 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(SN_ERR_DEVICE);
   h->overlap = getenv("SN_NO_OVERLAP") == nullptr;
   h->use_graphs = getenv("SN_NO_GRAPH") == nullptr;
+  h->low_slots = h->precision != SN_PREC_FP32 && getenv("SN_LOW_FP32") == nullptr && getenv("SN_DOWN_FP32") == nullptr &&
+                 getenv("SN_DOWN0_FP32") == nullptr && getenv("SN_X3_V1") == nullptr && getenv("SN_LOW_NCHW") == nullptr;
   {
     const char* e = getenv("SN_REF_DYN");     // dynamic tile queue of the fp16 tower (default on)
     h->ref_dyn = e ? atoi(e) != 0 : true;
@@ -1481,7 +1592,8 @@ int sn_dbg_conv2d(sn_handle* h, const float* in, int cin, int h_px, int w, const
   LoadF32 ld{din, cin, h_px, w};
   hipError_t e;
   if (k == 5 && x3) {
-    e = launch_conv_x3g<5, 2, 1, 4, 32>(st, L, ld, 1, Ho, Wo, dout, dres, lrelu != 0);
+    e = use_x3s() ? launch_conv_x3s<5, 2, 32, 4, 32, 32, 1, false, LoadF32>(st, L, ld, 1, Ho, Wo, dout, dres, lrelu != 0, h->num_cu)
+                  : launch_conv_x3g<5, 2, 1, 4, 32>(st, L, ld, 1, Ho, Wo, dout, dres, lrelu != 0);
   } else if (k == 5) {
     e = (Ho * Wo <= 64 * 128) ? launch_conv<5, 2, 1, 4, 4, 32>(st, L, ld, 1, Ho, Wo, dout, dres, lrelu != 0)
                               : launch_conv<5, 2, 1, 4, 8, 64>(st, L, ld, 1, Ho, Wo, dout, dres, lrelu != 0);
