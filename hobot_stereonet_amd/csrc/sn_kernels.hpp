@@ -100,6 +100,9 @@ struct LoadF32 {            // plain NCHW fp32 tensor [nimg][C][H][W]
   static constexpr bool kVec = true;
   static constexpr bool kSlots = false;
   __device__ __forceinline__ bool slot_base(int, int, const uint4*&) const { return false; }
+  __device__ __forceinline__ int plane_off(int) const { return 0; }
+  __device__ __forceinline__ bool plane_valid(int, int) const { return false; }
+  __device__ __forceinline__ const uint4* image_base(int) const { return nullptr; }
   __device__ __forceinline__ bool vec_aligned() const { return ((size_t)p & 3) == 0; }
   __device__ __forceinline__ bool cb_base(int img, int cb, const float*& base, unsigned& cstride) const {
     cstride = (unsigned)H * W;
@@ -134,6 +137,9 @@ struct LoadVol3D {
   static constexpr bool kVec = true;
   static constexpr bool kSlots = false;
   __device__ __forceinline__ bool slot_base(int, int, const uint4*&) const { return false; }
+  __device__ __forceinline__ int plane_off(int) const { return 0; }
+  __device__ __forceinline__ bool plane_valid(int, int) const { return false; }
+  __device__ __forceinline__ const uint4* image_base(int) const { return nullptr; }
   __device__ __forceinline__ bool vec_aligned() const { return ((size_t)p & 3) == 0; }
   __device__ __forceinline__ bool cb_base(int img, int cb, const float*& base, unsigned& cstride) const {
     const int n = img / Dl, d = img - n * Dl;
@@ -163,6 +169,9 @@ struct LoadCostVol {
   static constexpr bool kVec = false;        // two differently aligned reads per element: scalar staging
   static constexpr bool kSlots = false;
   __device__ __forceinline__ bool slot_base(int, int, const uint4*&) const { return false; }
+  __device__ __forceinline__ int plane_off(int) const { return 0; }
+  __device__ __forceinline__ bool plane_valid(int, int) const { return false; }
+  __device__ __forceinline__ const uint4* image_base(int) const { return nullptr; }
   __device__ __forceinline__ bool vec_aligned() const { return false; }
   __device__ __forceinline__ bool cb_base(int, int, const float*&, unsigned&) const { return false; }
 };
@@ -181,6 +190,17 @@ struct SlotIn {
   __device__ __forceinline__ bool vec_aligned() const { return false; }
   __device__ __forceinline__ float operator()(int, int, int, int) const { return 0.f; }
   __device__ __forceinline__ bool cb_base(int, int, const float*&, unsigned&) const { return false; }
+  // k_conv_x3s staging: slot offset of virtual block vb relative to block 0 of image img, and its validity
+  __device__ __forceinline__ int plane_off(int vb) const {
+    const int hw2 = 2 * H * W;
+    return Dl > 0 ? (((vb >> 2) - 1) * 4 + (vb & 3)) * hw2 : vb * hw2;
+  }
+  __device__ __forceinline__ bool plane_valid(int img, int vb) const {
+    if (Dl <= 0) return true;
+    const int d = img % Dl;
+    return (unsigned)(d + (vb >> 2) - 1) < (unsigned)Dl;
+  }
+  __device__ __forceinline__ const uint4* image_base(int img) const { return p + (size_t)img * 8 * ((size_t)H * W); }
   // hi plane of virtual block vb of image img (lo plane = hi + H * W); false = zero padding plane
   __device__ __forceinline__ bool slot_base(int img, int vb, const uint4*& hi) const {
     int image = img, cb = vb;
@@ -642,20 +662,22 @@ struct X3sTile {
   static constexpr int NU = NCB * ROWS_IN * NQ;
   static constexpr int UPT = (NU + 255) / 256;
   static constexpr int RED_FLOATS = 4 * 16 * 64;           // one segment partial per wave
-  static constexpr size_t LDS_BYTES = (size_t)2 * NCB * PLANE * 16 + (size_t)RED_FLOATS * 4;
+  static constexpr size_t LDS_BYTES = (size_t)2 * NCB * PLANE * 16 + (size_t)RED_FLOATS * 4 + 32 * 4;
   static_assert(VCH % 32 == 0 && SPW == 2, "two segments per wave pair member");
   static_assert(TR % SEGH == 0 && TC % SEGW == 0, "tile must be whole segments");
 };
 
 // Loader::kSlots: the input is a split-slot tensor (SlotIn) and staging is a 16-byte copy per (block, part, pixel);
 // OUTSLOT: the epilogue writes (and reads the residual from) a split-slot tensor instead of fp32 NCHW.
-template <int KS, int STRIDE, int VCH, int TR, int TC, int SEGW, int MINB, bool OUTSLOT, class Loader>
+// HASRES: a residual tensor (same format as the output) is added before the activation.
+template <int KS, int STRIDE, int VCH, int TR, int TC, int SEGW, int MINB, bool OUTSLOT, bool HASRES, class Loader>
 __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
   using T = X3sTile<KS, STRIDE, VCH, TR, TC, SEGW>;
   extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
   uint4* s_xh = smem4;
   uint4* s_xl = smem4 + T::NCB * T::PLANE;
   float* s_red = reinterpret_cast<float*>(smem4 + 2 * T::NCB * T::PLANE);
+  float* s_bias = s_red + T::RED_FLOATS;        // 32 floats: read back per tile through lgkmcnt, not vmcnt
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -683,11 +705,7 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
     const int srow = (seg / (TC / SEGW)) * T::SEGH + j / SEGW, scol = (seg % (TC / SEGW)) * SEGW + j % SEGW;
     lane_base[s] = (khalf * T::HCB + gh) * T::PLANE + srow * STRIDE * T::PITCH + scol;
   }
-  // bias of this lane's 16 output channels: loaded once (a global load in the per-tile epilogue would wait, through
-  // the in-order vmcnt, for every store of the previous tile and every prefetch load of the next one)
-  float bv[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) bv[r] = a.bias[(r & 3) + 8 * (r >> 2) + 4 * gh];
+  if (tid < kC) s_bias[tid] = a.bias[tid];
   const int total = a.tiles_x * a.tiles_y * a.nimg;
   // Staging.  Vector path (plain NCHW / 3-D volume loaders, W % 4 == 0): a unit is 8 channels x 4 consecutive
   // columns = eight aligned 16-byte loads and four pixel slots, with ONE address / bounds computation per unit
@@ -700,6 +718,26 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
   constexpr int NPRE = SLOTS ? LPT * 4 : (VEC ? T::UPT * 32 : T::SPT * 8);
   float pre[NPRE];
   const bool vec_ok = VEC && ld.vec_aligned();
+  // Slot path: which slot a thread copies in round e never changes, so (block, part, row, column, LDS offset) are
+  // decoded ONCE into one packed register per round; per tile a copy is then ~10 instructions of address math
+  // (decoding idx -> coordinates per tile cost 9,000 of the 21,000 cycles a 5x5 tile took).
+  //   bits 0..12 LDS slot offset (inside s_xh / s_xl), 13..19 column, 20..24 row, 25..28 virtual block, 29 part,
+  //   30 valid
+  unsigned stab[SLOTS ? LPT : 1];
+  if (SLOTS) {
+    static_assert(T::NCB * T::PLANE < 8192 && T::COLS_IN < 128 && T::ROWS_IN < 32 && T::NCB <= 16, "packed staging table");
+#pragma unroll
+    for (int e = 0; e < LPT; ++e) {
+      const int idx = e * 256 + tid;
+      const int vp = idx / (T::ROWS_IN * T::COLS_IN);
+      const int rem = idx - vp * (T::ROWS_IN * T::COLS_IN);
+      const int r = rem / T::COLS_IN;
+      const int cc = rem - r * T::COLS_IN;
+      const int di = STRIDE == 1 ? cc : (cc & 1) * T::HALF + (cc >> 1);
+      const unsigned off = (vp >> 1) * T::PLANE + r * T::PITCH + di;
+      stab[e] = idx < NSL ? (off | (cc << 13) | (r << 20) | ((vp >> 1) << 25) | ((vp & 1) << 29) | (1u << 30)) : 0u;
+    }
+  }
   auto fetch = [&](int tile) {
     const int tx = tile % a.tiles_x, t2 = tile / a.tiles_x;
     const int ty = t2 % a.tiles_y, img = t2 / a.tiles_y;
@@ -707,18 +745,17 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
     int tq = tid;
     asm volatile("" : "+v"(tq));
     if (SLOTS) {
+      const uint4* ibase = ld.image_base(img) + ((ptrdiff_t)iy0 * ld.W + ix0);
+      const int hw = ld.H * ld.W;
 #pragma unroll
       for (int e = 0; e < LPT; ++e) {
-        const int idx = e * 256 + tq;
-        const int vp = idx / (T::ROWS_IN * T::COLS_IN);                // virtual block * 2 + part
-        const int rem = idx - vp * (T::ROWS_IN * T::COLS_IN);
-        const int r = rem / T::COLS_IN;
-        const int cc = rem - r * T::COLS_IN;
+        unsigned t = stab[e];
+        asm volatile("" : "+v"(t));          // keep the unpacking inside the tile loop (hoisted it spills)
+        const int cc = (t >> 13) & 127, r = (t >> 20) & 31, vb = (t >> 25) & 15, part = (t >> 29) & 1;
         const int y = iy0 + r, x = ix0 + cc;
-        const uint4* hi;
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (idx < NSL && (unsigned)y < (unsigned)ld.H && (unsigned)x < (unsigned)ld.W && ld.slot_base(img, vp >> 1, hi))
-          v = hi[((size_t)(vp & 1) * ld.H + y) * ld.W + x];
+        if ((t >> 30) && (unsigned)y < (unsigned)ld.H && (unsigned)x < (unsigned)ld.W && ld.plane_valid(img, vb))
+          v = ibase[(ptrdiff_t)ld.plane_off(vb) + part * hw + r * ld.W + cc];
         *reinterpret_cast<uint4*>(&pre[e * 4]) = v;
       }
     } else if (VEC && vec_ok) {
@@ -785,16 +822,10 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
     if (SLOTS) {
 #pragma unroll
       for (int e = 0; e < LPT; ++e) {
-        const int idx = e * 256 + tq;
-        const int vp = idx / (T::ROWS_IN * T::COLS_IN);
-        const int rem = idx - vp * (T::ROWS_IN * T::COLS_IN);
-        const int r = rem / T::COLS_IN;
-        const int cc = rem - r * T::COLS_IN;
-        if (idx < NSL) {
-          const int di = STRIDE == 1 ? cc : (cc & 1) * T::HALF + (cc >> 1);
-          uint4* dst = (vp & 1) ? s_xl : s_xh;
-          dst[(vp >> 1) * T::PLANE + r * T::PITCH + di] = *reinterpret_cast<const uint4*>(&pre[e * 4]);
-        }
+        unsigned t = stab[e];
+        asm volatile("" : "+v"(t));
+        // s_xl follows s_xh at NCB * PLANE slots
+        if (t >> 30) s_xh[(t & 8191u) + ((t >> 29) & 1u) * (T::NCB * T::PLANE)] = *reinterpret_cast<const uint4*>(&pre[e * 4]);
       }
     } else if (VEC && vec_ok) {
 #pragma unroll
@@ -843,10 +874,10 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
     const int e_y = e_ty * TR + (e_seg / (TC / SEGW)) * T::SEGH + j / SEGW;
     const int e_x = e_tx * TC + (e_seg % (TC / SEGW)) * SEGW + j % SEGW;
     const bool e_in = e_y < a.Ho && e_x < a.Wo;
-    float rv[16];
+    float rv[HASRES ? 16 : 1];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) rv[r] = 0.f;
-    if (a.res && e_in) {
+    for (int r = 0; r < (HASRES ? 16 : 1); ++r) rv[r] = 0.f;
+    if (HASRES && e_in) {
       if (OUTSLOT) {
         const char* rs = reinterpret_cast<const char*>(a.res);
 #pragma unroll
@@ -916,6 +947,7 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
     }
     lds_barrier();                      // halo tile free, partials visible
     if (nxt < t_end) commit();
+
     {
       const float* src = s_red + (size_t)(wave ^ 2) * 16 * 64 + lane;      // partner: same pixel set, other K half
       if (e_in) {
@@ -930,7 +962,8 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const int r = 4 * q + e;
-              float v = acc0[0][r] + acc1[0][r] * kSplitInv + src[r * 64] + bv[r] + rv[r];
+              float v = acc0[0][r] + acc1[0][r] * kSplitInv + src[r * 64] + s_bias[8 * q + 4 * gh + e];
+              if (HASRES) v += rv[HASRES ? r : 0];
               if (a.lrelu) v = v > 0.f ? v : v * kSlope;
               const _Float16 hi = (_Float16)v;
               hh[e] = hi;
@@ -944,7 +977,8 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int co = (r & 3) + 8 * (r >> 2) + 4 * gh;
-            float v = acc0[0][r] + acc1[0][r] * kSplitInv + src[r * 64] + bv[r] + rv[r];
+            float v = acc0[0][r] + acc1[0][r] * kSplitInv + src[r * 64] + s_bias[co];
+            if (HASRES) v += rv[HASRES ? r : 0];
             if (a.lrelu) v = v > 0.f ? v : v * kSlope;
             a.out[base + (size_t)co * plane_o] = v;
           }

@@ -336,7 +336,7 @@ template <class K>
 hipError_t ensure_lds_attr(K kern, int bytes);
 
 // second generation (weights-stationary, K split across wave pairs): persistent grid of MINB workgroups per CU
-template <int KS, int STRIDE, int VCH, int TR, int TC, int SEGW, int MINB, bool OUTSLOT, class Loader>
+template <int KS, int STRIDE, int VCH, int TR, int TC, int SEGW, int MINB, bool OUTSLOT, class Loader, bool HASRES = false>
 hipError_t launch_conv_x3s(hipStream_t st, const ConvLayer& L, const Loader& ld, int nimg, int Ho, int Wo, float* out,
                            const float* res, bool lrelu, int num_cu) {
   using T = X3sTile<KS, STRIDE, VCH, TR, TC, SEGW>;
@@ -354,7 +354,9 @@ hipError_t launch_conv_x3s(hipStream_t st, const ConvLayer& L, const Loader& ld,
   a.lrelu = lrelu ? 1 : 0;
   a.tiles_x = (Wo + TC - 1) / TC;
   a.tiles_y = (Ho + TR - 1) / TR;
-  auto kern = k_conv_x3s<KS, STRIDE, VCH, TR, TC, SEGW, MINB, OUTSLOT, Loader>;
+  if (res != nullptr && !HASRES)      // residual layers use their own instantiation (16 more registers)
+    return launch_conv_x3s<KS, STRIDE, VCH, TR, TC, SEGW, MINB, OUTSLOT, Loader, true>(st, L, ld, nimg, Ho, Wo, out, res, lrelu, num_cu);
+  auto kern = k_conv_x3s<KS, STRIDE, VCH, TR, TC, SEGW, MINB, OUTSLOT, HASRES, Loader>;
   static_assert(T::LDS_BYTES <= 160 * 1024, "x3s tile does not fit the LDS");
   if (T::LDS_BYTES > 64 * 1024) {
     hipError_t e = ensure_lds_attr(kern, (int)T::LDS_BYTES);
@@ -423,7 +425,7 @@ hipError_t launch_conv(hipStream_t st, const ConvLayer& L, const Loader& ld, int
                        float* out, const float* res, bool lrelu, int f16_Hs = 0, int f16_Ws = 0,
                        size_t f16_lo_off = 0) {
   constexpr int dil = DIL;
-  ConvArgs a;
+  ConvArgs a{};
   a.f16_Hs = f16_Hs;
   a.f16_Ws = f16_Ws;
   a.f16_lo_off = f16_lo_off;
