@@ -662,7 +662,7 @@ struct X3sTile {
   static constexpr int NU = NCB * ROWS_IN * NQ;
   static constexpr int UPT = (NU + 255) / 256;
   static constexpr int RED_FLOATS = 4 * 16 * 64;           // one segment partial per wave
-  static constexpr size_t LDS_BYTES = (size_t)2 * NCB * PLANE * 16 + (size_t)RED_FLOATS * 4 + 32 * 4;
+  static constexpr size_t LDS_BYTES = (size_t)2 * NCB * PLANE * 16 + (size_t)RED_FLOATS * 4 + 32 * 4 + 16;
   static_assert(VCH % 32 == 0 && SPW == 2, "two segments per wave pair member");
   static_assert(TR % SEGH == 0 && TC % SEGW == 0, "tile must be whole segments");
 };
@@ -724,8 +724,10 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
   //   bits 0..12 LDS slot offset (inside s_xh / s_xl), 13..19 column, 20..24 row, 25..28 virtual block, 29 part,
   //   30 valid
   unsigned stab[SLOTS ? LPT : 1];
+  int srel[SLOTS ? LPT : 1];            // slot offset of the copy relative to (image, block 0, hi, row iy0, column ix0)
+  constexpr int DUMMY = 2 * T::NCB * T::PLANE + T::RED_FLOATS / 4 + 8;     // spare LDS slot behind the bias
   if (SLOTS) {
-    static_assert(T::NCB * T::PLANE < 8192 && T::COLS_IN < 128 && T::ROWS_IN < 32 && T::NCB <= 16, "packed staging table");
+    static_assert(DUMMY < 8192 && T::COLS_IN < 128 && T::ROWS_IN < 32 && T::NCB <= 16, "packed staging table");
 #pragma unroll
     for (int e = 0; e < LPT; ++e) {
       const int idx = e * 256 + tid;
@@ -734,10 +736,13 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
       const int r = rem / T::COLS_IN;
       const int cc = rem - r * T::COLS_IN;
       const int di = STRIDE == 1 ? cc : (cc & 1) * T::HALF + (cc >> 1);
-      const unsigned off = (vp >> 1) * T::PLANE + r * T::PITCH + di;
-      stab[e] = idx < NSL ? (off | (cc << 13) | (r << 20) | ((vp >> 1) << 25) | ((vp & 1) << 29) | (1u << 30)) : 0u;
+      const unsigned off = (vp & 1) * (T::NCB * T::PLANE) + (vp >> 1) * T::PLANE + r * T::PITCH + di;
+      const bool ok = idx < NSL;
+      stab[e] = ok ? (off | (cc << 13) | (r << 20) | ((vp >> 1) << 25) | (1u << 30)) : (unsigned)DUMMY;
+      srel[e] = ok ? ld.plane_off(vp >> 1) + (vp & 1) * (ld.H * ld.W) + r * ld.W + cc : 0;
     }
   }
+  unsigned vmask = 0;                   // bit e: the slot fetched in round e lies inside the tensor (else LDS gets 0)
   auto fetch = [&](int tile) {
     const int tx = tile % a.tiles_x, t2 = tile / a.tiles_x;
     const int ty = t2 % a.tiles_y, img = t2 / a.tiles_y;
@@ -745,18 +750,26 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
     int tq = tid;
     asm volatile("" : "+v"(tq));
     if (SLOTS) {
-      const uint4* ibase = ld.image_base(img) + ((ptrdiff_t)iy0 * ld.W + ix0);
-      const int hw = ld.H * ld.W;
+      // branch-free: every lane loads; a slot outside the tensor (zero padding, missing depth plane) reads slot 0
+      // of the image instead and is replaced by zeros when it is committed to LDS
+      const char* ibase = reinterpret_cast<const char*>(ld.image_base(img));
+      const int toff = iy0 * ld.W + ix0;
+      unsigned pmask = 0;               // valid virtual blocks of this image (3-D: neighbouring depth planes)
+#pragma unroll
+      for (int vb = 0; vb < T::NCB; ++vb) pmask |= ld.plane_valid(img, vb) ? (1u << vb) : 0u;
+      vmask = 0;
 #pragma unroll
       for (int e = 0; e < LPT; ++e) {
         unsigned t = stab[e];
-        asm volatile("" : "+v"(t));          // keep the unpacking inside the tile loop (hoisted it spills)
-        const int cc = (t >> 13) & 127, r = (t >> 20) & 31, vb = (t >> 25) & 15, part = (t >> 29) & 1;
-        const int y = iy0 + r, x = ix0 + cc;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if ((t >> 30) && (unsigned)y < (unsigned)ld.H && (unsigned)x < (unsigned)ld.W && ld.plane_valid(img, vb))
-          v = ibase[(ptrdiff_t)ld.plane_off(vb) + part * hw + r * ld.W + cc];
-        *reinterpret_cast<uint4*>(&pre[e * 4]) = v;
+        int rel = srel[e];
+        asm volatile("" : "+v"(t), "+v"(rel));      // keep the unpacking inside the tile loop (hoisted it spills)
+        const int cc = (t >> 13) & 127, r = (t >> 20) & 31, vb = (t >> 25) & 15;
+        const bool ok = (unsigned)(iy0 + r) < (unsigned)ld.H && (unsigned)(ix0 + cc) < (unsigned)ld.W &&
+                        ((pmask >> vb) & 1u) && (t >> 30);
+        // signed: the previous depth plane of a volume lies BEFORE the image base
+        const int soff = ok ? rel + toff : 0;
+        vmask |= ok ? (1u << e) : 0u;
+        *reinterpret_cast<uint4*>(&pre[e * 4]) = *reinterpret_cast<const uint4*>(ibase + (ptrdiff_t)soff * 16);
       }
     } else if (VEC && vec_ok) {
 #pragma unroll
@@ -824,8 +837,9 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
       for (int e = 0; e < LPT; ++e) {
         unsigned t = stab[e];
         asm volatile("" : "+v"(t));
-        // s_xl follows s_xh at NCB * PLANE slots
-        if (t >> 30) s_xh[(t & 8191u) + ((t >> 29) & 1u) * (T::NCB * T::PLANE)] = *reinterpret_cast<const uint4*>(&pre[e * 4]);
+        uint4 v = *reinterpret_cast<const uint4*>(&pre[e * 4]);
+        if (!((vmask >> e) & 1u)) v = make_uint4(0, 0, 0, 0);
+        s_xh[t & 8191u] = v;            // rounds past the tile's last slot write a spare slot
       }
     } else if (VEC && vec_ok) {
 #pragma unroll
@@ -947,6 +961,7 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
     }
     lds_barrier();                      // halo tile free, partials visible
     if (nxt < t_end) commit();
+
 
     {
       const float* src = s_red + (size_t)(wave ^ 2) * 16 * 64 + lane;      // partner: same pixel set, other K half
