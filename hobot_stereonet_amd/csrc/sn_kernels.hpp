@@ -219,6 +219,37 @@ __device__ __forceinline__ size_t low_slot_index(int img, int cb, int part, int 
   return ((((size_t)img * 4 + cb) * 2 + part) * H + y) * (size_t)W + x;
 }
 
+// Cost volume in split-slot form for the first 3-D conv of the slot pipeline:
+//   vol[n][d][c][y][x] = x >= d ? fL[n][c][y][x] - fR[n][c][y][x - d] : 0      (LoadCostVol, materialised)
+// feat fp32 [2n + eye][32][H][W]  ->  slots [n * Dl + d][4 blocks][hi | lo][H][W].  5.5 MB per pair at 1280x720:
+// materialising it costs less than building it element-wise inside the conv's staging loop (two differently
+// aligned scalar reads per element) — that loader made the first aggregation layer 2.6x slower than the others.
+__global__ __launch_bounds__(256) void k_cost_slots(const float* __restrict__ feat, uint4* __restrict__ vol, int Dl,
+                                                    int H, int W, int npairs) {
+  const int plane = H * W;
+  const long total = (long)npairs * Dl * 4 * plane;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int pix = (int)(i % plane);
+  long t = i / plane;
+  const int cb = (int)(t % 4);
+  t /= 4;
+  const int d = (int)(t % Dl), n = (int)(t / Dl);
+  const int y = pix / W, x = pix - y * W;
+  half8 hi, lo;
+  const float* fl = feat + ((size_t)(2 * n) * kC + cb * 8) * plane + pix;
+  const float* fr = fl + (size_t)kC * plane - d;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float v = x >= d ? fl[(size_t)k * plane] - fr[(size_t)k * plane] : 0.f;
+    hi[k] = (_Float16)v;
+    lo[k] = (_Float16)((v - (float)hi[k]) * kSplitScale);
+  }
+  uint4* o = vol + low_slot_index(n * Dl + d, cb, 0, y, x, H, W);
+  o[0] = *reinterpret_cast<const uint4*>(&hi);
+  o[plane] = *reinterpret_cast<const uint4*>(&lo);
+}
+
 // bilinear x16, align_corners=False, values x16 (disparity in full-res px)
 __device__ __forceinline__ float upsample16(const float* low, int hl, int wl, int y, int x) {
   float sy = ((float)y + 0.5f) * (1.0f / 16.0f) - 0.5f;

@@ -814,8 +814,14 @@ int lowres_slots(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, con
     HIP_TRY(h, (launch_conv_x3s<3, 1, 32, 8, 16, 16, 1, false, SlotIn>(st, h->fout, lx, ni, hl, wl, ws.feat, nullptr, false, ncu)));
   }
   if (prof) HIP_TRY(h, hipEventRecord(h->ev[1], st));
-  LoadCostVol lc{ws.feat, Dl, hl, wl};
-  HIP_TRY(h, (launch_conv_x3s<3, 1, 96, 8, 16, 16, 1, true, LoadCostVol>(st, h->agg[0], lc, m * Dl, hl, wl, ws.vol[0], nullptr, true, ncu)));
+  // cost volume -> slots (vol[1]), then every aggregation layer reads slots: agg0 vol[1] -> vol[0], agg1 -> vol[1], ...
+  {
+    const long total = (long)m * Dl * 4 * hl * wl;
+    hipLaunchKernelGGL(k_cost_slots, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ws.feat,
+                       reinterpret_cast<uint4*>(ws.vol[1]), Dl, hl, wl, m);
+    SlotIn lc{U4(ws.vol[1]), Dl, hl, wl};
+    HIP_TRY(h, (launch_conv_x3s<3, 1, 96, 8, 16, 16, 1, true, SlotIn>(st, h->agg[0], lc, m * Dl, hl, wl, ws.vol[0], nullptr, true, ncu)));
+  }
   for (int i = 1; i < kNAgg; ++i) {
     SlotIn lv{U4(ws.vol[(i - 1) & 1]), Dl, hl, wl};
     if (i + 1 < kNAgg)
