@@ -226,7 +226,7 @@ class StereoNetHIP:
                 "bytes_per_launch": by.value}
 
     # -- parity hooks --------------------------------------------------------------------------------
-    def dbg_conv2d(self, x, wt, bias, k, stride=1, dil=1, lrelu=False, residual=None, x3=False):
+    def dbg_conv2d(self, x, wt, bias, k, stride=1, dil=1, lrelu=False, residual=None, x3=False, slots=False):
         x = np.ascontiguousarray(x, np.float32)
         wt = np.ascontiguousarray(wt, np.float32)
         bias = np.ascontiguousarray(bias, np.float32)
@@ -235,7 +235,8 @@ class StereoNetHIP:
         out = np.empty((32, ho, wo), np.float32)
         res = np.ascontiguousarray(residual, np.float32) if residual is not None else None
         self._check(self._lib.sn_dbg_conv2d(self._h, x.ctypes.data, cin, h, w, wt.ctypes.data, bias.ctypes.data, k,
-                                            stride, dil, int(lrelu) | (2 if x3 else 0), _np_ptr(res), out.ctypes.data),
+                                            stride, dil, int(lrelu) | (2 if x3 else 0) | (4 if slots else 0), _np_ptr(res),
+                                            out.ctypes.data),
                     "sn_dbg_conv2d")
         return out
 
@@ -265,14 +266,15 @@ class StereoNetHIP:
                                            bias.ctypes.data, int(split), out.ctypes.data), "sn_dbg_refin")
         return out
 
-    def dbg_conv3d(self, x, wt, bias, lrelu=False, x3=False):
+    def dbg_conv3d(self, x, wt, bias, lrelu=False, x3=False, slots=False):
         x = np.ascontiguousarray(x, np.float32)
         wt = np.ascontiguousarray(wt, np.float32)
         bias = np.ascontiguousarray(bias, np.float32)
         _, d, h, w = x.shape
         out = np.empty_like(x)
         self._check(self._lib.sn_dbg_conv3d(self._h, x.ctypes.data, d, h, w, wt.ctypes.data, bias.ctypes.data,
-                                            int(lrelu) | (2 if x3 else 0), out.ctypes.data), "sn_dbg_conv3d")
+                                            int(lrelu) | (2 if x3 else 0) | (4 if slots else 0), out.ctypes.data),
+                    "sn_dbg_conv3d")
         return out
 
     def dbg_ref_conv_f16(self, x, wt, bias, dil=1, lrelu=False, residual=None):

@@ -1033,6 +1033,31 @@ int check_device(sn_handle* h) {
   return SN_OK;
 }
 
+// host <-> split-slot layout (SlotIn): src/dst fp32 [nimg][32][H][W]
+void host_to_slots(const float* src, int nimg, int H, int W, std::vector<_Float16>& dst) {
+  const size_t plane = (size_t)H * W;
+  dst.assign((size_t)nimg * 8 * plane * 8, (_Float16)0.f);
+  for (int img = 0; img < nimg; ++img)
+    for (int c = 0; c < kC; ++c)
+      for (size_t i = 0; i < plane; ++i) {
+        const float v = src[((size_t)img * kC + c) * plane + i];
+        const _Float16 hi = (_Float16)v;
+        const size_t base = (((size_t)img * 4 + (c >> 3)) * 2) * plane;
+        dst[(base + i) * 8 + (c & 7)] = hi;
+        dst[(base + plane + i) * 8 + (c & 7)] = (_Float16)((v - (float)hi) * kSplitScale);
+      }
+}
+void host_from_slots(const std::vector<_Float16>& src, int nimg, int H, int W, float* dst) {
+  const size_t plane = (size_t)H * W;
+  for (int img = 0; img < nimg; ++img)
+    for (int c = 0; c < kC; ++c)
+      for (size_t i = 0; i < plane; ++i) {
+        const size_t base = (((size_t)img * 4 + (c >> 3)) * 2) * plane;
+        dst[((size_t)img * kC + c) * plane + i] =
+            (float)src[(base + i) * 8 + (c & 7)] + (float)src[(base + plane + i) * 8 + (c & 7)] * kSplitInv;
+      }
+}
+
 }  // namespace
 
 // =====================================================================================================
@@ -1577,9 +1602,42 @@ int sn_dbg_conv2d(sn_handle* h, const float* in, int cin, int h_px, int w, const
   const int taps = k * k;
   const int Ho = stride == 1 ? h_px : h_px / 2, Wo = stride == 1 ? w : w / 2;
   if (stride == 2 && ((h_px & 1) || (w & 1))) return SN_ERR_ARG;
-  const bool x3 = (lrelu & 2) != 0;
+  const bool x3 = (lrelu & 2) != 0, slots = (lrelu & 4) != 0;
   lrelu &= 1;
   if (x3 && !(cin == kC && dil == 1)) return SN_ERR_ARG;
+  if (slots) {          // split-slot tensors in and out through the weights-stationary kernel (fp16 modes' low-res path)
+    if (!x3) return SN_ERR_ARG;
+    ConvLayer Ls;
+    HostLayer hls{wt, bias, kC, cin, taps};
+    if ((rc = upload_conv2d(h, hls, 8, &Ls))) return rc;
+    if ((rc = upload_x3(h, kC, [&](int co, int c, int tap) { return wt[((size_t)co * kC + c) * taps + tap]; }, &Ls, taps)))
+      return rc;
+    std::vector<_Float16> hin, hres, hout((size_t)8 * Ho * Wo * 8);
+    host_to_slots(in, 1, h_px, w, hin);
+    uint4 *din = nullptr, *dout = nullptr;
+    HIP_TRY(h, dalloc(&din, hin.size() / 8));
+    HIP_TRY(h, dalloc(&dout, hout.size() / 8));
+    HIP_TRY(h, hipMemcpy(din, hin.data(), hin.size() * 2, hipMemcpyHostToDevice));
+    const float* dres = nullptr;
+    if (residual) {
+      host_to_slots(residual, 1, Ho, Wo, hres);
+      HIP_TRY(h, hipMemcpy(dout, hres.data(), hres.size() * 2, hipMemcpyHostToDevice));
+      dres = reinterpret_cast<const float*>(dout);
+    }
+    SlotIn ls{din, 0, h_px, w};
+    hipError_t e2 = k == 5 ? launch_conv_x3s<5, 2, 32, 4, 32, 32, 1, true, SlotIn>(h->stream, Ls, ls, 1, Ho, Wo, reinterpret_cast<float*>(dout), dres, lrelu != 0, h->num_cu)
+                           : launch_conv_x3s<3, 1, 32, 8, 16, 16, 2, true, SlotIn>(h->stream, Ls, ls, 1, Ho, Wo, reinterpret_cast<float*>(dout), dres, lrelu != 0, h->num_cu);
+    HIP_TRY(h, e2);
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(hout.data(), dout, hout.size() * 2, hipMemcpyDeviceToHost));
+    host_from_slots(hout, 1, Ho, Wo, out);
+    hipFree(din);
+    hipFree(dout);
+    hipFree(Ls.wx3);
+    hipFree(Ls.wpk);
+    hipFree(Ls.bias);
+    return SN_OK;
+  }
   ConvLayer L;
   HostLayer hl{wt, bias, kC, cin, taps};
   if ((rc = upload_conv2d(h, hl, (k == 5 || cin <= 4) ? 4 : 8, &L))) return rc;
@@ -1709,8 +1767,9 @@ int sn_dbg_conv3d(sn_handle* h, const float* in, int d, int h_px, int w, const f
   if (!h || !in || !wt || !bias || !out || d <= 0) return SN_ERR_ARG;
   int rc = check_device(h);
   if (rc) return rc;
-  const bool x3 = (lrelu & 2) != 0;
+  const bool x3 = (lrelu & 2) != 0, slots = (lrelu & 4) != 0;
   lrelu &= 1;
+  if (slots && !x3) return SN_ERR_ARG;
   ConvLayer L;
   HostLayer hl{wt, bias, kC, kC, 27};
   if ((rc = upload_conv3d(h, hl, &L))) return rc;
@@ -1727,17 +1786,29 @@ int sn_dbg_conv3d(sn_handle* h, const float* in, int d, int h_px, int w, const f
   float *din = nullptr, *dout = nullptr;
   HIP_TRY(h, dalloc(&din, n));
   HIP_TRY(h, dalloc(&dout, n));
+  if (slots) {       // the volume as d split-slot images (same byte count as fp32)
+    std::vector<_Float16> hs, ho(n * 2);
+    host_to_slots(tmp.data(), d, h_px, w, hs);
+    HIP_TRY(h, hipMemcpy(din, hs.data(), n * 4, hipMemcpyHostToDevice));
+    SlotIn ls{reinterpret_cast<const uint4*>(din), d, h_px, w};
+    HIP_TRY(h, (launch_conv_x3s<3, 1, 96, 8, 16, 16, 1, true, SlotIn>(h->stream, L, ls, d, h_px, w, dout, nullptr, lrelu != 0, h->num_cu)));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(ho.data(), dout, n * 4, hipMemcpyDeviceToHost));
+    host_from_slots(ho, d, h_px, w, tmp.data());
+  } else {
   HIP_TRY(h, hipMemcpy(din, tmp.data(), n * 4, hipMemcpyHostToDevice));
   LoadVol3D lv{din, d, h_px, w};
   if (x3) HIP_TRY(h, (launch_conv_x3<1, 8, 32>(h->stream, L, lv, d, h_px, w, dout, nullptr, lrelu != 0)));
   else HIP_TRY(h, (launch_conv<3, 1, 1, 8, 4, 32>(h->stream, L, lv, d, h_px, w, dout, nullptr, lrelu != 0)));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   HIP_TRY(h, hipMemcpy(tmp.data(), dout, n * 4, hipMemcpyDeviceToHost));
+  }
   for (int co = 0; co < kC; ++co)
     for (int z = 0; z < d; ++z)
       memcpy(&out[((size_t)co * d + z) * plane], &tmp[((size_t)z * kC + co) * plane], plane * 4);
   hipFree(din);
   hipFree(dout);
+  hipFree(L.wx3);
   hipFree(L.wpk);
   hipFree(L.bias);
   return SN_OK;

@@ -140,7 +140,9 @@ int sn_get_dominant_kernel(sn_handle *h, char *name, size_t name_cap, int *launc
 
 /* Parity hooks (tests only; they run the product kernels on caller data, host memory) -------- */
 /* one C->32 convolution through the MFMA kernel: in [cin][h][w] fp32, wt [32][cin][k][k], out [32][ho][wo].
- * lrelu bit 0 = LeakyReLU, bit 1 = use the split-operand fp16 kernel of the fp16 modes (3x3, stride 1, cin 32). */
+ * lrelu bit 0 = LeakyReLU, bit 1 = use the split-operand fp16 kernel of the fp16 modes (cin 32; 3x3 stride 1 or
+ * 5x5 stride 2), bit 2 (with bit 1) = run it on split-slot tensors (hi/lo fp16, the fp16 modes' low-resolution
+ * activation format) through the weights-stationary kernel; the hook converts to and from that layout. */
 int sn_dbg_conv2d(sn_handle *h, const float *in, int cin, int h_px, int w, const float *wt,
                   const float *bias, int k, int stride, int dil, int lrelu, const float *residual,
                   float *out);
@@ -155,7 +157,7 @@ int sn_dbg_down0(sn_handle *h, const int8_t *in6, int h_px, int w, const float *
  * selects the hi/lo output of SN_PREC_F16X3 */
 int sn_dbg_refin(sn_handle *h, const float *disp_low, const int8_t *in6, int h_px, int w, int dmax,
                  const float *wt, const float *bias, int split, float *out);
-/* one 3x3x3 32->32 conv3d (+bias, optional LeakyReLU): in [32][d][h][w] -> out [32][d][h][w] */
+/* one 3x3x3 32->32 conv3d (+bias, optional LeakyReLU): in [32][d][h][w] -> out [32][d][h][w]; lrelu bits as above */
 int sn_dbg_conv3d(sn_handle *h, const float *in, int d, int h_px, int w, const float *wt,
                   const float *bias, int lrelu, float *out);
 /* one 32->32 3x3 conv (dilation 1/2/4/8) through the fp16 refinement-tower kernel: in / residual / out are
