@@ -774,6 +774,21 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
     }
   }
   unsigned vmask = 0;                   // bit e: the slot fetched in round e lies inside the tensor (else LDS gets 0)
+  const char* f_ibase = nullptr;
+  int f_iy0 = 0, f_ix0 = 0, f_toff = 0;
+  unsigned f_pmask = 0;
+  auto fetch_one = [&](int e) {         // SLOTS only: copy number e of the tile prepared by fetch()
+    unsigned t = stab[e];
+    int rel = srel[e];
+    asm volatile("" : "+v"(t), "+v"(rel));      // keep the unpacking inside the tile loop (hoisted it spills)
+    const int cc = (t >> 13) & 127, r = (t >> 20) & 31, vb = (t >> 25) & 15;
+    const bool ok = (unsigned)(f_iy0 + r) < (unsigned)ld.H && (unsigned)(f_ix0 + cc) < (unsigned)ld.W &&
+                    ((f_pmask >> vb) & 1u) && (t >> 30);
+    // signed: the previous depth plane of a volume lies BEFORE the image base
+    const int soff = ok ? rel + f_toff : 0;
+    vmask |= ok ? (1u << e) : 0u;
+    *reinterpret_cast<uint4*>(&pre[e * 4]) = *reinterpret_cast<const uint4*>(f_ibase + (ptrdiff_t)soff * 16);
+  };
   auto fetch = [&](int tile) {
     const int tx = tile % a.tiles_x, t2 = tile / a.tiles_x;
     const int ty = t2 % a.tiles_y, img = t2 / a.tiles_y;
@@ -782,26 +797,17 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
     asm volatile("" : "+v"(tq));
     if (SLOTS) {
       // branch-free: every lane loads; a slot outside the tensor (zero padding, missing depth plane) reads slot 0
-      // of the image instead and is replaced by zeros when it is committed to LDS
-      const char* ibase = reinterpret_cast<const char*>(ld.image_base(img));
-      const int toff = iy0 * ld.W + ix0;
-      unsigned pmask = 0;               // valid virtual blocks of this image (3-D: neighbouring depth planes)
+      // of the image instead and is replaced by zeros when it is committed to LDS.  Only the per-tile constants
+      // are set up here; the LPT copies themselves are issued from inside the MFMA loop (fetch_one), where their
+      // address arithmetic runs in the shadow of the matrix pipe.
+      f_ibase = reinterpret_cast<const char*>(ld.image_base(img));
+      f_iy0 = iy0;
+      f_ix0 = ix0;
+      f_toff = iy0 * ld.W + ix0;
+      f_pmask = 0;                      // valid virtual blocks of this image (3-D: neighbouring depth planes)
 #pragma unroll
-      for (int vb = 0; vb < T::NCB; ++vb) pmask |= ld.plane_valid(img, vb) ? (1u << vb) : 0u;
+      for (int vb = 0; vb < T::NCB; ++vb) f_pmask |= ld.plane_valid(img, vb) ? (1u << vb) : 0u;
       vmask = 0;
-#pragma unroll
-      for (int e = 0; e < LPT; ++e) {
-        unsigned t = stab[e];
-        int rel = srel[e];
-        asm volatile("" : "+v"(t), "+v"(rel));      // keep the unpacking inside the tile loop (hoisted it spills)
-        const int cc = (t >> 13) & 127, r = (t >> 20) & 31, vb = (t >> 25) & 15;
-        const bool ok = (unsigned)(iy0 + r) < (unsigned)ld.H && (unsigned)(ix0 + cc) < (unsigned)ld.W &&
-                        ((pmask >> vb) & 1u) && (t >> 30);
-        // signed: the previous depth plane of a volume lies BEFORE the image base
-        const int soff = ok ? rel + toff : 0;
-        vmask |= ok ? (1u << e) : 0u;
-        *reinterpret_cast<uint4*>(&pre[e * 4]) = *reinterpret_cast<const uint4*>(ibase + (ptrdiff_t)soff * 16);
-      }
     } else if (VEC && vec_ok) {
 #pragma unroll
       for (int u = 0; u < T::UPT; ++u) {
@@ -907,6 +913,10 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
   int tile = (int)((long)xcd * total / 8) + lb;
   if (tile >= t_end) return;
   fetch(tile);
+  if (SLOTS) {
+#pragma unroll
+    for (int e = 0; e < LPT; ++e) fetch_one(e);
+  }
   commit();
   __syncthreads();
   const size_t plane_o = (size_t)a.Ho * a.Wo;
@@ -982,7 +992,12 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
         acc1[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[k], xh, acc1[s], 0, 0, 0);
         acc1[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[k], xl, acc1[s], 0, 0, 0);
       }
+      if (SLOTS && k < LPT && nxt < t_end) fetch_one(k);     // one staging copy of the next tile per K-step
       __builtin_amdgcn_sched_barrier(0);
+    }
+    if (SLOTS && nxt < t_end) {
+#pragma unroll
+      for (int e = T::NK; e < LPT; ++e) fetch_one(e);         // (only when a tile has more copies than K-steps)
     }
     // ship the partial of the segment the pair partner finishes
     {
