@@ -106,6 +106,7 @@ struct sn_handle {
   hipStream_t s_low = nullptr, s_ref = nullptr;     // low-res branch / refinement tower (piece pipeline)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_piece[kMaxPieceEvents] = {};
   bool overlap = true;
+  int cu_low = 0, cu_ref = 0; // CU partition of the two pipeline streams (0 = streams share the whole device)
   bool low_slots = false;    // low-resolution branch on split-slot activations (lowres_slots)
   int ovl_cap = 1;           // tower workgroups per CU while the low-res branch runs beside it (SN_OVL_CAP)
   bool ref_dyn = true;       // dynamic tile queue in the fp16 tower (SN_REF_DYN=0: static stride)
@@ -496,7 +497,7 @@ RefGeom make_ref_geom(int Hp, int Wp) {
   g.tiles_y = (Hp + 7) / 8;
   g.H = Hp;
   g.W = Wp;
-  g.Hs = g.tiles_y * 8 + 2 * kRefPad;
+  g.Hs = (Hp + 15) / 16 * 16 + 2 * kRefPad;      // whole 16-row tiles (tall-tile variants of the dilated layers)
   g.Ws = g.tiles_x * 64 + 2 * kRefPad;
   return g;
 }
@@ -595,23 +596,26 @@ hipError_t launch_ref_f16(hipStream_t st, const RefLayerF16& L, const RefGeom& g
   return hipGetLastError();
 }
 
-template <int DIL, int TW>
+template <int DIL, int TW, int TH = 8, int MINW = 2>
 hipError_t launch_ref_f16_v2(hipStream_t st, const RefLayerF16& L, const RefGeom& g, int num_cu, const uint4* in,
                              uint4* out, const uint4* res, int nimg, bool lrelu, int per_cu_cap, unsigned* tile_ctr) {
-  using T = RefTile2<DIL, TW>;
+  using T = RefTile2<DIL, TW, TH>;
   // tile_ctr != nullptr: dynamic tile queue (8 zeroed counters, 64 B apart); nullptr: static stride
-  auto kern = tile_ctr ? (res ? k_ref_conv_f16_v2<DIL, TW, true, true> : k_ref_conv_f16_v2<DIL, TW, false, true>)
-                       : (res ? k_ref_conv_f16_v2<DIL, TW, true, false> : k_ref_conv_f16_v2<DIL, TW, false, false>);
+  auto kern = tile_ctr ? (res ? k_ref_conv_f16_v2<DIL, TW, true, true, TH, MINW> : k_ref_conv_f16_v2<DIL, TW, false, true, TH, MINW>)
+                       : (res ? k_ref_conv_f16_v2<DIL, TW, true, false, TH, MINW> : k_ref_conv_f16_v2<DIL, TW, false, false, TH, MINW>);
   if (T::LDS_BYTES > 64 * 1024) {
     hipError_t e = ensure_lds_attr(kern, T::LDS_BYTES);
     if (e != hipSuccess) return e;
   }
   RefGeom gt = g;                      // tile grid of this variant (the buffer geometry is for 8x64 tiles)
   gt.tiles_x = (g.W + TW - 1) / TW;
+  gt.tiles_y = (g.H + TH - 1) / TH;
   const int total = gt.tiles_x * gt.tiles_y * nimg;
   // per_cu_cap = 1 while the low-resolution branch of the next piece runs on the other stream: one tower
   // workgroup per CU leaves half of the register file / LDS for those kernels to co-reside (+2-3 %)
-  int per_cu = T::LDS_BYTES * 2 <= 160 * 1024 ? 2 : 1;
+  int per_cu = (160 * 1024) / T::LDS_BYTES;
+  if (per_cu > MINW) per_cu = MINW;
+  if (per_cu < 1) per_cu = 1;
   if (per_cu_cap > 0 && per_cu_cap < per_cu) per_cu = per_cu_cap;
   // persistent grid: 8 XCD bands; pick the block count per band so that every block walks the same number
   // of tiles (e.g. 225 tiles per band -> 57 blocks x 4 tiles, not 64 blocks x 3.5)
@@ -688,15 +692,31 @@ bool use_ref_v1() {
   return v;
 }
 
+inline int narrow_tiles() {            // SN_REF_NARROW=3|4: 8x32 tiles with 3 / 4 workgroups per CU for the dilation-1 layers
+  static const int v = getenv("SN_REF_NARROW") ? atoi(getenv("SN_REF_NARROW")) : 0;
+  return v;
+}
+inline bool tall_tiles() {
+  static const bool on = getenv("SN_REF_TALL") != nullptr;
+  return on;
+}
+
 hipError_t ref_conv_f16(hipStream_t st, const RefLayerF16& L, const RefGeom& g, int num_cu, int dil, const uint4* in,
                         uint4* out, const uint4* res, int nimg, bool lrelu, int per_cu_cap = 0,
                         unsigned* tile_ctr = nullptr) {
   if (!use_ref_v1()) {
     switch (dil) {
-      case 1: return launch_ref_f16_v2<1, 64>(st, L, g, num_cu, in, out, res, nimg, lrelu, per_cu_cap, tile_ctr);
+      case 1:
+        if (narrow_tiles() == 4) return launch_ref_f16_v2<1, 32, 8, 4>(st, L, g, num_cu, in, out, res, nimg, lrelu, per_cu_cap, tile_ctr);
+        if (narrow_tiles() == 3) return launch_ref_f16_v2<1, 32, 8, 3>(st, L, g, num_cu, in, out, res, nimg, lrelu, per_cu_cap, tile_ctr);
+        return launch_ref_f16_v2<1, 64>(st, L, g, num_cu, in, out, res, nimg, lrelu, per_cu_cap, tile_ctr);
       case 2: return launch_ref_f16_v2<2, 64>(st, L, g, num_cu, in, out, res, nimg, lrelu, per_cu_cap, tile_ctr);
-      case 4: return launch_ref_f16_v2<4, 64>(st, L, g, num_cu, in, out, res, nimg, lrelu, per_cu_cap, tile_ctr);
-      case 8: return launch_ref_f16_v2<8, 32>(st, L, g, num_cu, in, out, res, nimg, lrelu, per_cu_cap, tile_ctr);
+      case 4:
+        if (tall_tiles()) return launch_ref_f16_v2<4, 32, 16>(st, L, g, num_cu, in, out, res, nimg, lrelu, per_cu_cap, tile_ctr);
+        return launch_ref_f16_v2<4, 64>(st, L, g, num_cu, in, out, res, nimg, lrelu, per_cu_cap, tile_ctr);
+      case 8:
+        if (tall_tiles()) return launch_ref_f16_v2<8, 32, 16>(st, L, g, num_cu, in, out, res, nimg, lrelu, per_cu_cap, tile_ctr);
+        return launch_ref_f16_v2<8, 32>(st, L, g, num_cu, in, out, res, nimg, lrelu, per_cu_cap, tile_ctr);
       default: return hipErrorInvalidValue;
     }
   }
@@ -785,11 +805,11 @@ void free_ws(Workspace* ws) {
 // 16-byte copies.  Only the tensors other kernels read stay fp32 NCHW: the feature map (cost-volume loader, parity
 // hook) and the last aggregation volume (soft-argmin head).
 int lowres_slots(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, const int8_t* in6, bool want_cost,
-                 bool prof) {
+                 bool prof, int ncu_part) {
   const int Hp = h->Hp, Wp = h->Wp, hl = h->hl, wl = h->wl, Dl = h->Dl;
   const size_t HW = (size_t)h->H * h->W;
   const int8_t* in = in6 + (size_t)p0 * 6 * HW;
-  const int ncu = h->num_cu, ni = 2 * m;
+  const int ncu = ncu_part > 0 ? ncu_part : h->num_cu, ni = 2 * m;   // CUs of the stream's partition
   auto U4 = [](float* p) { return reinterpret_cast<const uint4*>(p); };
   HIP_TRY(h, (launch_down0_f16<32, true>(st, h->down0, h->down[0].bias, in, h->H, h->W, ni, Hp / 2, Wp / 2, ws.down[0], ncu)));
   {
@@ -831,18 +851,19 @@ int lowres_slots(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, con
   }
   const float* v = ws.vol[(kNAgg - 1) & 1];
   const int npix = m * hl * wl;
-  hipLaunchKernelGGL(k_head_softargmin<16>, dim3((npix + 63) / 64), dim3(256), 0, st, v, h->aout.w, h->aout.bias, Dl,
+  hipLaunchKernelGGL(k_head_softargmin<16>, dim3((npix + 63) / 64), dim3(512), 0, st, v, h->aout.w, h->aout.bias, Dl,
                      hl, wl, npix, ws.disp_low + (size_t)p0 * hl * wl,
                      want_cost ? ws.cost + (size_t)p0 * Dl * hl * wl : nullptr);
   HIP_TRY(h, hipGetLastError());
   return SN_OK;
 }
 
-int lowres(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, const int8_t* in6, bool want_cost, bool prof) {
+int lowres(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, const int8_t* in6, bool want_cost, bool prof,
+           int ncu_part = 0) {
   const int Hp = h->Hp, Wp = h->Wp, hl = h->hl, wl = h->wl, Dl = h->Dl;
   const size_t HW = (size_t)h->H * h->W;
   const int8_t* in = in6 + (size_t)p0 * 6 * HW;
-  if (h->low_slots) return lowres_slots(h, ws, st, p0, m, in6, want_cost, prof);
+  if (h->low_slots) return lowres_slots(h, ws, st, p0, m, in6, want_cost, prof, ncu_part);
   // --- Siamese feature tower: images = 2m (left, right interleaved), shared weights ---
   {
     LoadI8Eye ld{in, h->H, h->W};
@@ -885,7 +906,7 @@ int lowres(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, const int
   }
   const float* v = ws.vol[(kNAgg - 1) & 1];
   const int npix = m * hl * wl;
-  hipLaunchKernelGGL(k_head_softargmin<16>, dim3((npix + 63) / 64), dim3(256), 0, st, v, h->aout.w, h->aout.bias, Dl,
+  hipLaunchKernelGGL(k_head_softargmin<16>, dim3((npix + 63) / 64), dim3(512), 0, st, v, h->aout.w, h->aout.bias, Dl,
                      hl, wl, npix, ws.disp_low + (size_t)p0 * hl * wl,
                      want_cost ? ws.cost + (size_t)p0 * Dl * hl * wl : nullptr);
   HIP_TRY(h, hipGetLastError());
@@ -894,7 +915,8 @@ int lowres(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, const int
 
 // Refinement of pairs [p0, p0+m), `rb` pairs per tower launch.
 int refine(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, const int8_t* in6, float* out_disp,
-           int32_t* out_raw, bool prof, bool overlapped = false) {
+           int32_t* out_raw, bool prof, bool overlapped = false, int ncu_part = 0) {
+  const int ncu = ncu_part > 0 ? ncu_part : h->num_cu;      // CUs of the stream's partition
   const int Hp = h->Hp, Wp = h->Wp, hl = h->hl, wl = h->wl;
   const size_t HW = (size_t)h->H * h->W;
   const float inv_q = (float)(1.0 / ((double)h->D * (double)kOutScale));
@@ -932,7 +954,7 @@ int refine(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, const int
       const size_t lo_slots = ref16_slots(g, ws.rb) + kRefSlack;       // hi tensor -> lo tensor (F16X3)
       if (h->refin.wfrag) {
         HIP_TRY(h, launch_refin_f16(st, h->refin, h->rin.bias, ws.disp_low + (size_t)q0 * hl * wl, in6 + (size_t)q0 * 6 * HW,
-                                    hl, wl, h->H, h->W, 1.0f / (float)h->D, g, c, rx, x3, lo_slots * 16, h->num_cu));
+                                    hl, wl, h->H, h->W, 1.0f / (float)h->D, g, c, rx, x3, lo_slots * 16, ncu));
       } else if (x3) {
         if (Hp * Wp <= 64 * 128)
           HIP_TRY(h, (launch_conv<3, 1, 1, 4, 4, 32, LoadRefineIn, 2>(st, h->rin, ld, c, Hp, Wp, reinterpret_cast<float*>(rx),
@@ -951,10 +973,10 @@ int refine(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, const int
       unsigned* const chunk_ctr = dyn ? ws.tile_ctr + (size_t)(q0 / ws.rb) * (kTileCtrBytes / sizeof(unsigned)) : nullptr;
       for (int i = 0; i < kNRefRes; ++i) {
         if (x3) {
-          HIP_TRY(h, ref_conv_f16x3(st, h->rres16[i][0], g, h->num_cu, kRefDil[i], rx, rt, nullptr, lo_slots, c, true));
-          HIP_TRY(h, ref_conv_f16x3(st, h->rres16[i][1], g, h->num_cu, kRefDil[i], rt, rx, rx, lo_slots, c, true));
+          HIP_TRY(h, ref_conv_f16x3(st, h->rres16[i][0], g, ncu, kRefDil[i], rx, rt, nullptr, lo_slots, c, true));
+          HIP_TRY(h, ref_conv_f16x3(st, h->rres16[i][1], g, ncu, kRefDil[i], rt, rx, rx, lo_slots, c, true));
         } else {
-          HIP_TRY(h, ref_block_f16(st, h->rres16[i][0], h->rres16[i][1], g, h->num_cu, kRefDil[i], &rx, &rt, c,
+          HIP_TRY(h, ref_block_f16(st, h->rres16[i][0], h->rres16[i][1], g, ncu, kRefDil[i], &rx, &rt, c,
                                    overlapped ? h->ovl_cap : 0, dyn ? chunk_ctr + 2 * i * kTileCtrStride : nullptr));
         }
       }
@@ -1000,11 +1022,11 @@ int forward(sn_handle* h, Workspace& ws, hipStream_t st, int n, const int8_t* in
   for (int p0 = 0; p0 < n; p0 += ws.pb, ++k) {
     const int m = (n - p0) < ws.pb ? (n - p0) : ws.pb;
     // the piece-local low-res buffers are reused by the next piece: only disp_low crosses streams
-    if ((rc = lowres(h, ws, h->s_low, p0, m, in6, want_cost, false))) return rc;
+    if ((rc = lowres(h, ws, h->s_low, p0, m, in6, want_cost, false, h->cu_low))) return rc;
     hipEvent_t e = h->ev_piece[k % kMaxPieceEvents];
     HIP_TRY(h, hipEventRecord(e, h->s_low));
     HIP_TRY(h, hipStreamWaitEvent(h->s_ref, e, 0));
-    if ((rc = refine(h, ws, h->s_ref, p0, m, in6, out_disp, out_raw, false, true))) return rc;
+    if ((rc = refine(h, ws, h->s_ref, p0, m, in6, out_disp, out_raw, false, true, h->cu_ref))) return rc;
   }
   HIP_TRY(h, hipEventRecord(h->ev_join, h->s_ref));
   HIP_TRY(h, hipStreamWaitEvent(st, h->ev_join, 0));
@@ -1172,8 +1194,33 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(SN_ERR_DEVICE);
   for (auto& e : h->ev)
     if (hipEventCreate(&e) != hipSuccess) return fail(SN_ERR_DEVICE);
-  if (hipStreamCreateWithFlags(&h->s_low, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&h->s_ref, hipStreamNonBlocking) != hipSuccess ||
+  // The two pipeline streams get DISJOINT CU sets (CU-mask bit i is CU i/8 of XCD i%8, so any run of 8k bits takes k
+  // CUs from every XCD and workgroup b still lands on XCD b%8): the weights-stationary low-resolution kernels need
+  // 112 KB of LDS and a whole register file, the tower wants every CU it runs on for itself, so sharing CUs made
+  // both wait for each other.  The tower is HBM-bound and loses little on fewer CUs.  SN_CU_LOW = CUs of the
+  // low-resolution stream (multiple of 8; 0 = no partition).
+  {
+    int low = 0;      // default off: measured 1940 pairs/s shared vs 1700 / 1680 / 1510 with 64 / 96 / 128 CUs split off
+    if (const char* e = getenv("SN_CU_LOW")) low = atoi(e);
+    low = low / 8 * 8;
+    if (low > 0 && low < h->num_cu - 8 && h->num_cu % 8 == 0 && h->num_cu <= 256 && h->precision != SN_PREC_FP32) {
+      uint32_t mlow[8] = {0}, mref[8] = {0};
+      for (int i = 0; i < h->num_cu; ++i) (i < low ? mlow : mref)[i / 32] |= 1u << (i % 32);
+      const uint32_t words = (uint32_t)((h->num_cu + 31) / 32);
+      if (hipExtStreamCreateWithCUMask(&h->s_low, words, mlow) == hipSuccess &&
+          hipExtStreamCreateWithCUMask(&h->s_ref, words, mref) == hipSuccess) {
+        h->cu_low = low;
+        h->cu_ref = h->num_cu - low;
+      } else {
+        if (h->s_low) hipStreamDestroy(h->s_low);
+        if (h->s_ref) hipStreamDestroy(h->s_ref);
+        h->s_low = h->s_ref = nullptr;
+        hipGetLastError();
+      }
+    }
+  }
+  if ((h->s_low == nullptr && hipStreamCreateWithFlags(&h->s_low, hipStreamNonBlocking) != hipSuccess) ||
+      (h->s_ref == nullptr && hipStreamCreateWithFlags(&h->s_ref, hipStreamNonBlocking) != hipSuccess) ||
       hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess)
     return fail(SN_ERR_DEVICE);
@@ -1186,6 +1233,7 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
   {
     const char* e = getenv("SN_REF_DYN");     // dynamic tile queue of the fp16 tower (default on)
     h->ref_dyn = e ? atoi(e) != 0 : true;
+    if (h->cu_low > 0) h->ovl_cap = 0;     // exclusive CUs: the tower keeps its full occupancy
     if (const char* c = getenv("SN_OVL_CAP")) h->ovl_cap = atoi(c);
   }
 
