@@ -816,8 +816,8 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
         const int rem = idx - cb * (T::ROWS_IN * T::NQ);
         const int r = rem / T::NQ, q = rem - r * T::NQ;
         const int y = iy0 + r, x = ix0 - T::SH + 4 * q;
-        const float* base;
-        unsigned cs;
+        const float* base = nullptr;
+        unsigned cs = 0;
         const bool row_ok = idx < T::NU && ld.cb_base(img, cb, base, cs) && (unsigned)y < (unsigned)ld.H;
         const bool inside = row_ok && x >= 0 && x + 3 < ld.W;
         const bool edge = row_ok && !inside && x + 3 >= 0 && x < ld.W;
