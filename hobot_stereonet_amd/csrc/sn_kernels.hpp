@@ -1556,7 +1556,7 @@ __global__ __launch_bounds__(256, 2) void k_ref_conv_f16(const uint4* __restrict
 //     N = KW (+ 4*SPW), and 0 for the very last phase.
 //   * TW = 32 for dilation 8 keeps three buffers inside the 160 KiB LDS.
 // ------------------------------------------------------------------------------------------
-template <int DIL, int TW_, int TH_ = 8>
+template <int DIL, int TW_, int TH_ = 8, int NB_ = 3>
 struct RefTile2 {
   static constexpr int TH = TH_, TW = TW_;
   static constexpr int CSEG = TW / 32, SPW = TH * CSEG / 4;
@@ -1566,7 +1566,7 @@ struct RefTile2 {
   static constexpr int NINST = (HALF + 63) / 64;
   static constexpr int KW = (NINST + 3) / 4;            // DMA instructions per wave per group (constant)
   static constexpr int BUF = NINST * 64;
-  static constexpr int NBUF = 3;
+  static constexpr int NBUF = NB_;
   static constexpr int LDS_BYTES = NBUF * BUF * 16 + 16;   // + the two tile-queue words of the dynamic schedule
   static constexpr int NSTORE = 4 * SPW;
 };
@@ -1640,12 +1640,18 @@ __device__ __forceinline__ void ref2_compute(const uint4* lds_lane, const half8 
 // through two LDS words behind the ring.
 // TH = 16 (dilated layers): a taller tile re-reads less halo through L2 (dilation 8: 3.0x instead of 4.5x the
 // tile's own pixels, dilation 4: 1.9x instead of 2.25x).
-template <int DIL, int TW, bool RES, bool DYN, int TH = 8, int MINW = 2>
+// NB = 2 (dilation 8): two ring buffers instead of three.  The 110 KB three-buffer ring of the 24x48 halo tile
+// allows one workgroup per CU only; with 74 KB two fit, and eight resident waves hide more latency than a DMA
+// group in flight across the barrier does (dilation 4 went 76 -> 58 us per launch by the same move to two
+// workgroups per CU).  Schedule with NB = 2: group g+1 is issued after the barrier of phase g (its buffer was
+// read in phase g-1) and must be complete at the barrier of phase g+1.
+template <int DIL, int TW, bool RES, bool DYN, int TH = 8, int MINW = 2, int NB = 3>
 __global__ __launch_bounds__(256, MINW) void k_ref_conv_f16_v2(const uint4* __restrict__ in, uint4* out,
                                                             const uint4* res, const uint4* __restrict__ wfrag,
                                                             const float* __restrict__ bias, RefGeom g, int nimg,
                                                             int lrelu, unsigned* tile_ctr) {
-  using T = RefTile2<DIL, TW, TH>;
+  using T = RefTile2<DIL, TW, TH, NB>;
+  static_assert(NB == 2 || NB == 3, "ring depth");
   extern __shared__ __attribute__((aligned(16))) uint4 lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1716,7 +1722,7 @@ __global__ __launch_bounds__(256, MINW) void k_ref_conv_f16_v2(const uint4* __re
   };
   auto issue = [&](int gp, int img, int y0, int x0) {         // DMA group of phase gp (tile img,y0,x0) -> ring slot gp % 3
     const char* src = reinterpret_cast<const char*>(in) + (tile_base(img, y0 - DIL, x0 - DIL) + 2u * (gp & 1) * plane_b);
-    uint4* dst = lds + (gp % 3) * T::BUF;
+    uint4* dst = lds + (gp % NB) * T::BUF;
 #pragma unroll
     for (int k = 0; k < T::KW; ++k) {
       int i = wave + 4 * k;
@@ -1730,10 +1736,10 @@ __global__ __launch_bounds__(256, MINW) void k_ref_conv_f16_v2(const uint4* __re
   int img, y0, x0, nimg_ = 0, ny0 = 0, nx0 = 0;
   tile_xy(t0, img, y0, x0);
   issue(0, img, y0, x0);
-  issue(1, img, y0, x0);
+  if (NB == 3) issue(1, img, y0, x0);
   int t_next = t0 + nlb;                                      // tile ti+1 (second round is static as well)
   int t_next2 = t0 + 2 * nlb;                                 // tile ti+2 (static schedule; DYN overwrites it)
-  unsigned* tile_slot = reinterpret_cast<unsigned*>(lds + 3 * T::BUF);   // not volatile: that would drain vmcnt
+  unsigned* tile_slot = reinterpret_cast<unsigned*>(lds + NB * T::BUF);  // not volatile: that would drain vmcnt
   unsigned* const my_ctr = tile_ctr + 16 * xcd;
 
   f32x16 acc[T::SPW];
@@ -1742,8 +1748,13 @@ __global__ __launch_bounds__(256, MINW) void k_ref_conv_f16_v2(const uint4* __re
     const bool has_next = t_next < t_end;                     // wave-uniform
     if (has_next) tile_xy(t_next, nimg_, ny0, nx0);           // one coordinate decode per tile
     // ---- phase g0 (channels 0..15) ----
-    if (ti == 0) wait_vmcnt<T::KW>();                         // younger than group 0: group 1
-    else wait_vmcnt<T::KW + T::NSTORE>();                     // ... plus the previous tile's stores
+    if (NB == 3) {
+      if (ti == 0) wait_vmcnt<T::KW>();                       // younger than group 0: group 1
+      else wait_vmcnt<T::KW + T::NSTORE>();                   // ... plus the previous tile's stores
+    } else {
+      if (ti == 0) wait_vmcnt<0>();                           // two buffers: nothing else is in flight yet
+      else wait_vmcnt<T::NSTORE>();                           // only the previous tile's stores are younger
+    }
     block_barrier();
     // `fetched` is written asynchronously by the returning atomic: it is defined opaquely up front and tied
     // read-write into the asm so that hipcc keeps it in one register and never copies it before the wait below.
@@ -1761,17 +1772,21 @@ __global__ __launch_bounds__(256, MINW) void k_ref_conv_f16_v2(const uint4* __re
           : "v"(my_ctr), "v"(one)
           : "memory");
     }
-    if (has_next) issue(g0 + 2, nimg_, ny0, nx0);
+    if (NB == 3) {
+      if (has_next) issue(g0 + 2, nimg_, ny0, nx0);
+    } else {
+      issue(g0 + 1, img, y0, x0);                             // second channel half of THIS tile
+    }
     // accumulators start at the bias: saves one add per output in the epilogue
 #pragma unroll
     for (int s = 0; s < T::SPW; ++s)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[s][r] = bv[r];
-    ref2_compute<DIL, TW, 0, TH>(lds + (g0 % 3) * T::BUF + lane_off, wf, acc);
+    ref2_compute<DIL, TW, 0, TH>(lds + (g0 % NB) * T::BUF + lane_off, wf, acc);
 
     // ---- phase g0+1 (channels 16..31) ----
-    if (has_next) wait_vmcnt<T::KW>();                        // younger than group g0+1: group g0+2
-    else wait_vmcnt<0>();                                     // last phase of this block
+    if (NB == 3 && has_next) wait_vmcnt<T::KW>();             // younger than group g0+1: group g0+2
+    else wait_vmcnt<0>();                                     // last phase of this block / two-buffer ring
     if (DYN && has_next && wave == 0) {                       // the atomic is older than group g0+2: it has returned
       asm volatile("" : "+v"(fetched));
       if (lane == 0) tile_slot[ti & 1] = fetched;
@@ -1802,8 +1817,8 @@ __global__ __launch_bounds__(256, MINW) void k_ref_conv_f16_v2(const uint4* __re
       }
     }
     const bool more = has_next;
-    if (more) issue(g0 + 3, nimg_, ny0, nx0);
-    ref2_compute<DIL, TW, 1, TH>(lds + ((g0 + 1) % 3) * T::BUF + lane_off, wf, acc);
+    if (more) issue(NB == 3 ? g0 + 3 : g0 + 2, nimg_, ny0, nx0);     // NB = 2: first half of the next tile
+    ref2_compute<DIL, TW, 1, TH>(lds + ((g0 + 1) % NB) * T::BUF + lane_off, wf, acc);
     if (RES) {
       if (more) wait_vmcnt<T::KW>(); else wait_vmcnt<0>();
 #pragma unroll

@@ -596,13 +596,13 @@ hipError_t launch_ref_f16(hipStream_t st, const RefLayerF16& L, const RefGeom& g
   return hipGetLastError();
 }
 
-template <int DIL, int TW, int TH = 8, int MINW = 2>
+template <int DIL, int TW, int TH = 8, int MINW = 2, int NB = 3>
 hipError_t launch_ref_f16_v2(hipStream_t st, const RefLayerF16& L, const RefGeom& g, int num_cu, const uint4* in,
                              uint4* out, const uint4* res, int nimg, bool lrelu, int per_cu_cap, unsigned* tile_ctr) {
-  using T = RefTile2<DIL, TW, TH>;
+  using T = RefTile2<DIL, TW, TH, NB>;
   // tile_ctr != nullptr: dynamic tile queue (8 zeroed counters, 64 B apart); nullptr: static stride
-  auto kern = tile_ctr ? (res ? k_ref_conv_f16_v2<DIL, TW, true, true, TH, MINW> : k_ref_conv_f16_v2<DIL, TW, false, true, TH, MINW>)
-                       : (res ? k_ref_conv_f16_v2<DIL, TW, true, false, TH, MINW> : k_ref_conv_f16_v2<DIL, TW, false, false, TH, MINW>);
+  auto kern = tile_ctr ? (res ? k_ref_conv_f16_v2<DIL, TW, true, true, TH, MINW, NB> : k_ref_conv_f16_v2<DIL, TW, false, true, TH, MINW, NB>)
+                       : (res ? k_ref_conv_f16_v2<DIL, TW, true, false, TH, MINW, NB> : k_ref_conv_f16_v2<DIL, TW, false, false, TH, MINW, NB>);
   if (T::LDS_BYTES > 64 * 1024) {
     hipError_t e = ensure_lds_attr(kern, T::LDS_BYTES);
     if (e != hipSuccess) return e;
@@ -696,6 +696,14 @@ inline int narrow_tiles() {            // SN_REF_NARROW=3|4: 8x32 tiles with 3 /
   static const int v = getenv("SN_REF_NARROW") ? atoi(getenv("SN_REF_NARROW")) : 0;
   return v;
 }
+inline bool wide_d4() {                // SN_REF_D4_TW64: 8x64 tiles for dilation 4 (110 KB ring: one workgroup per CU)
+  static const bool on = getenv("SN_REF_D4_TW64") != nullptr;
+  return on;
+}
+inline bool ring3_d8() {               // SN_REF_D8_RING3: three ring buffers for dilation 8 (110 KB: one workgroup per CU)
+  static const bool on = getenv("SN_REF_D8_RING3") != nullptr;
+  return on;
+}
 inline bool tall_tiles() {
   static const bool on = getenv("SN_REF_TALL") != nullptr;
   return on;
@@ -713,10 +721,12 @@ hipError_t ref_conv_f16(hipStream_t st, const RefLayerF16& L, const RefGeom& g, 
       case 2: return launch_ref_f16_v2<2, 64>(st, L, g, num_cu, in, out, res, nimg, lrelu, per_cu_cap, tile_ctr);
       case 4:
         if (tall_tiles()) return launch_ref_f16_v2<4, 32, 16>(st, L, g, num_cu, in, out, res, nimg, lrelu, per_cu_cap, tile_ctr);
-        return launch_ref_f16_v2<4, 64>(st, L, g, num_cu, in, out, res, nimg, lrelu, per_cu_cap, tile_ctr);
+        if (wide_d4()) return launch_ref_f16_v2<4, 64>(st, L, g, num_cu, in, out, res, nimg, lrelu, per_cu_cap, tile_ctr);
+        return launch_ref_f16_v2<4, 32>(st, L, g, num_cu, in, out, res, nimg, lrelu, per_cu_cap, tile_ctr);   // 61 KB: two per CU
       case 8:
         if (tall_tiles()) return launch_ref_f16_v2<8, 32, 16>(st, L, g, num_cu, in, out, res, nimg, lrelu, per_cu_cap, tile_ctr);
-        return launch_ref_f16_v2<8, 32>(st, L, g, num_cu, in, out, res, nimg, lrelu, per_cu_cap, tile_ctr);
+        if (ring3_d8()) return launch_ref_f16_v2<8, 32>(st, L, g, num_cu, in, out, res, nimg, lrelu, per_cu_cap, tile_ctr);
+        return launch_ref_f16_v2<8, 32, 8, 2, 2>(st, L, g, num_cu, in, out, res, nimg, lrelu, per_cu_cap, tile_ctr);   // 74 KB: two per CU
       default: return hipErrorInvalidValue;
     }
   }
