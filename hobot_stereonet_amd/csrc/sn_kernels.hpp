@@ -2088,6 +2088,229 @@ __global__ __launch_bounds__(256, 1) void k_ref_block_f16(const uint4* __restric
 }
 
 // ------------------------------------------------------------------------------------------
+// Fused residual block, third form: sized so that TWO workgroups fit on a CU (this round's measurements: one
+// workgroup per CU is what held the first two fused kernels and the dilated v2 variants back).
+//   output tile 6 x 62, t on 8 x 64 (16 segments = 4 per wave), x on 10 x 66; ONE x tile in LDS (both channel
+//   halves, 43 KB) + the t tile (34 KB) = 77 KB; weights of both convs in registers (144), biases in LDS.
+//   The x tile is dead after stage 1 (the residual is re-read from global memory, L2-hot, as 8-byte loads issued
+//   BEFORE the next DMA group so the counted vmcnt retires them without draining it), so the next tile's x streams
+//   in during stage 2; the second resident workgroup covers what is left of the DMA latency.
+// VMEM order per tile and wave: [12 residual loads][2*KW DMA][12 stores]; tile start waits vmcnt(12).
+// ------------------------------------------------------------------------------------------
+struct FusedHTile {
+  static constexpr int TH = 6, TWO = 62;
+  static constexpr int RT = TH + 2, CT = 64;
+  static constexpr int RX = TH + 4, CX = 66;
+  static constexpr int PX = RX * CX, PT = RT * CT;
+  static constexpr int XHALF = 2 * PX;
+  static constexpr int NINST = (XHALF + 63) / 64;
+  static constexpr int KW = (NINST + 3) / 4;
+  static constexpr int XBUF = NINST * 64;
+  static constexpr int TBUF = 4 * PT + 64;
+  static constexpr int LDS_BYTES = (2 * XBUF + TBUF) * 16 + 64 * 4;      // + both bias vectors
+  static constexpr int S1 = RT * 2 / 4, S2 = TH * 2 / 4;
+  static constexpr int NSTORE = 4 * S2;
+  static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+};
+
+__global__ __launch_bounds__(256, 2) void k_ref_block_f16_h(const uint4* __restrict__ xin, uint4* __restrict__ yout,
+                                                            const uint4* __restrict__ wfrag1, const float* __restrict__ bias1,
+                                                            const uint4* __restrict__ wfrag2, const float* __restrict__ bias2,
+                                                            RefGeom g, int nimg, uint4* zero_slot) {
+  using T = FusedHTile;
+  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+  uint4* xbuf = lds;                       // [kk][XBUF]
+  uint4* tbuf = lds + 2 * T::XBUF;         // t tile [4 blocks][RT][CT]
+  float* s_b = reinterpret_cast<float*>(tbuf + T::TBUF);     // bias1[32], bias2[32]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, gh = lane >> 5;
+
+  half8 w1[18], w2[18];
+#pragma unroll
+  for (int i = 0; i < 18; ++i) {
+    const uint4 a = wfrag1[i * 64 + lane], b = wfrag2[i * 64 + lane];
+    w1[i] = *reinterpret_cast<const half8*>(&a);
+    w2[i] = *reinterpret_cast<const half8*>(&b);
+  }
+  if (tid < 32) s_b[tid] = bias1[tid];
+  else if (tid < 64) s_b[tid] = bias2[tid - 32];
+#pragma unroll
+  for (int i = 0; i < 18; ++i) {
+    asm volatile("" : "+v"(w1[i]));
+    asm volatile("" : "+v"(w2[i]));
+  }
+
+  const int per_img = g.tiles_x * g.tiles_y;
+  const int total = per_img * nimg;
+  const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, nlb = gridDim.x >> 3;
+  const int t_begin = (int)((long)xcd * total / 8), t_end = (int)((long)(xcd + 1) * total / 8);
+  const int t0 = t_begin + lb;
+  if (t0 >= t_end) return;
+  const int ntiles = (t_end - t0 + nlb - 1) / nlb;
+
+  auto tile_xy = [&](int ti, int& img, int& y0, int& x0) {
+    const int t = t0 + ti * nlb;
+    img = t / per_img;
+    const int rem = t - img * per_img;
+    const int ty = rem / g.tiles_x;
+    y0 = ty * T::TH;
+    x0 = (rem - ty * g.tiles_x) * T::TWO;
+  };
+  // fixed per-lane slot offsets of the DMA instructions of this wave (relative to the tile's x origin)
+  unsigned dma_off[T::KW];
+#pragma unroll
+  for (int k = 0; k < T::KW; ++k) {
+    int i = wave + 4 * k;
+    i = i < T::NINST ? i : T::NINST - 1;
+    int s = i * 64 + lane;
+    s = s < T::XHALF ? s : T::XHALF - 1;
+    const int pc = s / T::PX;
+    const int rem = s - pc * T::PX;
+    const int r = rem / T::CX;
+    const int c = rem - r * T::CX;
+    dma_off[k] = ((unsigned)pc * g.Hs + r) * g.Ws + c;
+  }
+  auto issue_x = [&](int ti) {             // both channel halves of tile ti
+    int img, y0, x0;
+    tile_xy(ti, img, y0, x0);
+    const size_t origin = (((size_t)img * 4) * g.Hs + (y0 - 2 + kRefPad)) * g.Ws + (x0 - 2 + kRefPad);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const uint4* src = xin + origin + (size_t)(2 * kk) * g.Hs * g.Ws;
+      uint4* dst = xbuf + kk * T::XBUF;
+#pragma unroll
+      for (int k = 0; k < T::KW; ++k) {
+        int i = wave + 4 * k;
+        i = i < T::NINST ? i : T::NINST - 1;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + dma_off[k]),
+                                         (__attribute__((address_space(3))) void*)(dst + i * 64), 16, 0, 0);
+      }
+    }
+  };
+
+  wait_vmcnt<0>();
+  issue_x(0);
+
+  for (int ti = 0; ti < ntiles; ++ti) {
+    int img, y0, x0;
+    tile_xy(ti, img, y0, x0);
+    if (ti == 0) wait_vmcnt<0>();
+    else wait_vmcnt<T::NSTORE>();      // younger than this tile's x: the previous tile's stores
+    block_barrier();                   // x tile visible; everyone is past the previous tile's stage 2 (t buffer free)
+    const uint4* xa = xbuf;
+    const uint4* xb = xbuf + T::XBUF;
+
+    // ---- stage 1: t = lrelu(conv1(x) + b1) on 8 x 64 ----
+    {
+      f32x16 acc[T::S1];
+#pragma unroll
+      for (int s = 0; s < T::S1; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[s][r] = s_b[(r & 3) + 8 * (r >> 2) + 4 * gh];
+      const int seg0 = wave * T::S1;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const uint4* base = (kk ? xb : xa) + gh * T::PX + j;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+          for (int s = 0; s < T::S1; ++s) {
+            const int seg = seg0 + s;
+            const int off = ((seg >> 1) + ky) * T::CX + (seg & 1) * 32 + kx;
+            const half8 v = *reinterpret_cast<const half8*>(base + off);
+            acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[tap * 2 + kk], v, acc[s], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < T::S1; ++s) {
+        const int seg = seg0 + s;
+        const int tr = seg >> 1, tc = (seg & 1) * 32 + j;
+        const int gy = y0 - 1 + tr, gx = x0 - 1 + tc;
+        const bool inside = (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          half4 hv;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float u = lrelu_fast(acc[s][4 * q + e]);
+            hv[e] = inside ? (_Float16)u : (_Float16)0.f;
+          }
+          *reinterpret_cast<half4*>(reinterpret_cast<char*>(tbuf + q * T::PT + tr * T::CT + tc) + gh * 8) = hv;
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    block_barrier();                   // t tile complete; the x tile is dead from here on
+
+    // ---- stage 2: y = lrelu(x + conv2(t) + b2) on 6 x 62 ----
+    {
+      const int seg0 = wave * T::S2;
+      // residual x at the output pixels: 8-byte global loads (L2-hot), issued before the next DMA group
+      uint2 rres[T::NSTORE];
+#pragma unroll
+      for (int s = 0; s < T::S2; ++s) {
+        const int seg = seg0 + s;
+        const int orow = seg >> 1, ocol = (seg & 1) * 32 + j;
+        // clamp masked lanes onto a valid slot (their result is discarded)
+        const int y = y0 + orow, x = x0 + (ocol < T::TWO ? ocol : 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const char* rp = reinterpret_cast<const char*>(xin + ((((size_t)img * 4 + q) * g.Hs + (y + kRefPad)) * g.Ws + (x + kRefPad))) + gh * 8;
+          asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rres[s * 4 + q]) : "v"(rp) : "memory");
+        }
+      }
+      if (ti + 1 < ntiles) issue_x(ti + 1);
+
+      f32x16 acc[T::S2];
+#pragma unroll
+      for (int s = 0; s < T::S2; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[s][r] = s_b[32 + (r & 3) + 8 * (r >> 2) + 4 * gh];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const uint4* base = tbuf + (2 * kk + gh) * T::PT + j;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+          for (int s = 0; s < T::S2; ++s) {
+            const int seg = seg0 + s;
+            const int off = ((seg >> 1) + ky) * T::CT + (seg & 1) * 32 + kx;
+            const half8 v = *reinterpret_cast<const half8*>(base + off);
+            acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2[tap * 2 + kk], v, acc[s], 0, 0, 0);
+          }
+        }
+      }
+      if (ti + 1 < ntiles) wait_vmcnt<2 * T::KW>(); else wait_vmcnt<0>();      // the residual loads are older than the DMA
+#pragma unroll
+      for (int i = 0; i < T::NSTORE; ++i) asm volatile("" : "+v"(rres[i]));
+#pragma unroll
+      for (int s = 0; s < T::S2; ++s) {
+        const int seg = seg0 + s;
+        const int orow = seg >> 1, ocol = (seg & 1) * 32 + j;
+        const int y = y0 + orow, x = x0 + ocol;
+        const bool ok = ocol < T::TWO && y < g.H && x < g.W;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const half4 rv = *reinterpret_cast<const half4*>(&rres[s * 4 + q]);
+          half4 hv;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float u = lrelu_fast(acc[s][4 * q + e] + (float)rv[e]);
+            hv[e] = ok ? (_Float16)u : (_Float16)0.f;
+          }
+          uint4* dst = ok ? yout + ((((size_t)img * 4 + q) * g.Hs + (y + kRefPad)) * g.Ws + (x + kRefPad)) : zero_slot;
+          *reinterpret_cast<half4*>(reinterpret_cast<char*>(dst) + gh * 8) = hv;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Wave-specialised fused residual block (second generation).  One 512-thread workgroup per CU:
 //   waves 0-3 ("stage 1"): conv1 of tile k   — x half-tiles stream through a 3-deep LDS-DMA ring (as v2),
 //                          t = lrelu(conv1(x)+b1) is written to LDS buffer T[k & 1];

@@ -652,6 +652,27 @@ hipError_t launch_ref_block_f16(hipStream_t st, const RefLayerF16& L1, const Ref
   return hipGetLastError();
 }
 
+// third form: 77 KB of LDS, two workgroups per CU (SN_FUSE=3)
+hipError_t launch_ref_block_f16_h(hipStream_t st, const RefLayerF16& L1, const RefLayerF16& L2, const RefGeom& g,
+                                  int num_cu, const uint4* x, uint4* y, int nimg) {
+  using T = FusedHTile;
+  auto kern = k_ref_block_f16_h;
+  hipError_t e = ensure_lds_attr(kern, T::LDS_BYTES);
+  if (e != hipSuccess) return e;
+  RefGeom gt = g;
+  gt.tiles_x = (g.W + T::TWO - 1) / T::TWO;
+  gt.tiles_y = (g.H + T::TH - 1) / T::TH;
+  const int total = gt.tiles_x * gt.tiles_y * nimg;
+  const int band = (total + 7) / 8;
+  int cap = 2 * num_cu / 8;                // two workgroups per CU
+  if (cap < 1) cap = 1;
+  const int rounds = (band + cap - 1) / cap;
+  const int nlb = (band + rounds - 1) / rounds;
+  hipLaunchKernelGGL(kern, dim3(nlb * 8), dim3(256), T::LDS_BYTES, st, x, y, L1.wfrag, L1.bias, L2.wfrag, L2.bias, gt,
+                     nimg, y /* slot 0 = top-left pad corner, zero by construction */);
+  return hipGetLastError();
+}
+
 template <int DIL>
 hipError_t launch_ref_block_f16_ws(hipStream_t st, const RefLayerF16& L1, const RefLayerF16& L2, const RefGeom& g,
                                    int num_cu, const uint4* x, uint4* y, int nimg) {
@@ -742,8 +763,9 @@ hipError_t ref_conv_f16(hipStream_t st, const RefLayerF16& L, const RefGeom& g, 
 hipError_t ref_block_f16(hipStream_t st, const RefLayerF16& L1, const RefLayerF16& L2, const RefGeom& g, int num_cu,
                          int dil, uint4** cur, uint4** oth, int nimg, int per_cu_cap = 0, unsigned* tile_ctr = nullptr) {
   if (const int fm = use_fused_block(dil)) {
-    hipError_t e = fm == 2 ? launch_ref_block_f16_ws<1>(st, L1, L2, g, num_cu, *cur, *oth, nimg)
-                           : launch_ref_block_f16<1>(st, L1, L2, g, num_cu, *cur, *oth, nimg);
+    hipError_t e = fm == 3   ? launch_ref_block_f16_h(st, L1, L2, g, num_cu, *cur, *oth, nimg)
+                   : fm == 2 ? launch_ref_block_f16_ws<1>(st, L1, L2, g, num_cu, *cur, *oth, nimg)
+                             : launch_ref_block_f16<1>(st, L1, L2, g, num_cu, *cur, *oth, nimg);
     uint4* t = *cur;
     *cur = *oth;
     *oth = t;

@@ -99,7 +99,7 @@ def test_two_stream_piece_pipeline_is_bit_identical(model_factory, prec):
         assert (singles[i][0] == disp[i]).all() and (singles[i][1] == raw[i]).all(), i
 
 
-@pytest.mark.parametrize("fused", [0, 1, 2])
+@pytest.mark.parametrize("fused", [0, 1, 2, 3])
 @pytest.mark.parametrize("h,w,dil", [(8, 62, 1), (64, 96, 1), (45, 80, 1), (100, 129, 1), (37, 250, 1), (720, 1280, 1),
                                      (40, 70, 2)])
 def test_residual_block_f16(eng16, oracle, h, w, dil, fused):
