@@ -108,7 +108,8 @@ struct sn_handle {
   bool overlap = true;
   int cu_low = 0, cu_ref = 0; // CU partition of the two pipeline streams (0 = streams share the whole device)
   bool low_slots = false;    // low-resolution branch on split-slot activations (lowres_slots)
-  int ovl_cap = 1;           // tower workgroups per CU while the low-res branch runs beside it (SN_OVL_CAP)
+  int ovl_cap = 0;           // cap on tower workgroups per CU while the low-res branch runs beside it (SN_OVL_CAP; 0 = none:
+                             // the weights-stationary low-res kernels cannot share a CU with a tower workgroup anyway)
   bool ref_dyn = true;       // dynamic tile queue in the fp16 tower (SN_REF_DYN=0: static stride)
   bool use_graphs = true;    // hipGraph replay for the async single-pair path (SN_NO_GRAPH disables)
   ConvLayer down[kNDown], fres[kNFeatRes][2], fout, agg[kNAgg], rin, rres[kNRefRes][2];
