@@ -759,6 +759,7 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
   constexpr int DUMMY = 2 * T::NCB * T::PLANE + T::RED_FLOATS / 4 + 8;     // spare LDS slot behind the bias
   if (SLOTS) {
     static_assert(DUMMY < 8192 && T::COLS_IN < 128 && T::ROWS_IN < 32 && T::NCB <= 16, "packed staging table");
+    static_assert(LPT <= 32, "one validity bit per staging round");
 #pragma unroll
     for (int e = 0; e < LPT; ++e) {
       const int idx = e * 256 + tid;
