@@ -2117,7 +2117,7 @@ struct FusedHTile {
 __global__ __launch_bounds__(256, 2) void k_ref_block_f16_h(const uint4* __restrict__ xin, uint4* __restrict__ yout,
                                                             const uint4* __restrict__ wfrag1, const float* __restrict__ bias1,
                                                             const uint4* __restrict__ wfrag2, const float* __restrict__ bias2,
-                                                            RefGeom g, int nimg, uint4* zero_slot) {
+                                                            RefGeom g, int nimg, uint4* /*zero_slot*/) {
   using T = FusedHTile;
   extern __shared__ __attribute__((aligned(16))) uint4 lds[];
   uint4* xbuf = lds;                       // [kk][XBUF]
@@ -2172,13 +2172,38 @@ __global__ __launch_bounds__(256, 2) void k_ref_block_f16_h(const uint4* __restr
     const int c = rem - r * T::CX;
     dma_off[k] = ((unsigned)pc * g.Hs + r) * g.Ws + c;
   }
-  auto issue_x = [&](int ti) {             // both channel halves of tile ti
-    int img, y0, x0;
-    tile_xy(ti, img, y0, x0);
-    const size_t origin = (((size_t)img * 4) * g.Hs + (y0 - 2 + kRefPad)) * g.Ws + (x0 - 2 + kRefPad);
+  // Addressing as in k_ref_conv_f16_v2: every global address is a uniform 32-bit byte offset of the tile (SGPRs,
+  // once per tile) plus a per-lane 32-bit byte offset that never changes (computed here once).  The phase timing
+  // of the first version of this kernel showed 5 k cycles of address arithmetic in stage 2 and 4 k in its epilogue
+  // against 5.3 k cycles of MFMAs per tile.
+  const unsigned plane_b = (unsigned)g.Hs * (unsigned)g.Ws * 16u;
+  auto tile_base = [&](int img, int y, int x) -> unsigned {
+    return (((unsigned)img * 4u * (unsigned)g.Hs + (unsigned)(y + kRefPad)) * (unsigned)g.Ws + (unsigned)(x + kRefPad)) * 16u;
+  };
+#pragma unroll
+  for (int k = 0; k < T::KW; ++k) dma_off[k] *= 16u;                           // bytes
+  unsigned t_off[T::S1];            // stage 1: LDS byte offset of this lane's t pixel (block 0, + gh * 8)
+#pragma unroll
+  for (int s = 0; s < T::S1; ++s) {
+    const int seg = wave * T::S1 + s;
+    t_off[s] = (unsigned)((seg >> 1) * T::CT + (seg & 1) * 32 + j) * 16u + gh * 8u;
+  }
+  // stage 2: output = residual byte offsets relative to the tile base (the two lanes per row that fall into the
+  // next tile's first columns read a valid slot there and simply do not store)
+  unsigned o_off[T::S2];
+  unsigned o_ok = 0;                     // bit s: this lane's column of segment s is one of the 62 real ones
+#pragma unroll
+  for (int s = 0; s < T::S2; ++s) {
+    const int seg = wave * T::S2 + s;
+    const int orow = seg >> 1, ocol = (seg & 1) * 32 + j;
+    o_off[s] = ((unsigned)orow * (unsigned)g.Ws + (unsigned)ocol) * 16u + gh * 8u;
+    o_ok |= ocol < T::TWO ? (1u << s) : 0u;
+  }
+  auto issue_x = [&](int img, int y0, int x0) {             // both channel halves of tile (img, y0, x0)
+    const unsigned origin = tile_base(img, y0 - 2, x0 - 2);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      const uint4* src = xin + origin + (size_t)(2 * kk) * g.Hs * g.Ws;
+      const char* src = reinterpret_cast<const char*>(xin) + (origin + 2u * kk * plane_b);
       uint4* dst = xbuf + kk * T::XBUF;
 #pragma unroll
       for (int k = 0; k < T::KW; ++k) {
@@ -2191,13 +2216,15 @@ __global__ __launch_bounds__(256, 2) void k_ref_block_f16_h(const uint4* __restr
   };
 
   wait_vmcnt<0>();
-  issue_x(0);
+  bool prev_full = false;
+  int img, y0, x0, nimg_ = 0, ny0 = 0, nx0 = 0;
+  tile_xy(0, img, y0, x0);
+  issue_x(img, y0, x0);
 
   for (int ti = 0; ti < ntiles; ++ti) {
-    int img, y0, x0;
-    tile_xy(ti, img, y0, x0);
-    if (ti == 0) wait_vmcnt<0>();
-    else wait_vmcnt<T::NSTORE>();      // younger than this tile's x: the previous tile's stores
+    if (ti + 1 < ntiles) tile_xy(ti + 1, nimg_, ny0, nx0);      // one coordinate decode per tile
+    if (ti == 0 || !prev_full) wait_vmcnt<0>();
+    else wait_vmcnt<T::NSTORE>();      // younger than this tile's x: the previous tile's NSTORE (exec-masked) stores
     block_barrier();                   // x tile visible; everyone is past the previous tile's stage 2 (t buffer free)
     const uint4* xa = xbuf;
     const uint4* xb = xbuf + T::XBUF;
@@ -2225,12 +2252,16 @@ __global__ __launch_bounds__(256, 2) void k_ref_block_f16_h(const uint4* __restr
           }
         }
       }
+      // t positions outside the image are conv2's zero padding; tiles whose whole t region lies inside skip the test
+      const bool t_interior = y0 >= 1 && y0 - 1 + T::RT <= g.H && x0 >= 1 && x0 - 1 + T::CT <= g.W;      // uniform
 #pragma unroll
       for (int s = 0; s < T::S1; ++s) {
-        const int seg = seg0 + s;
-        const int tr = seg >> 1, tc = (seg & 1) * 32 + j;
-        const int gy = y0 - 1 + tr, gx = x0 - 1 + tc;
-        const bool inside = (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W;
+        bool inside = true;
+        if (!t_interior) {
+          const int seg = seg0 + s;
+          const int gy = y0 - 1 + (seg >> 1), gx = x0 - 1 + (seg & 1) * 32 + j;
+          inside = (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W;
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           half4 hv;
@@ -2239,7 +2270,7 @@ __global__ __launch_bounds__(256, 2) void k_ref_block_f16_h(const uint4* __restr
             const float u = lrelu_fast(acc[s][4 * q + e]);
             hv[e] = inside ? (_Float16)u : (_Float16)0.f;
           }
-          *reinterpret_cast<half4*>(reinterpret_cast<char*>(tbuf + q * T::PT + tr * T::CT + tc) + gh * 8) = hv;
+          *reinterpret_cast<half4*>(reinterpret_cast<char*>(tbuf + q * T::PT) + t_off[s]) = hv;
         }
       }
     }
@@ -2250,20 +2281,18 @@ __global__ __launch_bounds__(256, 2) void k_ref_block_f16_h(const uint4* __restr
     {
       const int seg0 = wave * T::S2;
       // residual x at the output pixels: 8-byte global loads (L2-hot), issued before the next DMA group
+      const unsigned tb = tile_base(img, y0, x0);
       uint2 rres[T::NSTORE];
 #pragma unroll
-      for (int s = 0; s < T::S2; ++s) {
-        const int seg = seg0 + s;
-        const int orow = seg >> 1, ocol = (seg & 1) * 32 + j;
-        // clamp masked lanes onto a valid slot (their result is discarded)
-        const int y = y0 + orow, x = x0 + (ocol < T::TWO ? ocol : 0);
+      for (int q = 0; q < 4; ++q) {
+        const char* rq = reinterpret_cast<const char*>(xin) + (tb + (unsigned)q * plane_b);        // uniform
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const char* rp = reinterpret_cast<const char*>(xin + ((((size_t)img * 4 + q) * g.Hs + (y + kRefPad)) * g.Ws + (x + kRefPad))) + gh * 8;
+        for (int s = 0; s < T::S2; ++s) {
+          const char* rp = rq + o_off[s];
           asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rres[s * 4 + q]) : "v"(rp) : "memory");
         }
       }
-      if (ti + 1 < ntiles) issue_x(ti + 1);
+      if (ti + 1 < ntiles) issue_x(nimg_, ny0, nx0);
 
       f32x16 acc[T::S2];
 #pragma unroll
@@ -2288,26 +2317,30 @@ __global__ __launch_bounds__(256, 2) void k_ref_block_f16_h(const uint4* __restr
       if (ti + 1 < ntiles) wait_vmcnt<2 * T::KW>(); else wait_vmcnt<0>();      // the residual loads are older than the DMA
 #pragma unroll
       for (int i = 0; i < T::NSTORE; ++i) asm volatile("" : "+v"(rres[i]));
+      const bool interior = y0 + T::TH <= g.H && x0 + T::TWO <= g.W;            // uniform
 #pragma unroll
       for (int s = 0; s < T::S2; ++s) {
-        const int seg = seg0 + s;
-        const int orow = seg >> 1, ocol = (seg & 1) * 32 + j;
-        const int y = y0 + orow, x = x0 + ocol;
-        const bool ok = ocol < T::TWO && y < g.H && x < g.W;
+        bool ok = (o_ok >> s) & 1u;
+        if (!interior) {
+          const int seg = seg0 + s;
+          const int y = y0 + (seg >> 1), x = x0 + (seg & 1) * 32 + j;
+          ok = ok && y < g.H && x < g.W;
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const half4 rv = *reinterpret_cast<const half4*>(&rres[s * 4 + q]);
           half4 hv;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float u = lrelu_fast(acc[s][4 * q + e] + (float)rv[e]);
-            hv[e] = ok ? (_Float16)u : (_Float16)0.f;
-          }
-          uint4* dst = ok ? yout + ((((size_t)img * 4 + q) * g.Hs + (y + kRefPad)) * g.Ws + (x + kRefPad)) : zero_slot;
-          *reinterpret_cast<half4*>(reinterpret_cast<char*>(dst) + gh * 8) = hv;
+          for (int e = 0; e < 4; ++e) hv[e] = (_Float16)lrelu_fast(acc[s][4 * q + e] + (float)rv[e]);
+          // (pixels outside the image stay zero: the border of y is never written)
+          if (ok) *reinterpret_cast<half4*>(reinterpret_cast<char*>(yout) + (tb + (unsigned)q * plane_b) + o_off[s]) = hv;
         }
       }
+      prev_full = interior;      // an edge tile may skip whole store instructions: the next wait must not count them
     }
+    img = nimg_;
+    y0 = ny0;
+    x0 = nx0;
   }
 }
 
