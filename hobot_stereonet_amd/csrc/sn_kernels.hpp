@@ -1767,6 +1767,7 @@ __global__ __launch_bounds__(256, MINW) void k_ref_conv_f16_v2(const uint4* __re
       asm volatile(
           "s_mov_b64 %1, exec\n\t"
           "s_mov_b64 exec, 1\n\t"
+          "v_mov_b32 %0, -1\n\t"                      // sentinel: overwritten when the atomic returns
           "global_atomic_add %0, %2, %3, off sc0\n\t"
           "s_mov_b64 exec, %1"
           : "+v"(fetched), "=&s"(saved_exec)
@@ -1790,6 +1791,12 @@ __global__ __launch_bounds__(256, MINW) void k_ref_conv_f16_v2(const uint4* __re
     else wait_vmcnt<0>();                                     // last phase of this block / two-buffer ring
     if (DYN && has_next && wave == 0) {                       // the atomic is older than group g0+2: it has returned
       asm volatile("" : "+v"(fetched));
+      // belt and braces: should a returning atomic ever be retired out of order with the DMA groups, the sentinel
+      // is still there -> drain and read again (never taken in practice; costs one readfirstlane + compare per tile)
+      if (__builtin_amdgcn_readfirstlane(fetched) == 0xFFFFFFFFu) {
+        wait_vmcnt<0>();
+        asm volatile("" : "+v"(fetched));
+      }
       if (lane == 0) tile_slot[ti & 1] = fetched;
       // block_barrier() is a bare s_barrier: an ordinary LDS write has to be retired by its own wave first
       // (the ring itself is filled by LDS-DMA and ordered by vmcnt)
