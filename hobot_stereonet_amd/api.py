@@ -18,7 +18,7 @@ import numpy as np
 from . import build as _build
 
 SN_MEM_HOST, SN_MEM_DEVICE = 0, 1
-PREC_FP32, PREC_F16X3, PREC_F16 = 0, 1, 2
+PREC_DEFAULT, PREC_F16X3, PREC_F16, PREC_FP32 = 0, 1, 2, 3      # include/stereonet_hip.h; 0 selects PREC_F16
 STAGES = ("features", "aggregate", "refine", "refine_conv", "total")
 
 
@@ -32,7 +32,8 @@ class SnIoInfo(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("dmax", C.c_int), ("in_channels", C.c_int),
                 ("max_batch", C.c_int), ("precision", C.c_int), ("task_num", C.c_int), ("device", C.c_int),
                 ("out_scale", C.c_float), ("in_bytes", C.c_size_t), ("out_bytes", C.c_size_t),
-                ("flops_per_pair", C.c_double)]
+                ("flops_per_pair", C.c_double), ("refine_chunk", C.c_int), ("piece", C.c_int),
+                ("tower_streams", C.c_int), ("reserved", C.c_int)]
 
 
 class StereoNetError(RuntimeError):
@@ -73,13 +74,24 @@ def load_library(path: Optional[str] = None):
     lib.sn_infer_batch.argtypes = [vp, ip, i8p, i32p, fp, ip, vp]
     lib.sn_preprocess_nv12.argtypes = [vp, u8p, u8p, ip, ip, i8p, ip, vp]
     lib.sn_infer_sbs_nv12.argtypes = [vp, u8p, ip, ip, i32p, fp, i8p, ip, vp]
+    lib.sn_preprocess_sbs_nv12_batch.argtypes = [vp, ip, u8p, ip, ip, i8p, ip, vp]
     lib.sn_submit.argtypes = [vp, i8p, i32p, fp, ip, C.POINTER(C.c_uint64)]
+    lib.sn_submit_nv12.argtypes = [vp, u8p, ip, ip, i32p, fp, ip, C.POINTER(C.c_uint64)]
     lib.sn_wait.argtypes = [vp, C.c_uint64, C.POINTER(C.c_float)]
     lib.sn_synchronize.argtypes = [vp]
     lib.sn_set_profiling.argtypes = [vp, ip]
     lib.sn_get_stage_ms.argtypes = [vp, C.POINTER(C.c_float), ip]
     lib.sn_get_dominant_kernel.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(ip), C.POINTER(C.c_double),
                                            C.POINTER(C.c_double)]
+    lib.sn_mgpu_shard.argtypes = [ip, ip, ip, C.POINTER(ip), C.POINTER(ip)]
+    lib.sn_mgpu_create.argtypes = [C.c_char_p, C.POINTER(SnConfig), C.POINTER(ip), ip, C.POINTER(vp)]
+    lib.sn_mgpu_destroy.argtypes = [vp]
+    lib.sn_mgpu_get_info.argtypes = [vp, C.POINTER(ip), C.POINTER(ip), C.POINTER(ip)]
+    lib.sn_mgpu_get_handle.argtypes = [vp, ip, C.POINTER(vp)]
+    lib.sn_mgpu_infer_batch.argtypes = [vp, ip, i8p, i32p, fp]
+    lib.sn_mgpu_infer_batch_device.argtypes = [vp, ip, C.POINTER(vp), i32p, fp]
+    lib.sn_mgpu_last_error.restype = C.c_char_p
+    lib.sn_mgpu_last_error.argtypes = [vp]
     lib.sn_dbg_conv2d.argtypes = [vp, fp, ip, ip, ip, fp, fp, ip, ip, ip, ip, fp, fp]
     lib.sn_dbg_down0.argtypes = [vp, i8p, ip, ip, fp, fp, ip, fp]
     lib.sn_dbg_refin.argtypes = [vp, fp, i8p, ip, ip, ip, fp, fp, ip, fp]
@@ -89,8 +101,9 @@ def load_library(path: Optional[str] = None):
     lib.sn_dbg_ref_block_f16.argtypes = [vp, fp, ip, ip, fp, fp, fp, fp, ip, fp]
     lib.sn_dbg_read.argtypes = [vp, C.c_char_p, fp, C.c_size_t, C.POINTER(C.c_size_t)]
     for name in ("sn_create", "sn_destroy", "sn_get_io_info", "sn_infer_i8", "sn_infer_batch", "sn_preprocess_nv12",
-                 "sn_infer_sbs_nv12", "sn_submit", "sn_wait", "sn_synchronize", "sn_set_profiling",
-                 "sn_get_stage_ms", "sn_get_dominant_kernel", "sn_dbg_conv2d", "sn_dbg_down0", "sn_dbg_refin", "sn_dbg_conv3d", "sn_dbg_ref_conv_f16", "sn_dbg_ref_conv_f16x3", "sn_dbg_ref_block_f16", "sn_dbg_read"):
+                 "sn_infer_sbs_nv12", "sn_preprocess_sbs_nv12_batch", "sn_submit", "sn_submit_nv12", "sn_wait", "sn_synchronize", "sn_set_profiling",
+                 "sn_get_stage_ms", "sn_get_dominant_kernel", "sn_mgpu_shard", "sn_mgpu_create", "sn_mgpu_destroy",
+                 "sn_mgpu_get_info", "sn_mgpu_get_handle", "sn_mgpu_infer_batch", "sn_mgpu_infer_batch_device", "sn_dbg_conv2d", "sn_dbg_down0", "sn_dbg_refin", "sn_dbg_conv3d", "sn_dbg_ref_conv_f16", "sn_dbg_ref_conv_f16x3", "sn_dbg_ref_block_f16", "sn_dbg_read"):
         getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
@@ -108,7 +121,7 @@ class StereoNetHIP:
     """One GPU's StereoNet engine (sn_handle)."""
 
     def __init__(self, model_file: str, device: int = -1, max_batch: int = 1, width: int = 0, height: int = 0,
-                 dmax: int = 0, precision: int = PREC_FP32, task_num: int = 4, refine_chunk: int = 0,
+                 dmax: int = 0, precision: int = PREC_DEFAULT, task_num: int = 4, refine_chunk: int = 0,
                  piece: int = 0):
         self._lib = load_library()
         self._h = C.c_void_p()
@@ -123,6 +136,7 @@ class StereoNetHIP:
         self.info = info
         self.width, self.height, self.dmax = info.width, info.height, info.dmax
         self.max_batch = info.max_batch
+        self.refine_chunk, self.piece, self.tower_streams = info.refine_chunk, info.piece, info.tower_streams
         self.out_scale = float(info.out_scale)
         self.flops_per_pair = float(info.flops_per_pair)
 
@@ -180,6 +194,19 @@ class StereoNetHIP:
                                                  SN_MEM_HOST, None), "sn_preprocess_nv12")
         return out
 
+    def preprocess_sbs_nv12_device(self, n: int, sbs_ptr: int, out_ptr: int, stream: int = 0):
+        """n side-by-side NV12 frames (device, n*3*H*W bytes) -> n int8 model tensors (device), on `stream`."""
+        self._check(self._lib.sn_preprocess_sbs_nv12_batch(self._h, n, sbs_ptr, 2 * self.width, self.height, out_ptr,
+                                                           SN_MEM_DEVICE, stream or None), "sn_preprocess_sbs_nv12_batch")
+
+    def preprocess_sbs_nv12(self, sbs: np.ndarray) -> np.ndarray:
+        """uint8 (n, 3*H*W) side-by-side NV12 frames -> int8 (n, 6, H, W) model tensors (host buffers)."""
+        x = np.ascontiguousarray(sbs, dtype=np.uint8).reshape(-1, 3 * self.width * self.height)
+        out = np.empty((x.shape[0], 6, self.height, self.width), np.int8)
+        self._check(self._lib.sn_preprocess_sbs_nv12_batch(self._h, x.shape[0], x.ctypes.data, 2 * self.width, self.height,
+                                                           out.ctypes.data, SN_MEM_HOST, None), "sn_preprocess_sbs_nv12_batch")
+        return out
+
     def infer_sbs_nv12(self, sbs: np.ndarray, want_tensor: bool = False):
         """sbs: uint8 side-by-side NV12 frame (H*3/2 rows of 2W bytes) -> (disp, raw[, tensor])"""
         sbs = np.ascontiguousarray(sbs, dtype=np.uint8)
@@ -197,6 +224,17 @@ class StereoNetHIP:
         t = C.c_uint64()
         self._check(self._lib.sn_submit(self._h, x.ctypes.data, _np_ptr(raw_out), _np_ptr(disp_out), timeout_ms,
                                         C.byref(t)), "sn_submit")
+        return t.value
+
+    def submit_nv12(self, sbs: np.ndarray, raw_out: Optional[np.ndarray], disp_out: Optional[np.ndarray],
+                    timeout_ms: int = -1) -> int:
+        """async Run on FeedImg's raw side-by-side NV12 frame (uint8, 3*H*W bytes): half the H2D bytes of submit()."""
+        x = np.ascontiguousarray(sbs, dtype=np.uint8)
+        if x.size != 3 * self.width * self.height:
+            raise StereoNetError(-1, "submit_nv12", f"frame has {x.size} bytes, expected {3 * self.width * self.height}")
+        t = C.c_uint64()
+        self._check(self._lib.sn_submit_nv12(self._h, x.ctypes.data, 2 * self.width, self.height, _np_ptr(raw_out),
+                                             _np_ptr(disp_out), timeout_ms, C.byref(t)), "sn_submit_nv12")
         return t.value
 
     def wait(self, ticket: int) -> float:
@@ -316,3 +354,76 @@ class StereoNetHIP:
         out = np.empty(n.value, np.float32)
         self._check(self._lib.sn_dbg_read(self._h, what.encode(), out.ctypes.data, n.value, C.byref(n)), "sn_dbg_read")
         return out
+
+
+def mgpu_shard(n: int, ndev: int, k: int):
+    """(first, count) of shard k when n pairs are cut over ndev devices (sn_mgpu_shard; needs no GPU)."""
+    lib = load_library()
+    first, count = C.c_int(), C.c_int()
+    rc = lib.sn_mgpu_shard(n, ndev, k, C.byref(first), C.byref(count))
+    if rc != 0:
+        raise StereoNetError(rc, "sn_mgpu_shard")
+    return first.value, count.value
+
+
+class StereoNetMultiGPU:
+    """sn_mgpu_*: one batch sharded over the GPUs of one node inside ONE process (one host thread per GPU)."""
+
+    def __init__(self, model_file: str, devices=None, ndev: int = 0, max_batch: int = 1, precision: int = PREC_DEFAULT,
+                 refine_chunk: int = 0, piece: int = 0, width: int = 0, height: int = 0, dmax: int = 0):
+        self._lib = load_library()
+        self._m = C.c_void_p()
+        devs = list(devices) if devices is not None else None
+        n = len(devs) if devs is not None else ndev
+        arr = (C.c_int * n)(*devs) if devs is not None else None
+        cfg = SnConfig(-1, max_batch, width, height, dmax, precision, 4, refine_chunk, piece)
+        rc = self._lib.sn_mgpu_create(model_file.encode(), C.byref(cfg), arr, n, C.byref(self._m))
+        if rc != 0:
+            self._m = C.c_void_p()
+            raise StereoNetError(rc, f"sn_mgpu_create({model_file!r}, ndev={n})")
+        nd, per, kind = C.c_int(), C.c_int(), C.c_int()
+        self._lib.sn_mgpu_get_info(self._m, C.byref(nd), C.byref(per), C.byref(kind))
+        self.ndev, self.per_device_batch, self.gather_kind = nd.value, per.value, kind.value
+        h = C.c_void_p()
+        self._lib.sn_mgpu_get_handle(self._m, 0, C.byref(h))
+        info = SnIoInfo()
+        self._lib.sn_get_io_info(h, C.byref(info))
+        self.width, self.height, self.dmax = info.width, info.height, info.dmax
+        self.max_batch = max_batch
+
+    def _check(self, rc: int, where: str):
+        if rc != 0:
+            raise StereoNetError(rc, where, self._lib.sn_mgpu_last_error(self._m).decode() if self._m else "")
+
+    def infer(self, in6: np.ndarray):
+        """int8 (n,6,H,W) host array -> (disp float32 (n,H,W), raw int32 (n,H,W)); the host is the gather root."""
+        x = np.ascontiguousarray(in6, dtype=np.int8)
+        n = x.shape[0]
+        disp = np.empty((n, self.height, self.width), np.float32)
+        raw = np.empty((n, self.height, self.width), np.int32)
+        self._check(self._lib.sn_mgpu_infer_batch(self._m, n, x.ctypes.data, raw.ctypes.data, disp.ctypes.data),
+                    "sn_mgpu_infer_batch")
+        return disp, raw
+
+    def infer_device(self, n: int, in_ptrs, raw_root_ptr: int, disp_root_ptr: int):
+        """in_ptrs[k] = device pointer of shard k on device k; outputs gathered on device 0."""
+        arr = (C.c_void_p * self.ndev)(*[C.c_void_p(p) for p in in_ptrs])
+        self._check(self._lib.sn_mgpu_infer_batch_device(self._m, n, arr, raw_root_ptr or None, disp_root_ptr or None),
+                    "sn_mgpu_infer_batch_device")
+
+    def close(self):
+        if getattr(self, "_m", None) and self._m.value:
+            self._lib.sn_mgpu_destroy(self._m)
+            self._m = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

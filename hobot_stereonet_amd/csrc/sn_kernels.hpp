@@ -1658,23 +1658,6 @@ __global__ __launch_bounds__(256, MINW) void k_ref_conv_f16_v2(const uint4* __re
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, gh = lane >> 5;
 
-  half8 wf[18];
-#pragma unroll
-  for (int i = 0; i < 18; ++i) {
-    const uint4 v = wfrag[i * 64 + lane];
-    wf[i] = *reinterpret_cast<const half8*>(&v);
-  }
-  float bv[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) bv[r] = bias[(r & 3) + 8 * (r >> 2) + 4 * gh];
-  // Consume the ordinary loads HERE so that hipcc's own vmcnt bookkeeping is clean before the loop;
-  // otherwise it re-inserts s_waitcnt vmcnt(0) at the first MFMA of every iteration (loop-header merge)
-  // and drains the LDS-DMA ring.
-#pragma unroll
-  for (int i = 0; i < 18; ++i) asm volatile("" : "+v"(wf[i]));
-#pragma unroll
-  for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(bv[r]));
-
   const int per_img = g.tiles_x * g.tiles_y;
   const int total = per_img * nimg;
   const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, nlb = gridDim.x >> 3;
@@ -1733,11 +1716,28 @@ __global__ __launch_bounds__(256, MINW) void k_ref_conv_f16_v2(const uint4* __re
     }
   };
 
-  wait_vmcnt<0>();
   int img, y0, x0, nimg_ = 0, ny0 = 0, nx0 = 0;
   tile_xy(t0, img, y0, x0);
   issue(0, img, y0, x0);
   if (NB == 3) issue(1, img, y0, x0);
+  // Weights and bias are fetched AFTER the first tile's DMA groups are on their way, so the two latencies of a
+  // workgroup's start-up overlap (~1-2 us of every launch).  The loads are consumed HERE (hipcc waits for them with
+  // vmcnt(0), which also lands the first groups) so that its own vmcnt bookkeeping is clean before the loop; otherwise
+  // it re-inserts s_waitcnt vmcnt(0) at the first MFMA of every iteration (loop-header merge) and drains the ring.
+  half8 wf[18];
+#pragma unroll
+  for (int i = 0; i < 18; ++i) {
+    const uint4 v = wfrag[i * 64 + lane];
+    wf[i] = *reinterpret_cast<const half8*>(&v);
+  }
+  float bv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bv[r] = bias[(r & 3) + 8 * (r >> 2) + 4 * gh];
+#pragma unroll
+  for (int i = 0; i < 18; ++i) asm volatile("" : "+v"(wf[i]));
+#pragma unroll
+  for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(bv[r]));
+  wait_vmcnt<0>();
   int t_next = t0 + nlb;                                      // tile ti+1 (second round is static as well)
   int t_next2 = t0 + 2 * nlb;                                 // tile ti+2 (static schedule; DYN overwrites it)
   unsigned* tile_slot = reinterpret_cast<unsigned*>(lds + NB * T::BUF);  // not volatile: that would drain vmcnt

@@ -28,6 +28,7 @@ constexpr int kNDown = 4, kNFeatRes = 6, kNAgg = 4, kNRefRes = 6;
 constexpr int kRefDil[kNRefRes] = {1, 2, 4, 8, 1, 1};
 constexpr float kOutScale = 2.60443857769133e-6f;   // stereonet_node.cpp:282
 constexpr int kMaxPieceEvents = 64;
+constexpr int kMaxTowerStreams = 2;
 
 #define HIP_TRY(h, expr)                                                              \
   do {                                                                                \
@@ -71,8 +72,9 @@ struct Workspace {          // activations for up to `nb` pairs
   float* vol[2] = {nullptr, nullptr};
   float* cost = nullptr;     // [nb][Dl][hl][wl] (debug / parity)
   float* disp_low = nullptr;
-  float* ref[2] = {nullptr, nullptr};
-  uint4* ref16[2] = {nullptr, nullptr};   // fp16 NCHW8c padded (SN_PREC_F16)
+  int ns = 1;                 // tower streams this workspace serves: one (x, t) activation pair per stream
+  float* ref[2 * kMaxTowerStreams] = {};
+  uint4* ref16[2 * kMaxTowerStreams] = {};   // fp16 NCHW8c padded (fp16 modes): [2 * stream + {x, t}]
   int n_chunks = 0;
   unsigned* tile_ctr = nullptr;           // dynamic tile queues of the fp16 tower: [12 launches][8 XCDs][16] uints
   float* out_disp = nullptr;
@@ -92,8 +94,9 @@ struct Slot {                // async request slot (sn_submit / sn_wait)
   uint64_t ticket = 0;       // 0 = free
   // hipGraph of {H2D, forward, D2H} per output mask (1 = int32, 2 = float, 3 = both): the second request with a
   // given mask is captured, later ones replay it (the ~45 launches of a single-pair forward are launch-bound)
-  hipGraphExec_t gexec[4] = {nullptr, nullptr, nullptr, nullptr};
-  int uses[4] = {0, 0, 0, 0};
+  // the first index is the input kind: 0 = int8 model tensor (sn_submit), 1 = side-by-side NV12 frame (sn_submit_nv12)
+  hipGraphExec_t gexec[2][4] = {};
+  int uses[2][4] = {};
 };
 
 }  // namespace
@@ -103,10 +106,13 @@ struct sn_handle {
   int W = 0, H = 0, D = 0, Wp = 0, Hp = 0, wl = 0, hl = 0, Dl = 0;
   int max_batch = 1, precision = 0, task_num = 4, refine_chunk = 1, piece = 8;
   hipStream_t stream = nullptr;
-  hipStream_t s_low = nullptr, s_ref = nullptr;     // low-res branch / refinement tower (piece pipeline)
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_piece[kMaxPieceEvents] = {};
+  // piece pipeline: the low-resolution branch of piece k+1 runs on s_low while the refinement towers of piece k run
+  // on s_tow[]; consecutive tower chunks alternate between the tower streams so that the ramp-up / tail of one
+  // chunk's launches is filled by the other chunk's workgroups
+  hipStream_t s_low = nullptr, s_tow[kMaxTowerStreams] = {};
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_tow_join[kMaxTowerStreams] = {}, ev_piece[kMaxPieceEvents] = {};
   bool overlap = true;
-  int cu_low = 0, cu_ref = 0; // CU partition of the two pipeline streams (0 = streams share the whole device)
+  int tower_streams = kMaxTowerStreams;
   bool low_slots = false;    // low-resolution branch on split-slot activations (lowres_slots)
   int ovl_cap = 0;           // cap on tower workgroups per CU while the low-res branch runs beside it (SN_OVL_CAP; 0 = none:
                              // the weights-stationary low-res kernels cannot share a CU with a tower workgroup anyway)
@@ -779,9 +785,10 @@ hipError_t ref_block_f16(hipStream_t st, const RefLayerF16& L1, const RefLayerF1
 }
 
 // ---- workspace -----------------------------------------------------------------------------------
-int alloc_ws(sn_handle* h, Workspace* ws, int nb, int rb) {
+int alloc_ws(sn_handle* h, Workspace* ws, int nb, int rb, int ns) {
   ws->nb = nb;
   ws->rb = rb;
+  ws->ns = (ns > 1 && nb > rb) ? (ns < kMaxTowerStreams ? ns : kMaxTowerStreams) : 1;
   ws->pb = h->piece > 0 ? h->piece : 8;
   if (ws->pb > nb) ws->pb = nb;
   if (ws->pb < rb) ws->pb = rb;
@@ -796,15 +803,17 @@ int alloc_ws(sn_handle* h, Workspace* ws, int nb, int rb) {
   HIP_TRY(h, dalloc(&ws->cost, (size_t)nb * h->Dl * hw));
   HIP_TRY(h, dalloc(&ws->disp_low, (size_t)nb * hw));
   if (h->precision == SN_PREC_FP32) {
-    for (int k = 0; k < 2; ++k) HIP_TRY(h, dalloc(&ws->ref[k], (size_t)rb * kC * HWp));
+    for (int k = 0; k < 2 * ws->ns; ++k) HIP_TRY(h, dalloc(&ws->ref[k], (size_t)rb * kC * HWp));
   } else {
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < 2 * ws->ns; ++k) {
       const size_t slots = (ref16_slots(h->rg, rb) + kRefSlack) * (h->precision == SN_PREC_F16X3 ? 2 : 1);
       HIP_TRY(h, dalloc(&ws->ref16[k], slots));
       HIP_TRY(h, hipMemset(ws->ref16[k], 0, slots * sizeof(uint4)));   // the zero border is never written again
     }
     // fine-grained: the queue words must be coherent across the 8 XCD L2s at device scope and with the memset
-    ws->n_chunks = (nb + rb - 1) / rb;
+    // one counter block per tower chunk: chunks never straddle a low-resolution piece, so a piece of pb pairs
+    // holds ceil(pb / rb) of them (the last one short when pb % rb != 0) — see chunk_ordinal()
+    ws->n_chunks = ((nb + pb - 1) / pb) * ((pb + rb - 1) / rb);
     HIP_TRY(h, hipExtMallocWithFlags(reinterpret_cast<void**>(&ws->tile_ctr), kTileCtrBytes * ws->n_chunks, hipDeviceMallocFinegrained));
   }
   HIP_TRY(h, dalloc(&ws->out_disp, (size_t)nb * HW));
@@ -838,11 +847,11 @@ void free_ws(Workspace* ws) {
 // 16-byte copies.  Only the tensors other kernels read stay fp32 NCHW: the feature map (cost-volume loader, parity
 // hook) and the last aggregation volume (soft-argmin head).
 int lowres_slots(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, const int8_t* in6, bool want_cost,
-                 bool prof, int ncu_part) {
+                 bool prof) {
   const int Hp = h->Hp, Wp = h->Wp, hl = h->hl, wl = h->wl, Dl = h->Dl;
   const size_t HW = (size_t)h->H * h->W;
   const int8_t* in = in6 + (size_t)p0 * 6 * HW;
-  const int ncu = ncu_part > 0 ? ncu_part : h->num_cu, ni = 2 * m;   // CUs of the stream's partition
+  const int ncu = h->num_cu, ni = 2 * m;
   auto U4 = [](float* p) { return reinterpret_cast<const uint4*>(p); };
   HIP_TRY(h, (launch_down0_f16<32, true>(st, h->down0, h->down[0].bias, in, h->H, h->W, ni, Hp / 2, Wp / 2, ws.down[0], ncu)));
   {
@@ -891,12 +900,11 @@ int lowres_slots(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, con
   return SN_OK;
 }
 
-int lowres(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, const int8_t* in6, bool want_cost, bool prof,
-           int ncu_part = 0) {
+int lowres(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, const int8_t* in6, bool want_cost, bool prof) {
   const int Hp = h->Hp, Wp = h->Wp, hl = h->hl, wl = h->wl, Dl = h->Dl;
   const size_t HW = (size_t)h->H * h->W;
   const int8_t* in = in6 + (size_t)p0 * 6 * HW;
-  if (h->low_slots) return lowres_slots(h, ws, st, p0, m, in6, want_cost, prof, ncu_part);
+  if (h->low_slots) return lowres_slots(h, ws, st, p0, m, in6, want_cost, prof);
   // --- Siamese feature tower: images = 2m (left, right interleaved), shared weights ---
   {
     LoadI8Eye ld{in, h->H, h->W};
@@ -946,123 +954,151 @@ int lowres(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, const int
   return SN_OK;
 }
 
-// Refinement of pairs [p0, p0+m), `rb` pairs per tower launch.
-int refine(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, const int8_t* in6, float* out_disp,
-           int32_t* out_raw, bool prof, bool overlapped = false, int ncu_part = 0) {
-  const int ncu = ncu_part > 0 ? ncu_part : h->num_cu;      // CUs of the stream's partition
+// Ordinal of the tower chunk that starts at pair q0 of the piece that starts at pair p0 (pieces start at multiples of
+// ws.pb, chunks at p0 + k * ws.rb): indexes the per-chunk tile-queue counters, which are zeroed once per forward() and
+// never reset by the kernel, so two chunks of one forward must never share an ordinal.
+inline int chunk_ordinal(const Workspace& ws, int p0, int q0) {
+  return (p0 / ws.pb) * ((ws.pb + ws.rb - 1) / ws.rb) + (q0 - p0) / ws.rb;
+}
+
+// Refinement of ONE tower chunk: pairs [q0, q0+c), c <= ws.rb, on stream `st` with the activation pair of tower
+// stream `sidx`; `ordinal` selects the chunk's tile-queue counters.
+int refine_chunk(sn_handle* h, Workspace& ws, hipStream_t st, int sidx, int ordinal, int q0, int c, const int8_t* in6,
+                 float* out_disp, int32_t* out_raw, bool pe) {
+  const int ncu = h->num_cu;
   const int Hp = h->Hp, Wp = h->Wp, hl = h->hl, wl = h->wl;
   const size_t HW = (size_t)h->H * h->W;
   const float inv_q = (float)(1.0 / ((double)h->D * (double)kOutScale));
-  for (int q0 = p0; q0 < p0 + m; q0 += ws.rb) {
-    const int c = (p0 + m - q0) < ws.rb ? (p0 + m - q0) : ws.rb;
-    const bool pe = prof && q0 == 0;
-    LoadRefineIn ld{ws.disp_low + (size_t)q0 * hl * wl, in6 + (size_t)q0 * 6 * HW, hl, wl, h->H, h->W, Hp, Wp,
-                    1.0f / (float)h->D};
-    float* od = out_disp ? out_disp + (size_t)q0 * HW : nullptr;
-    int32_t* orw = out_raw ? out_raw + (size_t)q0 * HW : nullptr;
-    const float* dl = ws.disp_low + (size_t)q0 * hl * wl;
-    dim3 grid((h->W + 63) / 64, (h->H + 3) / 4, c);
-    if (h->precision == SN_PREC_FP32) {
-      float* rx = ws.ref[0];
-      float* rt = ws.ref[1];
-      if (Hp * Wp <= 64 * 128)
-        HIP_TRY(h, (launch_conv<3, 1, 1, 4, 4, 32>(st, h->rin, ld, c, Hp, Wp, rx, nullptr, true)));
-      else
-        HIP_TRY(h, (launch_conv<3, 1, 1, 4, 8, 64>(st, h->rin, ld, c, Hp, Wp, rx, nullptr, true)));
-      if (pe) HIP_TRY(h, hipEventRecord(h->ev[4], st));
-      for (int i = 0; i < kNRefRes; ++i) {
-        HIP_TRY(h, conv3x3(st, h->rres[i][0], rx, c, Hp, Wp, kRefDil[i], rt, nullptr, true));
-        HIP_TRY(h, conv3x3(st, h->rres[i][1], rt, c, Hp, Wp, kRefDil[i], rx, rx, true));
-      }
-      if (pe) HIP_TRY(h, hipEventRecord(h->ev[5], st));
-      hipLaunchKernelGGL(k_head_final, grid, dim3(256), 0, st, rx, h->rout.w, h->rout.bias, dl, hl, wl, Hp, Wp, h->H,
-                         h->W, (float)h->D, inv_q, od, orw);
-    } else {
-      // fp16 tower: ref.in (K=36, fp32 MFMA) writes the NCHW8c fp16 tensor, the 12 C->C convs run on
-      // v_mfma_f32_32x32x16_f16, the head reads fp16 and finishes in fp32
-      uint4* rx = ws.ref16[0];
-      uint4* rt = ws.ref16[1];
-      const RefGeom& g = h->rg;
-      const bool x3 = h->precision == SN_PREC_F16X3;
-      const size_t lo_slots = ref16_slots(g, ws.rb) + kRefSlack;       // hi tensor -> lo tensor (F16X3)
-      if (h->refin.wfrag) {
-        HIP_TRY(h, launch_refin_f16(st, h->refin, h->rin.bias, ws.disp_low + (size_t)q0 * hl * wl, in6 + (size_t)q0 * 6 * HW,
-                                    hl, wl, h->H, h->W, 1.0f / (float)h->D, g, c, rx, x3, lo_slots * 16, ncu));
-      } else if (x3) {
-        if (Hp * Wp <= 64 * 128)
-          HIP_TRY(h, (launch_conv<3, 1, 1, 4, 4, 32, LoadRefineIn, 2>(st, h->rin, ld, c, Hp, Wp, reinterpret_cast<float*>(rx),
-                                                                    nullptr, true, g.Hs, g.Ws, lo_slots * 16)));
-        else
-          HIP_TRY(h, (launch_conv<3, 1, 1, 4, 8, 64, LoadRefineIn, 2>(st, h->rin, ld, c, Hp, Wp, reinterpret_cast<float*>(rx),
-                                                                    nullptr, true, g.Hs, g.Ws, lo_slots * 16)));
-      } else if (Hp * Wp <= 64 * 128)
-        HIP_TRY(h, (launch_conv<3, 1, 1, 4, 4, 32, LoadRefineIn, 1>(st, h->rin, ld, c, Hp, Wp, reinterpret_cast<float*>(rx),
-                                                                  nullptr, true, g.Hs, g.Ws)));
-      else
-        HIP_TRY(h, (launch_conv<3, 1, 1, 4, 8, 64, LoadRefineIn, 1>(st, h->rin, ld, c, Hp, Wp, reinterpret_cast<float*>(rx),
-                                                                  nullptr, true, g.Hs, g.Ws)));
-      if (pe) HIP_TRY(h, hipEventRecord(h->ev[4], st));
-      const bool dyn = !x3 && h->ref_dyn && ws.tile_ctr != nullptr;
-      unsigned* const chunk_ctr = dyn ? ws.tile_ctr + (size_t)(q0 / ws.rb) * (kTileCtrBytes / sizeof(unsigned)) : nullptr;
-      for (int i = 0; i < kNRefRes; ++i) {
-        if (x3) {
-          HIP_TRY(h, ref_conv_f16x3(st, h->rres16[i][0], g, ncu, kRefDil[i], rx, rt, nullptr, lo_slots, c, true));
-          HIP_TRY(h, ref_conv_f16x3(st, h->rres16[i][1], g, ncu, kRefDil[i], rt, rx, rx, lo_slots, c, true));
-        } else {
-          HIP_TRY(h, ref_block_f16(st, h->rres16[i][0], h->rres16[i][1], g, ncu, kRefDil[i], &rx, &rt, c,
-                                   overlapped ? h->ovl_cap : 0, dyn ? chunk_ctr + 2 * i * kTileCtrStride : nullptr));
-        }
-      }
-      if (pe) HIP_TRY(h, hipEventRecord(h->ev[5], st));
-      if (x3)
-        hipLaunchKernelGGL(k_head_final_f16<true>, grid, dim3(256), 0, st, rx, lo_slots, g, h->rout.w, h->rout.bias, dl,
-                           hl, wl, h->H, h->W, (float)h->D, inv_q, od, orw);
-      else
-        hipLaunchKernelGGL(k_head_final_f16<false>, grid, dim3(256), 0, st, rx, (size_t)0, g, h->rout.w, h->rout.bias,
-                           dl, hl, wl, h->H, h->W, (float)h->D, inv_q, od, orw);
+  LoadRefineIn ld{ws.disp_low + (size_t)q0 * hl * wl, in6 + (size_t)q0 * 6 * HW, hl, wl, h->H, h->W, Hp, Wp,
+                  1.0f / (float)h->D};
+  float* od = out_disp ? out_disp + (size_t)q0 * HW : nullptr;
+  int32_t* orw = out_raw ? out_raw + (size_t)q0 * HW : nullptr;
+  const float* dl = ws.disp_low + (size_t)q0 * hl * wl;
+  dim3 grid((h->W + 63) / 64, (h->H + 3) / 4, c);
+  if (h->precision == SN_PREC_FP32) {
+    float* rx = ws.ref[2 * sidx];
+    float* rt = ws.ref[2 * sidx + 1];
+    if (Hp * Wp <= 64 * 128)
+      HIP_TRY(h, (launch_conv<3, 1, 1, 4, 4, 32>(st, h->rin, ld, c, Hp, Wp, rx, nullptr, true)));
+    else
+      HIP_TRY(h, (launch_conv<3, 1, 1, 4, 8, 64>(st, h->rin, ld, c, Hp, Wp, rx, nullptr, true)));
+    if (pe) HIP_TRY(h, hipEventRecord(h->ev[4], st));
+    for (int i = 0; i < kNRefRes; ++i) {
+      HIP_TRY(h, conv3x3(st, h->rres[i][0], rx, c, Hp, Wp, kRefDil[i], rt, nullptr, true));
+      HIP_TRY(h, conv3x3(st, h->rres[i][1], rt, c, Hp, Wp, kRefDil[i], rx, rx, true));
     }
-    HIP_TRY(h, hipGetLastError());
+    if (pe) HIP_TRY(h, hipEventRecord(h->ev[5], st));
+    hipLaunchKernelGGL(k_head_final, grid, dim3(256), 0, st, rx, h->rout.w, h->rout.bias, dl, hl, wl, Hp, Wp, h->H,
+                       h->W, (float)h->D, inv_q, od, orw);
+  } else {
+    // fp16 tower: ref.in writes the NCHW8c fp16 tensor, the 12 C->C convs run on v_mfma_f32_32x32x16_f16, the head
+    // reads fp16 and finishes in fp32
+    uint4* rx = ws.ref16[2 * sidx];
+    uint4* rt = ws.ref16[2 * sidx + 1];
+    const RefGeom& g = h->rg;
+    const bool x3 = h->precision == SN_PREC_F16X3;
+    const size_t lo_slots = ref16_slots(g, ws.rb) + kRefSlack;       // hi tensor -> lo tensor (F16X3)
+    if (h->refin.wfrag) {
+      HIP_TRY(h, launch_refin_f16(st, h->refin, h->rin.bias, ws.disp_low + (size_t)q0 * hl * wl, in6 + (size_t)q0 * 6 * HW,
+                                  hl, wl, h->H, h->W, 1.0f / (float)h->D, g, c, rx, x3, lo_slots * 16, ncu));
+    } else if (x3) {
+      if (Hp * Wp <= 64 * 128)
+        HIP_TRY(h, (launch_conv<3, 1, 1, 4, 4, 32, LoadRefineIn, 2>(st, h->rin, ld, c, Hp, Wp, reinterpret_cast<float*>(rx),
+                                                                  nullptr, true, g.Hs, g.Ws, lo_slots * 16)));
+      else
+        HIP_TRY(h, (launch_conv<3, 1, 1, 4, 8, 64, LoadRefineIn, 2>(st, h->rin, ld, c, Hp, Wp, reinterpret_cast<float*>(rx),
+                                                                  nullptr, true, g.Hs, g.Ws, lo_slots * 16)));
+    } else if (Hp * Wp <= 64 * 128)
+      HIP_TRY(h, (launch_conv<3, 1, 1, 4, 4, 32, LoadRefineIn, 1>(st, h->rin, ld, c, Hp, Wp, reinterpret_cast<float*>(rx),
+                                                                nullptr, true, g.Hs, g.Ws)));
+    else
+      HIP_TRY(h, (launch_conv<3, 1, 1, 4, 8, 64, LoadRefineIn, 1>(st, h->rin, ld, c, Hp, Wp, reinterpret_cast<float*>(rx),
+                                                                nullptr, true, g.Hs, g.Ws)));
+    if (pe) HIP_TRY(h, hipEventRecord(h->ev[4], st));
+    const bool dyn = !x3 && h->ref_dyn && ws.tile_ctr != nullptr;
+    unsigned* const chunk_ctr = dyn ? ws.tile_ctr + (size_t)ordinal * (kTileCtrBytes / sizeof(unsigned)) : nullptr;
+    for (int i = 0; i < kNRefRes; ++i) {
+      if (x3) {
+        HIP_TRY(h, ref_conv_f16x3(st, h->rres16[i][0], g, ncu, kRefDil[i], rx, rt, nullptr, lo_slots, c, true));
+        HIP_TRY(h, ref_conv_f16x3(st, h->rres16[i][1], g, ncu, kRefDil[i], rt, rx, rx, lo_slots, c, true));
+      } else {
+        HIP_TRY(h, ref_block_f16(st, h->rres16[i][0], h->rres16[i][1], g, ncu, kRefDil[i], &rx, &rt, c, h->ovl_cap,
+                                 dyn ? chunk_ctr + 2 * i * kTileCtrStride : nullptr));
+      }
+    }
+    if (pe) HIP_TRY(h, hipEventRecord(h->ev[5], st));
+    if (x3)
+      hipLaunchKernelGGL(k_head_final_f16<true>, grid, dim3(256), 0, st, rx, lo_slots, g, h->rout.w, h->rout.bias, dl,
+                         hl, wl, h->H, h->W, (float)h->D, inv_q, od, orw);
+    else
+      hipLaunchKernelGGL(k_head_final_f16<false>, grid, dim3(256), 0, st, rx, (size_t)0, g, h->rout.w, h->rout.bias,
+                         dl, hl, wl, h->H, h->W, (float)h->D, inv_q, od, orw);
   }
+  HIP_TRY(h, hipGetLastError());
   return SN_OK;
 }
 
 // in6: device int8 [n][6][H][W]; out_disp / out_raw: device, nullable.
-// The batch is cut into pieces of ws.pb pairs.  The low-resolution branch is fp32-MFMA bound and touches
-// little HBM, the refinement tower is HBM bound and keeps the matrix pipe ~25 % busy, so the two run on
-// separate HIP streams: low-res(piece k+1) overlaps refine(piece k).  Both streams fork from / join back
-// into the caller's stream with events, so the call keeps plain stream semantics for the caller.
+// The batch is cut into pieces of ws.pb pairs and every piece into tower chunks of ws.rb pairs.  More than one chunk:
+// three streams forked from / joined back into the caller's stream with events (plain stream semantics for the caller):
+//   s_low      the low-resolution branch of piece k+1 (matrix-pipe bound, little HBM traffic) runs under
+//   s_tow[0/1] the refinement towers of piece k (HBM bound); consecutive chunks ALTERNATE between the two tower
+//              streams.  A tower launch costs bytes / 7.5 TB/s plus ~14 us that do not depend on its size (kernel
+//              boundary, weight / first-tile prologue, and a tail in which the last tiles of the persistent grid
+//              finish one by one); with two independent chunks in flight the workgroups of chunk B's launch take over
+//              the CUs that chunk A's launch drains, and A's next launch (which depends only on A) is ready by the
+//              time B drains.  Two one-pair chunks in flight = four 61 MB tensors = the footprint of one two-pair
+//              chunk, still inside the 256 MB Infinity Cache.
 int forward(sn_handle* h, Workspace& ws, hipStream_t st, int n, const int8_t* in6, float* out_disp,
             int32_t* out_raw, bool want_cost) {
   const bool prof = h->profiling && (&ws == &h->ws);
-  const bool overlap = !prof && (&ws == &h->ws) && h->overlap && n > ws.pb;
+  const bool multi = !prof && (&ws == &h->ws) && h->overlap && n > ws.rb;
   int rc;
   if (ws.tile_ctr && h->ref_dyn) HIP_TRY(h, hipMemsetAsync(ws.tile_ctr, 0, kTileCtrBytes * ws.n_chunks, st));
-  if (!overlap) {
+  if (!multi) {
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[0], st));
     for (int p0 = 0; p0 < n; p0 += ws.pb) {
       const int m = (n - p0) < ws.pb ? (n - p0) : ws.pb;
       if ((rc = lowres(h, ws, st, p0, m, in6, want_cost, prof && p0 == 0))) return rc;
       if (prof && p0 == 0) HIP_TRY(h, hipEventRecord(h->ev[2], st));
-      if ((rc = refine(h, ws, st, p0, m, in6, out_disp, out_raw, prof))) return rc;
+      for (int q0 = p0; q0 < p0 + m; q0 += ws.rb) {
+        const int c = (p0 + m - q0) < ws.rb ? (p0 + m - q0) : ws.rb;
+        if ((rc = refine_chunk(h, ws, st, 0, chunk_ordinal(ws, p0, q0), q0, c, in6, out_disp, out_raw, prof && q0 == 0)))
+          return rc;
+      }
     }
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[3], st));
     return SN_OK;
   }
+  const int ns = ws.ns;
   HIP_TRY(h, hipEventRecord(h->ev_fork, st));
   HIP_TRY(h, hipStreamWaitEvent(h->s_low, h->ev_fork, 0));
-  HIP_TRY(h, hipStreamWaitEvent(h->s_ref, h->ev_fork, 0));
-  int k = 0;
+  for (int s = 0; s < ns; ++s) HIP_TRY(h, hipStreamWaitEvent(h->s_tow[s], h->ev_fork, 0));
+  int k = 0, chunk = 0;
   for (int p0 = 0; p0 < n; p0 += ws.pb, ++k) {
     const int m = (n - p0) < ws.pb ? (n - p0) : ws.pb;
     // the piece-local low-res buffers are reused by the next piece: only disp_low crosses streams
-    if ((rc = lowres(h, ws, h->s_low, p0, m, in6, want_cost, false, h->cu_low))) return rc;
+    if ((rc = lowres(h, ws, h->s_low, p0, m, in6, want_cost, false))) return rc;
     hipEvent_t e = h->ev_piece[k % kMaxPieceEvents];
     HIP_TRY(h, hipEventRecord(e, h->s_low));
-    HIP_TRY(h, hipStreamWaitEvent(h->s_ref, e, 0));
-    if ((rc = refine(h, ws, h->s_ref, p0, m, in6, out_disp, out_raw, false, true, h->cu_ref))) return rc;
+    bool waited[kMaxTowerStreams] = {};
+    for (int q0 = p0; q0 < p0 + m; q0 += ws.rb, ++chunk) {
+      const int c = (p0 + m - q0) < ws.rb ? (p0 + m - q0) : ws.rb;
+      const int s = chunk % ns;
+      if (!waited[s]) {
+        HIP_TRY(h, hipStreamWaitEvent(h->s_tow[s], e, 0));
+        waited[s] = true;
+      }
+      if ((rc = refine_chunk(h, ws, h->s_tow[s], s, chunk_ordinal(ws, p0, q0), q0, c, in6, out_disp, out_raw, false)))
+        return rc;
+    }
   }
-  HIP_TRY(h, hipEventRecord(h->ev_join, h->s_ref));
+  HIP_TRY(h, hipEventRecord(h->ev_join, h->s_low));
   HIP_TRY(h, hipStreamWaitEvent(st, h->ev_join, 0));
+  for (int s = 0; s < ns; ++s) {
+    HIP_TRY(h, hipEventRecord(h->ev_tow_join[s], h->s_tow[s]));
+    HIP_TRY(h, hipStreamWaitEvent(st, h->ev_tow_join[s], 0));
+  }
   return SN_OK;
 }
 
@@ -1172,6 +1208,7 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
   const int H = c.height > 0 ? c.height : (int)hd.height;
   const int D = c.dmax > 0 ? c.dmax : (int)hd.dmax;
   if (W <= 0 || H <= 0 || D < 16 || D % 16 || D > 256) return SN_ERR_ARG;   // NV12 entry points add w%4, h%2
+  if (c.precision == SN_PREC_DEFAULT) c.precision = SN_PREC_F16;
   if (c.precision != SN_PREC_FP32 && c.precision != SN_PREC_F16 && c.precision != SN_PREC_F16X3) return SN_ERR_ARG;
 
   int ndev = 0;
@@ -1201,7 +1238,8 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
   h->max_batch = c.max_batch > 0 ? c.max_batch : 1;
   h->precision = c.precision;
   h->task_num = c.task_num > 0 ? c.task_num : 4;
-  h->refine_chunk = c.refine_chunk > 0 ? c.refine_chunk : 2;   // 2 pairs per tower launch measured best
+  h->refine_chunk = c.refine_chunk > 0 ? c.refine_chunk : 1;   // one pair per tower launch, two chunks in flight
+                                                               // (forward()); SN_TOWER_STREAMS=1 wants 2 here
   h->piece = c.piece > 0 ? c.piece : 8;
   h->rg = make_ref_geom(h->Hp, h->Wp);
   h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -1227,36 +1265,22 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(SN_ERR_DEVICE);
   for (auto& e : h->ev)
     if (hipEventCreate(&e) != hipSuccess) return fail(SN_ERR_DEVICE);
-  // The two pipeline streams get DISJOINT CU sets (CU-mask bit i is CU i/8 of XCD i%8, so any run of 8k bits takes k
-  // CUs from every XCD and workgroup b still lands on XCD b%8): the weights-stationary low-resolution kernels need
-  // 112 KB of LDS and a whole register file, the tower wants every CU it runs on for itself, so sharing CUs made
-  // both wait for each other.  The tower is HBM-bound and loses little on fewer CUs.  SN_CU_LOW = CUs of the
-  // low-resolution stream (multiple of 8; 0 = no partition).
-  {
-    int low = 0;      // default off: measured 1940 pairs/s shared vs 1700 / 1680 / 1510 with 64 / 96 / 128 CUs split off
-    if (const char* e = getenv("SN_CU_LOW")) low = atoi(e);
-    low = low / 8 * 8;
-    if (low > 0 && low < h->num_cu - 8 && h->num_cu % 8 == 0 && h->num_cu <= 256 && h->precision != SN_PREC_FP32) {
-      uint32_t mlow[8] = {0}, mref[8] = {0};
-      for (int i = 0; i < h->num_cu; ++i) (i < low ? mlow : mref)[i / 32] |= 1u << (i % 32);
-      const uint32_t words = (uint32_t)((h->num_cu + 31) / 32);
-      if (hipExtStreamCreateWithCUMask(&h->s_low, words, mlow) == hipSuccess &&
-          hipExtStreamCreateWithCUMask(&h->s_ref, words, mref) == hipSuccess) {
-        h->cu_low = low;
-        h->cu_ref = h->num_cu - low;
-      } else {
-        if (h->s_low) hipStreamDestroy(h->s_low);
-        if (h->s_ref) hipStreamDestroy(h->s_ref);
-        h->s_low = h->s_ref = nullptr;
-        hipGetLastError();
-      }
-    }
-  }
-  if ((h->s_low == nullptr && hipStreamCreateWithFlags(&h->s_low, hipStreamNonBlocking) != hipSuccess) ||
-      (h->s_ref == nullptr && hipStreamCreateWithFlags(&h->s_ref, hipStreamNonBlocking) != hipSuccess) ||
+  // (Disjoint CU sets for the pipeline streams through hipExtStreamCreateWithCUMask were measured and dropped:
+  // 1940 pairs/s shared vs 1700 / 1680 / 1510 with 64 / 96 / 128 CUs split off for the low-resolution branch.)
+  if (hipStreamCreateWithFlags(&h->s_low, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess)
     return fail(SN_ERR_DEVICE);
+  {
+    const char* e = getenv("SN_TOWER_STREAMS");        // 1 = every tower chunk on one stream (A/B switch)
+    h->tower_streams = e ? atoi(e) : kMaxTowerStreams;
+    if (h->tower_streams < 1) h->tower_streams = 1;
+    if (h->tower_streams > kMaxTowerStreams) h->tower_streams = kMaxTowerStreams;
+  }
+  for (int i = 0; i < kMaxTowerStreams; ++i)
+    if (hipStreamCreateWithFlags(&h->s_tow[i], hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_tow_join[i], hipEventDisableTiming) != hipSuccess)
+      return fail(SN_ERR_DEVICE);
   for (auto& e : h->ev_piece)
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(SN_ERR_DEVICE);
   h->overlap = getenv("SN_NO_OVERLAP") == nullptr;
@@ -1266,7 +1290,6 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
   {
     const char* e = getenv("SN_REF_DYN");     // dynamic tile queue of the fp16 tower (default on)
     h->ref_dyn = e ? atoi(e) != 0 : true;
-    if (h->cu_low > 0) h->ovl_cap = 0;     // exclusive CUs: the tower keeps its full occupancy
     if (const char* c = getenv("SN_OVL_CAP")) h->ovl_cap = atoi(c);
   }
 
@@ -1322,7 +1345,7 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
   if ((rc = upload_head(h, bw.next(1, kC, 9), &h->rout))) return fail(rc);
   if (bw.off != blob.size()) return fail(SN_ERR_FORMAT);
 
-  if ((rc = alloc_ws(h, &h->ws, h->max_batch, h->refine_chunk))) return fail(rc == SN_ERR_DEVICE ? SN_ERR_NOMEM : rc);
+  if ((rc = alloc_ws(h, &h->ws, h->max_batch, h->refine_chunk, h->tower_streams))) return fail(rc == SN_ERR_DEVICE ? SN_ERR_NOMEM : rc);
   *out = h;
   return SN_OK;
 }
@@ -1359,8 +1382,9 @@ int sn_destroy(sn_handle* h) {
     if (s.pin_in) hipHostFree(s.pin_in);
     if (s.pin_raw) hipHostFree(s.pin_raw);
     if (s.pin_disp) hipHostFree(s.pin_disp);
-    for (auto& g : s.gexec)
-      if (g) hipGraphExecDestroy(g);
+    for (auto& gk : s.gexec)
+      for (auto& g : gk)
+        if (g) hipGraphExecDestroy(g);
     if (s.ev0) hipEventDestroy(s.ev0);
     if (s.ev1) hipEventDestroy(s.ev1);
     if (s.stream) hipStreamDestroy(s.stream);
@@ -1372,7 +1396,10 @@ int sn_destroy(sn_handle* h) {
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
   if (h->ev_join) hipEventDestroy(h->ev_join);
   if (h->s_low) hipStreamDestroy(h->s_low);
-  if (h->s_ref) hipStreamDestroy(h->s_ref);
+  for (auto& st : h->s_tow)
+    if (st) hipStreamDestroy(st);
+  for (auto& e : h->ev_tow_join)
+    if (e) hipEventDestroy(e);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
   return SN_OK;
@@ -1399,6 +1426,9 @@ int sn_get_io_info(const sn_handle* h, sn_io_info* info) {
   mac += kNAgg * dl * hl * wl * kC * kC * 27 + dl * hl * wl * kC * 27;
   mac += wp * hp * (4.0 * kC * 9 + 2.0 * kNRefRes * kC * kC * 9 + kC * 9);
   info->flops_per_pair = 2.0 * mac;
+  info->refine_chunk = h->ws.rb;
+  info->piece = h->ws.pb;
+  info->tower_streams = h->ws.ns;
   return SN_OK;
 }
 
@@ -1518,6 +1548,41 @@ int sn_infer_sbs_nv12(sn_handle* h, const uint8_t* sbs, int w2, int h_px, int32_
   return SN_OK;
 }
 
+// FeedImg's split + CvtNV12Data2Tensors for a batch of side-by-side frames (device or host buffers): n frames of
+// 3*H*W bytes -> n int8 model tensors of 6*H*W bytes.  The streaming ingest of bench.py --stream: the host ships the
+// 2.76 MB camera frame instead of the 5.53 MB tensor.
+int sn_preprocess_sbs_nv12_batch(sn_handle* h, int n, const uint8_t* sbs, int w2, int h_px, int8_t* out6, int mem,
+                                 void* stream) {
+  if (!h) return SN_ERR_ARG;
+  if (!sbs || !out6 || n <= 0 || !pre_args_ok(h, w2 / 2, h_px) || (w2 & 7) || (h_px & 1) ||
+      (mem != SN_MEM_HOST && mem != SN_MEM_DEVICE) || (mem == SN_MEM_HOST && n > h->max_batch)) {
+    set_err(h, "sn_preprocess_sbs_nv12_batch: bad arguments");
+    return SN_ERR_ARG;
+  }
+  if (mem == SN_MEM_DEVICE && (((uintptr_t)sbs | (uintptr_t)out6) & 3)) return SN_ERR_ARG;
+  int rc = check_device(h);
+  if (rc) return rc;
+  hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+  const int w = w2 / 2;
+  const size_t HW = (size_t)h->H * h->W;
+  const long total = 6L * h_px * (w >> 2);
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  for (int i = 0; i < n; ++i) {
+    const uint8_t* src = sbs + (size_t)i * 3 * HW;
+    int8_t* dst = out6 + (size_t)i * 6 * HW;
+    if (mem == SN_MEM_HOST) {           // one frame at a time through the NV12 staging buffer
+      HIP_TRY(h, hipMemcpyAsync(h->ws.nv12, src, 3 * HW, hipMemcpyHostToDevice, st));
+      src = h->ws.nv12;
+      dst = h->ws.in6 + (size_t)i * 6 * HW;
+    }
+    hipLaunchKernelGGL(k_pre_nv12, dim3(blocks), dim3(256), 0, st, src, src + w, w2, w, h_px, dst);
+  }
+  HIP_TRY(h, hipGetLastError());
+  if (mem == SN_MEM_HOST) HIP_TRY(h, hipMemcpyAsync(out6, h->ws.in6, (size_t)n * 6 * HW, hipMemcpyDeviceToHost, st));
+  if (mem == SN_MEM_HOST || !stream) HIP_TRY(h, hipStreamSynchronize(st));
+  return SN_OK;
+}
+
 // ---- async task slots (DnnNode::Run with is_sync_mode = false) ---------------------------------------
 static int ensure_slots(sn_handle* h) {
   if (!h->slots.empty()) return SN_OK;
@@ -1527,7 +1592,7 @@ static int ensure_slots(sn_handle* h) {
     HIP_TRY(h, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
     HIP_TRY(h, hipEventCreate(&s.ev0));
     HIP_TRY(h, hipEventCreate(&s.ev1));
-    int rc = alloc_ws(h, &s.ws, 1, 1);
+    int rc = alloc_ws(h, &s.ws, 1, 1, 1);
     if (rc) return rc;
     HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&s.pin_in), 6 * HW, hipHostMallocDefault));
     HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&s.pin_raw), 4 * HW, hipHostMallocDefault));
@@ -1536,8 +1601,10 @@ static int ensure_slots(sn_handle* h) {
   return SN_OK;
 }
 
-int sn_submit(sn_handle* h, const int8_t* in, int32_t* out_i32, float* out_disp, int timeout_ms,
-              uint64_t* ticket) {
+// kind 0: `in` is the int8 model tensor (6*H*W bytes); kind 1: the raw 2W x H side-by-side NV12 frame of FeedImg
+// (3*H*W bytes: half the H2D traffic; split + chroma replication + ^0x80 run on the GPU in k_pre_nv12)
+static int submit_common(sn_handle* h, const void* in, int kind, int32_t* out_i32, float* out_disp, int timeout_ms,
+                         uint64_t* ticket) {
   if (!h || !in || (!out_i32 && !out_disp) || !ticket) return SN_ERR_ARG;
   std::unique_lock<std::mutex> lk(h->mu);
   int rc = check_device(h);
@@ -1561,11 +1628,31 @@ int sn_submit(sn_handle* h, const int8_t* in, int32_t* out_i32, float* out_disp,
   s->ticket = h->next_ticket++;
   s->user_raw = out_i32;
   s->user_disp = out_disp;
-  *ticket = s->ticket;
-  memcpy(s->pin_in, in, 6 * HW);   // the caller may release its tensor as soon as we return
+  // Every error exit below must hand the slot back (a slot left busy would make a later submit with
+  // timeout -1 — what the node passes — block forever); *ticket is written on success only.
+  struct SlotGuard {
+    sn_handle* h;
+    Slot* s;
+    bool armed = true;
+    ~SlotGuard() {
+      if (!armed) return;
+      s->ticket = 0;            // h->mu is still held by the caller's unique_lock
+      h->cv.notify_one();
+    }
+  } guard{h, s};
+  memcpy(s->pin_in, in, (kind == 1 ? 3 : 6) * HW);   // the caller may release its buffer as soon as we return
   const int mask = (out_i32 ? 1 : 0) | (out_disp ? 2 : 0);
   auto enqueue = [&]() -> int {
-    HIP_TRY(h, hipMemcpyAsync(s->ws.in6, s->pin_in, 6 * HW, hipMemcpyHostToDevice, s->stream));
+    if (kind == 1) {
+      HIP_TRY(h, hipMemcpyAsync(s->ws.nv12, s->pin_in, 3 * HW, hipMemcpyHostToDevice, s->stream));
+      const long total = 6L * h->H * (h->W >> 2);
+      const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+      hipLaunchKernelGGL(k_pre_nv12, dim3(blocks), dim3(256), 0, s->stream, s->ws.nv12, s->ws.nv12 + h->W, 2 * h->W, h->W,
+                         h->H, s->ws.in6);
+      HIP_TRY(h, hipGetLastError());
+    } else {
+      HIP_TRY(h, hipMemcpyAsync(s->ws.in6, s->pin_in, 6 * HW, hipMemcpyHostToDevice, s->stream));
+    }
     const bool prof = h->profiling;
     h->profiling = false;   // stage events belong to the synchronous path
     const int r = forward(h, s->ws, s->stream, 1, s->ws.in6, out_disp ? s->ws.out_disp : nullptr,
@@ -1576,35 +1663,50 @@ int sn_submit(sn_handle* h, const int8_t* in, int32_t* out_i32, float* out_disp,
     if (out_disp) HIP_TRY(h, hipMemcpyAsync(s->pin_disp, s->ws.out_disp, 4 * HW, hipMemcpyDeviceToHost, s->stream));
     return SN_OK;
   };
-  if (h->use_graphs && !s->gexec[mask] && s->uses[mask] >= 1) {
+  if (h->use_graphs && !s->gexec[kind][mask] && s->uses[kind][mask] >= 1) {
     // capture on the second use (the first, un-captured run has done every one-time initialisation)
     hipGraph_t graph = nullptr;
     if (hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
       const int r = enqueue();
       const hipError_t e = hipStreamEndCapture(s->stream, &graph);
       if (r == SN_OK && e == hipSuccess && graph &&
-          hipGraphInstantiate(&s->gexec[mask], graph, nullptr, nullptr, 0) != hipSuccess)
-        s->gexec[mask] = nullptr;
+          hipGraphInstantiate(&s->gexec[kind][mask], graph, nullptr, nullptr, 0) != hipSuccess)
+        s->gexec[kind][mask] = nullptr;
       if (graph) hipGraphDestroy(graph);
     }
-    if (!s->gexec[mask]) {
+    if (!s->gexec[kind][mask]) {
       (void)hipGetLastError();
       h->use_graphs = false;          // capture unsupported here: keep issuing plain launches (same kernels)
     }
   }
   HIP_TRY(h, hipEventRecord(s->ev0, s->stream));
-  if (s->gexec[mask]) {
-    HIP_TRY(h, hipGraphLaunch(s->gexec[mask], s->stream));
+  if (s->gexec[kind][mask]) {
+    HIP_TRY(h, hipGraphLaunch(s->gexec[kind][mask], s->stream));
   } else {
     rc = enqueue();
-    if (rc) {
-      s->ticket = 0;
-      return rc;
-    }
-    ++s->uses[mask];
+    if (rc) return rc;
+    ++s->uses[kind][mask];
   }
   HIP_TRY(h, hipEventRecord(s->ev1, s->stream));
+  guard.armed = false;
+  *ticket = s->ticket;
   return SN_OK;
+}
+
+int sn_submit(sn_handle* h, const int8_t* in, int32_t* out_i32, float* out_disp, int timeout_ms,
+              uint64_t* ticket) {
+  return submit_common(h, in, 0, out_i32, out_disp, timeout_ms, ticket);
+}
+
+int sn_submit_nv12(sn_handle* h, const uint8_t* sbs, int w2, int h_px, int32_t* out_i32, float* out_disp,
+                   int timeout_ms, uint64_t* ticket) {
+  if (!h) return SN_ERR_ARG;
+  // geometry check of FeedImg (stereonet_node.cpp:682-690): height == model h, width == 2 * model w
+  if (!pre_args_ok(h, w2 / 2, h_px) || (w2 & 7) || (h_px & 1)) {
+    set_err(h, "sn_submit_nv12: image size does not match the model input");
+    return SN_ERR_ARG;
+  }
+  return submit_common(h, sbs, 1, out_i32, out_disp, timeout_ms, ticket);
 }
 
 int sn_wait(sn_handle* h, uint64_t ticket, float* infer_ms) {

@@ -59,11 +59,13 @@ enum { SN_MEM_HOST = 0, SN_MEM_DEVICE = 1 };
 
 /* Arithmetic of the convolution contractions.  All variants accumulate in fp32. */
 enum {
-  SN_PREC_FP32 = 0,      /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere                  */
+  SN_PREC_DEFAULT = 0,   /* a zero-initialised or NULL sn_config selects SN_PREC_F16              */
   SN_PREC_F16X3 = 1,     /* refinement tower on fp16 MFMA with hi/lo operand split (3 MFMAs per   */
                          /* product, ~2^-22 relative): fp32-class accuracy at 3/16 of the fp32    */
                          /* MFMA cost; activations stored as two fp16 tensors                     */
-  SN_PREC_F16 = 2        /* refinement tower on plain fp16 MFMA operands                          */
+  SN_PREC_F16 = 2,       /* refinement tower on plain fp16 MFMA operands; low-resolution branch on */
+                         /* 22-bit split fp16 operands (the default, and what bench.py measures)  */
+  SN_PREC_FP32 = 3       /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere                  */
 };
 
 typedef struct sn_config {
@@ -72,9 +74,9 @@ typedef struct sn_config {
   int width;         /* 0 = take from the model file header                                      */
   int height;        /* 0 = take from the model file header                                      */
   int dmax;          /* max disparity D (multiple of 16, <= 256); 0 = from the model file        */
-  int precision;     /* SN_PREC_*                                                                 */
+  int precision;     /* SN_PREC_*; 0 = SN_PREC_F16                                                */
   int task_num;      /* async slots for sn_submit; <=0 -> 4 (stereonet_node.cpp:144)              */
-  int refine_chunk;  /* pairs per refinement-tower launch; <=0 -> 2                               */
+  int refine_chunk;  /* pairs per refinement-tower launch; <=0 -> 1 (two such chunks are in flight)  */
   int piece;         /* pairs per low-resolution piece of the two-stream pipeline; <=0 -> 8       */
 } sn_config;
 
@@ -86,6 +88,10 @@ typedef struct sn_io_info {
   size_t in_bytes;        /* per pair: 6*H*W  (int8)  */
   size_t out_bytes;       /* per pair: 4*H*W  (int32) */
   double flops_per_pair;  /* algorithmic conv FLOPs (2*MAC), DESIGN.md §5 */
+  int refine_chunk;       /* pairs per refinement-tower launch actually in use */
+  int piece;              /* pairs per low-resolution piece actually in use    */
+  int tower_streams;      /* tower chunks in flight (1 or 2)                   */
+  int reserved;
 } sn_io_info;
 
 /* DnnNode::Init + Model introspection ------------------------------------------------------- */
@@ -113,14 +119,45 @@ int sn_preprocess_nv12(sn_handle *h, const uint8_t *left_nv12, const uint8_t *ri
 int sn_infer_sbs_nv12(sn_handle *h, const uint8_t *sbs_nv12, int w2, int h_px, int32_t *out_i32,
                       float *out_disp, int8_t *out_tensor, int mem, void *stream);
 
+/* The same split + mapping for n side-by-side frames (n * 3*H*W bytes -> n * 6*H*W bytes), no inference: the batched
+ * ingest of a streaming host (bench.py --stream) that ships camera frames instead of model tensors. */
+int sn_preprocess_sbs_nv12_batch(sn_handle *h, int n, const uint8_t *sbs_nv12, int w2, int h_px, int8_t *out_nchw6,
+                                 int mem, void *stream);
+
 /* DnnNode::Run, asynchronous form (stereonet_node.cpp:812): host buffers only.  sn_submit copies
  * the input and returns at once with a ticket; up to task_num tickets are in flight;
  * timeout_ms < 0 waits for a free slot forever (the reference passes -1).  sn_wait blocks until the
  * ticket's pair is done, fills the host outputs given at submit, and reports the device time. */
 int sn_submit(sn_handle *h, const int8_t *in_nchw6_host, int32_t *out_i32_host, float *out_disp_host,
               int timeout_ms, uint64_t *ticket);
+/* The same with FeedImg's raw 2W x H side-by-side NV12 frame as the input (stereonet_node.cpp:705-738 + preprocess.cpp:
+ * 913-1059 run on the GPU): half the host-to-device bytes of sn_submit. */
+int sn_submit_nv12(sn_handle *h, const uint8_t *sbs_nv12_host, int w2, int h_px, int32_t *out_i32_host,
+                   float *out_disp_host, int timeout_ms, uint64_t *ticket);
 int sn_wait(sn_handle *h, uint64_t ticket, float *infer_ms);
 int sn_synchronize(sn_handle *h);
+
+/* Multi-GPU form: the independent pairs of one batch sharded over the GPUs of one node -------------------------
+ * The reference keeps task_num = 4 independent frames in flight behind one Run() call site
+ * (stereonet_node.cpp:144,812); this spreads such units of work over devices instead: contiguous shards (the first
+ * n % ndev shards get one extra pair), one host thread + one engine per GPU, weights replicated, NO data-path
+ * collective; the single exchange is the gather of the maps to the root.  cfg->device is ignored, cfg->max_batch is
+ * the largest TOTAL n; devices == NULL selects 0..ndev-1.
+ *   sn_mgpu_infer_batch         host buffers: every device copies its shard in and its maps out — the host is the root.
+ *   sn_mgpu_infer_batch_device  in_per_device[k] = shard k resident on device k; maps gathered in batch order into
+ *                               out_* on device 0 over xGMI (hipMemcpyPeerAsync from each peer over its own link, or —
+ *                               SN_MGPU_GATHER=rccl — one grouped RCCL ncclSend/ncclRecv exchange).
+ * Results are bit-identical to sn_infer_batch on one GPU (same kernels, no cross-pair reduction). */
+typedef struct sn_mgpu sn_mgpu;
+int sn_mgpu_shard(int n, int ndev, int k, int *first, int *count);         /* pure shard arithmetic */
+int sn_mgpu_create(const char *model_file, const sn_config *cfg, const int *devices, int ndev, sn_mgpu **out);
+int sn_mgpu_destroy(sn_mgpu *m);
+int sn_mgpu_get_info(const sn_mgpu *m, int *ndev, int *per_device_batch, int *gather_kind /* 1 peer copy, 2 RCCL */);
+int sn_mgpu_get_handle(sn_mgpu *m, int k, sn_handle **h);                  /* the engine of shard k (borrowed) */
+int sn_mgpu_infer_batch(sn_mgpu *m, int n, const int8_t *in_nchw6_host, int32_t *out_i32_host, float *out_disp_host);
+int sn_mgpu_infer_batch_device(sn_mgpu *m, int n, const int8_t *const *in_per_device, int32_t *out_i32_root,
+                               float *out_disp_root);
+const char *sn_mgpu_last_error(const sn_mgpu *m);
 
 /* Measurement hooks (bench.py): per-stage device time of the most recent sn_infer_batch, taken
  * with hipEvents on the stream the kernels ran on.  Stage ids: */

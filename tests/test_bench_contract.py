@@ -21,8 +21,42 @@ def test_bench_refuses_to_run_without_a_gpu():
     assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout)
     h = subprocess.run([sys.executable, BENCH, "--help"], capture_output=True, text=True, cwd=ROOT, timeout=300)
     assert h.returncode == 0
-    for flag in ("--gpus", "--steps", "--warmup", "--batch", "--precision", "--no-cpu-baseline"):
+    for flag in ("--gpus", "--steps", "--warmup", "--batch", "--precision", "--no-cpu-baseline", "--config", "--stream"):
         assert flag in h.stdout
+
+
+def test_gpus_n_without_n_gpus_exits_nonzero():
+    """`python bench.py --gpus 2` started WITHOUT a launcher must start 2 ranks itself or refuse: on a box with fewer
+    than 2 GPUs it exits non-zero with a clear message (it used to run 1 GPU silently and label it n_gpus 1)."""
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("2+ GPUs present")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                       cwd=ROOT, timeout=300, env=env)
+    assert r.returncode != 0
+    assert "--gpus 2" in r.stderr and "GPU(s) are visible" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]          # no metric line under a wrong label
+
+
+def test_self_launch_plumbing_two_ranks_gloo():
+    """The self-launch path end to end on CPU: plain `python bench.py --gpus 2` (no WORLD_SIZE) re-executes itself
+    under torch.distributed.run with 2 ranks on 127.0.0.1; the ranks rendezvous (gloo), gather their maps to rank 0
+    with the bench's AsyncGather and rank 0 checks every gathered map.  No inference, no metric line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--batch", "3", "--selftest-plumbing"], capture_output=True,
+                       text=True, cwd=ROOT, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    assert lines[0] == {"plumbing": "ok", "n_gpus": 2, "world_size_seen": 2, "self_launched": True}
+
+
+def test_launcher_world_size_mismatch_is_refused():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--steps", "1"], capture_output=True, text=True, cwd=ROOT,
+                       timeout=300, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
 
 
 @pytest.mark.gpu
@@ -34,8 +68,11 @@ def test_bench_json_line_contract():
     assert len(lines) == 1
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "verified", "end_to_end"):
         assert k in d, k
+    assert d["verified"] is True
+    e2e = d["end_to_end"]
+    assert e2e["unit"] == "pairs/s" and 0 < e2e["value"] < d["value"] * 1.05 and e2e["async_single_pair"]["value"] > 0
     assert d["unit"] == "pairs/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert "workload" in d["config"] and "model" not in d["config"]

@@ -99,6 +99,21 @@ def test_two_stream_piece_pipeline_is_bit_identical(model_factory, prec):
         assert (singles[i][0] == disp[i]).all() and (singles[i][1] == raw[i]).all(), i
 
 
+@pytest.mark.parametrize("rc,piece,n", [(3, 4, 9), (3, 8, 11), (2, 3, 7), (1, 8, 9)])
+def test_ragged_chunks_get_their_own_tile_queue(model_factory, rc, piece, n):
+    """piece % refine_chunk != 0: every tower chunk of one forward() needs its own tile-queue counters (they are
+    zeroed once per forward and never reset by the kernel).  With shared counters the second chunk sees an exhausted
+    queue and leaves tiles uncomputed -> stale activations.  The image is large enough (> 2 rounds of tiles per XCD
+    band) for the dynamic queue to be in use."""
+    w, h, d = 1280, 720, 192
+    xs = np.stack([synth.model_input_i8(w, h, d, 40 + (s % 3)) for s in range(n)])
+    with api.StereoNetHIP(model_factory(w, h, d), precision=api.PREC_F16, max_batch=n, refine_chunk=rc, piece=piece) as eng:
+        disp, raw = eng.infer(xs)
+        singles = [eng.infer(xs[i]) for i in range(3)]
+    for i in range(n):
+        assert (singles[i % 3][0] == disp[i]).all() and (singles[i % 3][1] == raw[i]).all(), i
+
+
 @pytest.mark.parametrize("fused", [0, 1, 2, 3])
 @pytest.mark.parametrize("h,w,dil", [(8, 62, 1), (64, 96, 1), (45, 80, 1), (100, 129, 1), (37, 250, 1), (720, 1280, 1),
                                      (40, 70, 2)])

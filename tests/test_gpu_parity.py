@@ -13,7 +13,7 @@ EPE_TOL = 1e-3
 
 @pytest.fixture(scope="module")
 def small_engine(model_factory):
-    eng = api.StereoNetHIP(model_factory(96, 64, 48), max_batch=2)
+    eng = api.StereoNetHIP(model_factory(96, 64, 48), max_batch=2, precision=api.PREC_FP32)
     yield eng
     eng.close()
 
@@ -91,7 +91,7 @@ CASES = [("c96x64_d48", 96, 64, 48, 3), ("c160x96_d96", 160, 96, 96, 4), ("c100x
 @pytest.mark.parametrize("name,w,h,d,seed", CASES)
 def test_forward_small_vs_golden_and_oracle(model_factory, oracle, golden_net, weights_blob, name, w, h, d, seed):
     x = synth.model_input_i8(w, h, d, seed)
-    with api.StereoNetHIP(model_factory(w, h, d)) as eng:
+    with api.StereoNetHIP(model_factory(w, h, d), precision=api.PREC_FP32) as eng:
         disp, raw = eng.infer(x)
         low = eng.dbg_read("disp_low").reshape((h + 15) // 16, (w + 15) // 16)
         cost = eng.dbg_read("cost").reshape(d // 16, (h + 15) // 16, (w + 15) // 16)
@@ -112,7 +112,7 @@ def test_features_identical_eyes(model_factory, oracle, weights_blob):
     w, h, d = 96, 64, 48
     x = synth.model_input_i8(w, h, d, 5).copy()
     x[3:] = x[:3]
-    with api.StereoNetHIP(model_factory(w, h, d)) as eng:
+    with api.StereoNetHIP(model_factory(w, h, d), precision=api.PREC_FP32) as eng:
         eng.infer(x)
         fl, fr = eng.dbg_read("feat_l"), eng.dbg_read("feat_r")
     assert (fl == fr).all()
@@ -124,7 +124,7 @@ def test_full_size_epe(model_factory, oracle, weights_blob):
     """BASELINE.json configs[1]: 1280x720, D=192, one pair, fp32."""
     w, h, d = 1280, 720, 192
     x = synth.model_input_i8(w, h, d, 0)
-    with api.StereoNetHIP(model_factory(w, h, d)) as eng:
+    with api.StereoNetHIP(model_factory(w, h, d), precision=api.PREC_FP32) as eng:
         disp, raw = eng.infer(x)
         disp2, raw2 = eng.infer(x)
     odisp, oraw, _ = oracle.forward(weights_blob, x, d)
@@ -142,7 +142,7 @@ def test_padded_geometry(model_factory, oracle, weights_blob):
     # sizes that are not multiples of 16 are zero-padded right/bottom and cropped (C1 960x540, C5 1242x375 shapes)
     w, h, d = 124, 38, 32
     x = synth.model_input_i8(w, h, d, 9)
-    with api.StereoNetHIP(model_factory(w, h, d)) as eng:
+    with api.StereoNetHIP(model_factory(w, h, d), precision=api.PREC_FP32) as eng:
         disp, _ = eng.infer(x)
     odisp, _, _ = oracle.forward(weights_blob, x, d)
     assert disp.shape == (h, w)
@@ -177,11 +177,39 @@ def test_side_by_side_nv12_path(model_factory, oracle):
     sbs = np.random.default_rng(4).integers(0, 256, (h * 3 // 2) * 2 * w, dtype=np.uint8)
     left, right = oracle.split_sbs_nv12(sbs, w, h)
     ten_ref = oracle.preprocess_nv12(left, right, w, h)
-    with api.StereoNetHIP(model_factory(w, h, d)) as eng:
+    with api.StereoNetHIP(model_factory(w, h, d), precision=api.PREC_FP32) as eng:
         disp, raw, ten = eng.infer_sbs_nv12(sbs, want_tensor=True)
         disp2, raw2 = eng.infer(ten_ref)
     assert (ten == ten_ref).all()
     assert (disp == disp2).all() and (raw == raw2).all()
+
+
+def test_async_and_batched_nv12_ingest(model_factory, oracle):
+    """sn_submit_nv12 (async Run on FeedImg's raw frame, graph-replayed from the third use of a slot on) and
+    sn_preprocess_sbs_nv12_batch (the streaming ingest) == the reference's host split + CvtNV12Data2Tensors, then Run."""
+    w, h, d = 96, 64, 48
+    rng = np.random.default_rng(14)
+    frames = [rng.integers(0, 256, (h * 3 // 2) * 2 * w, dtype=np.uint8) for _ in range(3)]
+    tens = np.stack([oracle.preprocess_nv12(*oracle.split_sbs_nv12(f, w, h), w, h) for f in frames])
+    with api.StereoNetHIP(model_factory(w, h, d), precision=api.PREC_F16, max_batch=3, task_num=2) as eng:
+        disp_ref, raw_ref = eng.infer(tens)
+        got = eng.preprocess_sbs_nv12(np.stack(frames))
+        assert (got == tens).all()
+        outs = [(np.empty((h, w), np.int32), np.empty((h, w), np.float32)) for _ in range(9)]
+        tickets = []
+        for i in range(9):                  # 2 slots x (plain, capture, replay, replay...) and a mix with sn_submit
+            if len(tickets) == 2:
+                eng.wait(tickets.pop(0))
+            if i == 4:
+                tickets.append(eng.submit(tens[i % 3], outs[i][0], outs[i][1]))
+            else:
+                tickets.append(eng.submit_nv12(frames[i % 3], outs[i][0], outs[i][1]))
+        for t in tickets:
+            eng.wait(t)
+        for i in range(9):
+            assert (outs[i][0] == raw_ref[i % 3]).all() and (outs[i][1] == disp_ref[i % 3]).all(), i
+        with pytest.raises(api.StereoNetError):
+            eng.submit_nv12(frames[0][:-2], outs[0][0], None)
 
 
 def test_error_behaviour(model_factory, tmp_path):
@@ -193,7 +221,7 @@ def test_error_behaviour(model_factory, tmp_path):
     with pytest.raises(api.StereoNetError) as e:
         api.StereoNetHIP(str(bad))
     assert e.value.code == -3
-    with api.StereoNetHIP(model_factory(96, 64, 48)) as eng:
+    with api.StereoNetHIP(model_factory(96, 64, 48), precision=api.PREC_FP32) as eng:
         with pytest.raises(api.StereoNetError):
             eng.infer(np.zeros((6, 32, 32), np.int8))           # geometry mismatch (stereonet_node.cpp:682-690)
         with pytest.raises(api.StereoNetError):
