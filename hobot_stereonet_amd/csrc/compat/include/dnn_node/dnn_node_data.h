@@ -1,6 +1,7 @@
 // dnn_node_data.h — data types of the (closed) ROS package `dnn_node` as used by hobot_stereonet:
 // DNNTensor (preprocess.cpp:81-92), DnnNodeOutput (stereonet_node.cpp:693-696,1033-1034,1071-1083),
-// DnnNodePara / ModelTaskType (stereonet_node.cpp:129-147), Model (stereonet_node.cpp:51-91).
+// DnnNodePara / ModelTaskType (stereonet_node.cpp:129-147), Model (stereonet_node.cpp:51-91), and the two input types
+// the reference only names in using-declarations (stereonet_infer/include/preprocess.h:36,39): DNNInput, NV12PyramidInput.
 #pragma once
 #include <memory>
 #include <string>
@@ -17,6 +18,21 @@ namespace dnn_node {
 struct DNNTensor {
   hbSysMem sysMem[4] = {};
   hbDNNTensorProperties properties = {};
+};
+
+// Base of the typed model inputs of dnn_node; hobot_stereonet feeds DNNTensor (below: preprocess.cpp:952-966) and only
+// imports these two names into its namespace.
+struct DNNInput {
+  virtual ~DNNInput() = default;
+  virtual void Reset() {}
+};
+
+struct NV12PyramidInput : DNNInput {
+  uint64_t y_phy_addr = 0;
+  void* y_vir_addr = nullptr;
+  uint64_t uv_phy_addr = 0;
+  void* uv_vir_addr = nullptr;
+  int32_t height = 0, width = 0, y_stride = 0, uv_stride = 0;
 };
 
 enum class ModelTaskType { InvalidType = 0, ModelInferType = 1, ModelRoiInferType = 2 };

@@ -1,6 +1,7 @@
 // image_io.cpp — PNG / PPM / BMP -> BGR, PFM in/out.  See image_io.h for the role in the file-list feeder.
 #include "image_io.h"
 
+#include <cstdint>
 #include <zlib.h>
 
 #include <cmath>
@@ -40,6 +41,11 @@ int paeth(int a, int b, int c) {
   return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
 }
 
+// Header sizes come from user-supplied files (the list feeder): bound them before any size arithmetic so that
+// (size_t)w * h * k can neither wrap nor ask for an absurd allocation (a bad_alloc would kill the node).
+constexpr int kMaxImageDim = 16384;
+inline bool dims_ok(long w, long h) { return w > 0 && h > 0 && w <= kMaxImageDim && h <= kMaxImageDim; }
+
 bool decode_png(const std::vector<uint8_t>& file, int& w, int& h, std::vector<uint8_t>& bgr, std::string* err) {
   size_t pos = 8;
   int depth = 0, ctype = -1, interlace = 0;
@@ -67,6 +73,7 @@ bool decode_png(const std::vector<uint8_t>& file, int& w, int& h, std::vector<ui
     pos += 12 + (size_t)len;
   }
   if (ctype < 0 || w <= 0 || h <= 0) return fail(err, "png: no IHDR");
+  if (!dims_ok(w, h)) return fail(err, "png: image larger than 16384 x 16384");
   const bool packed = depth == 1 || depth == 2 || depth == 4;
   if (depth != 8 && !(packed && (ctype == 0 || ctype == 3)))
     return fail(err, "png: only 8-bit samples (or packed gray / palette) are supported for colour input");
@@ -153,7 +160,10 @@ bool pnm_token(const std::vector<uint8_t>& f, size_t& pos, int& value) {
   }
   if (pos >= f.size() || !isdigit(f[pos])) return false;
   long v = 0;
-  while (pos < f.size() && isdigit(f[pos])) v = v * 10 + (f[pos++] - '0');
+  while (pos < f.size() && isdigit(f[pos])) {
+    v = v * 10 + (f[pos++] - '0');
+    if (v > 1000000000L) return false;          // would not fit an int: reject instead of truncating
+  }
   value = (int)v;
   return true;
 }
@@ -164,9 +174,10 @@ bool decode_pnm(const std::vector<uint8_t>& f, int& w, int& h, std::vector<uint8
   int maxv = 0;
   if (!pnm_token(f, pos, w) || !pnm_token(f, pos, h) || !pnm_token(f, pos, maxv)) return fail(err, "pnm: bad header");
   if (maxv != 255) return fail(err, "pnm: only maxval 255 is supported");
+  if (!dims_ok(w, h)) return fail(err, "pnm: bad size (1..16384 per side)");
   ++pos;   // the single whitespace after maxval
-  const size_t need = (size_t)w * h * (colour ? 3 : 1);
-  if (w <= 0 || h <= 0 || pos + need > f.size()) return fail(err, "pnm: truncated");
+  const size_t need = (size_t)w * h * (colour ? 3 : 1);          // <= 3 * 2^28: no wrap
+  if (pos > f.size() || need > f.size() - pos) return fail(err, "pnm: truncated");
   bgr.resize((size_t)w * h * 3);
   const uint8_t* s = &f[pos];
   for (size_t i = 0; i < (size_t)w * h; ++i) {
@@ -191,9 +202,9 @@ bool decode_bmp(const std::vector<uint8_t>& f, int& w, int& h, std::vector<uint8
   if ((bpp != 24 && bpp != 32) || (comp != 0 && comp != 3)) return fail(err, "bmp: only uncompressed 24/32-bit is supported");
   w = bw;
   h = bh < 0 ? -bh : bh;
-  if (w <= 0 || h <= 0) return fail(err, "bmp: bad size");
+  if (bh == INT32_MIN || !dims_ok(w, h)) return fail(err, "bmp: bad size (1..16384 per side)");
   const size_t bytes = bpp / 8, pitch = ((size_t)w * bytes + 3) & ~(size_t)3;
-  if ((size_t)off + pitch * h > f.size()) return fail(err, "bmp: truncated pixels");
+  if ((size_t)off > f.size() || pitch * (size_t)h > f.size() - (size_t)off) return fail(err, "bmp: truncated pixels");
   bgr.resize((size_t)w * h * 3);
   for (int r = 0; r < h; ++r) {
     const int src_row = bh < 0 ? r : h - 1 - r;   // positive height = bottom-up
@@ -241,7 +252,7 @@ bool ReadPFM(const std::string& path, int& w, int& h, std::vector<float>& data, 
   std::string magic;
   double scale = 0;
   f >> magic >> w >> h >> scale;
-  if (magic != "Pf" || w <= 0 || h <= 0 || scale == 0) return fail(err, "pfm: bad header (single-channel Pf expected)");
+  if (magic != "Pf" || !dims_ok(w, h) || scale == 0) return fail(err, "pfm: bad header (single-channel Pf expected, 1..16384 per side)");
   f.get();   // the newline that ends the header
   data.resize((size_t)w * h);
   for (int r = h - 1; r >= 0; --r) {

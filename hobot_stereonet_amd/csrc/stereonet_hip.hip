@@ -27,6 +27,7 @@ using namespace sn;
 constexpr int kNDown = 4, kNFeatRes = 6, kNAgg = 4, kNRefRes = 6;
 constexpr int kRefDil[kNRefRes] = {1, 2, 4, 8, 1, 1};
 constexpr float kOutScale = 2.60443857769133e-6f;   // stereonet_node.cpp:282
+constexpr double kWireFactor = 16.0 * 12.0;         // parser.cpp:86
 constexpr int kMaxPieceEvents = 64;
 constexpr int kMaxTowerStreams = 2;
 
@@ -968,7 +969,9 @@ int refine_chunk(sn_handle* h, Workspace& ws, hipStream_t st, int sidx, int ordi
   const int ncu = h->num_cu;
   const int Hp = h->Hp, Wp = h->Wp, hl = h->hl, wl = h->wl;
   const size_t HW = (size_t)h->H * h->W;
-  const float inv_q = (float)(1.0 / ((double)h->D * (double)kOutScale));
+  // The wire factor is the reference's literal 16 * 12 for EVERY dmax (parser.cpp:86, stereonet_node.cpp:288,
+  // publisher_member_function.py:75): the unmodified consumers recover pixels whatever D the model was built for.
+  const float inv_q = (float)(1.0 / (kWireFactor * (double)kOutScale));
   LoadRefineIn ld{ws.disp_low + (size_t)q0 * hl * wl, in6 + (size_t)q0 * 6 * HW, hl, wl, h->H, h->W, Hp, Wp,
                   1.0f / (float)h->D};
   float* od = out_disp ? out_disp + (size_t)q0 * HW : nullptr;

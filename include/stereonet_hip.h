@@ -28,8 +28,9 @@
  * Tensor contract (unchanged from the reference):
  *   input  int8  NCHW [n][6][H][W]: L-Y, L-"U", L-"V", R-Y, R-"U", R-"V"; value = byte ^ 0x80
  *          (preprocess.cpp:999-1003,1033-1040)
- *   output int32 NCHW [n][1][H][W]: raw; disparity_px = raw * out_scale * dmax
- *          (stereonet_node.cpp:282-288, parser.cpp:84-86, publisher_member_function.py:73-75)
+ *   output int32 NCHW [n][1][H][W]: raw; disparity_px = raw * out_scale * 16 * 12 — the reference's literal
+ *          factor (stereonet_node.cpp:282-288, parser.cpp:84-86, publisher_member_function.py:73-75) for every
+ *          dmax, so the unmodified consumers recover pixels whatever D the model was built for
  *   optional float output [n][H][W]: disparity in px before int32 quantisation.
  */
 #ifndef STEREONET_HIP_H_

@@ -505,8 +505,9 @@ int so_forward(const float *weights, const int8_t *in6, int w, int h, int dmax,
   float *dup = falloc(pp), *dfull = falloc(pp);
   so_upsample_bilinear(dlow, hl, wl, 16, 16.0f, dup);
   so_refine(weights, dup, planes, hp, wp, dmax, dfull);
-  /* wire format: raw = lrintf(disp * inv_q), inv_q = float(1 / (dmax * scale)) */
-  const float inv_q = (float)(1.0 / ((double)dmax * (double)SO_OUT_SCALE));
+  /* wire format: raw = lrintf(disp * inv_q), inv_q = float(1 / (16 * 12 * scale)) for EVERY dmax: every consumer of
+   * the tensor multiplies by the literal 16 * 12 (parser.cpp:86, stereonet_node.cpp:288, publisher_member_function.py:75) */
+  const float inv_q = (float)(1.0 / (16.0 * 12.0 * (double)SO_OUT_SCALE));
   for (int y = 0; y < h; ++y)
     for (int x = 0; x < w; ++x) {
       const float v = dfull[(size_t)y * wp + x];

@@ -54,7 +54,7 @@ def test_forward_small_f16(model_factory, oracle, golden_net, weights_blob, name
     epe = float(np.abs(disp - odisp).mean())
     assert epe < EPE_TOL, epe
     assert np.abs(disp - golden_net[name + ".disp"]).mean() < EPE_TOL
-    inv_q = np.float32(1.0 / (float(d) * float(np.float32(spec.OUT_SCALE))))
+    inv_q = np.float32(1.0 / (192.0 * float(np.float32(spec.OUT_SCALE))))
     assert (raw == np.rint(disp * inv_q).astype(np.int32)).all()
 
 

@@ -102,7 +102,7 @@ def test_forward_small_vs_golden_and_oracle(model_factory, oracle, golden_net, w
     assert np.abs(disp - odisp).mean() < EPE_TOL
     assert np.abs(disp - odisp).max() < 20 * EPE_TOL
     # wire format is the same integer map of the float disparity as the oracle's
-    inv_q = np.float32(1.0 / (float(d) * float(np.float32(spec.OUT_SCALE))))
+    inv_q = np.float32(1.0 / (192.0 * float(np.float32(spec.OUT_SCALE))))
     assert (raw == np.rint(disp * inv_q).astype(np.int32)).all()
     assert raw.min() >= 0
 
@@ -132,10 +132,10 @@ def test_full_size_epe(model_factory, oracle, weights_blob):
     print(f"EPE vs oracle at 1280x720 D=192: {epe:.3e} px, max {np.abs(disp - odisp).max():.3e}")
     assert epe < EPE_TOL
     assert (disp == disp2).all() and (raw == raw2).all()          # deterministic
-    assert np.abs(raw.astype(np.int64) - oraw).max() <= 1 + int(20 * EPE_TOL / (d * spec.OUT_SCALE))
+    assert np.abs(raw.astype(np.int64) - oraw).max() <= 1 + int(20 * EPE_TOL / (192 * spec.OUT_SCALE))
     # the render node's dequantisation (publisher_member_function.py:65-75) recovers the disparity
     back = raw.view(np.uint32).astype(np.float64) * spec.OUT_SCALE * 16 * 12
-    assert np.abs(back - disp).max() < 0.51 * d * spec.OUT_SCALE + 1e-5
+    assert np.abs(back - disp).max() < 0.51 * 192 * spec.OUT_SCALE + 1e-5
 
 
 def test_padded_geometry(model_factory, oracle, weights_blob):
@@ -252,7 +252,7 @@ def test_baseline_config_c5_kitti_1242x375_d256(model_factory, oracle, weights_b
     epe = float(np.abs(disp - odisp).mean())
     print(f"C5 1242x375 D=256 prec={prec}: EPE {epe:.3e} px")
     assert disp.shape == (h, w) and epe < EPE_TOL
-    inv_q = np.float32(1.0 / (float(d) * float(np.float32(spec.OUT_SCALE))))
+    inv_q = np.float32(1.0 / (192.0 * float(np.float32(spec.OUT_SCALE))))
     assert (raw == np.rint(disp * inv_q).astype(np.int32)).all()
 
 
