@@ -95,20 +95,6 @@ struct LoadF32 {            // plain NCHW fp32 tensor [nimg][C][H][W]
     if ((unsigned)y >= (unsigned)H || (unsigned)x >= (unsigned)W || c >= C) return 0.f;
     return p[(((unsigned)img * C + c) * H + y) * W + x];      // 32-bit index: tensors are < 2^32 elements (host check)
   }
-  // vector staging (k_conv_x3s): base of the 8-channel block cb at (y, x) = (0, 0) and the channel stride;
-  // false = the whole block is zero padding
-  static constexpr bool kVec = true;
-  static constexpr bool kSlots = false;
-  __device__ __forceinline__ bool slot_base(int, int, const uint4*&) const { return false; }
-  __device__ __forceinline__ int plane_off(int) const { return 0; }
-  __device__ __forceinline__ bool plane_valid(int, int) const { return false; }
-  __device__ __forceinline__ const uint4* image_base(int) const { return nullptr; }
-  __device__ __forceinline__ bool vec_aligned() const { return ((size_t)p & 3) == 0; }
-  __device__ __forceinline__ bool cb_base(int img, int cb, const float*& base, unsigned& cstride) const {
-    cstride = (unsigned)H * W;
-    base = p + ((size_t)img * C + 8 * cb) * cstride;
-    return 8 * cb < C;
-  }
 };
 
 struct LoadI8Eye {          // model input int8 [n][6][H][W]; image = n*2 + eye; 3 real channels
@@ -134,20 +120,6 @@ struct LoadVol3D {
       return 0.f;
     return p[((((unsigned)n * Dl + dd) * kC + ci) * H + y) * W + x];
   }
-  static constexpr bool kVec = true;
-  static constexpr bool kSlots = false;
-  __device__ __forceinline__ bool slot_base(int, int, const uint4*&) const { return false; }
-  __device__ __forceinline__ int plane_off(int) const { return 0; }
-  __device__ __forceinline__ bool plane_valid(int, int) const { return false; }
-  __device__ __forceinline__ const uint4* image_base(int) const { return nullptr; }
-  __device__ __forceinline__ bool vec_aligned() const { return ((size_t)p & 3) == 0; }
-  __device__ __forceinline__ bool cb_base(int img, int cb, const float*& base, unsigned& cstride) const {
-    const int n = img / Dl, d = img - n * Dl;
-    const int dd = d + (cb >> 2) - 1;
-    cstride = (unsigned)H * W;
-    base = p + (((size_t)n * Dl + dd) * kC + 8 * (cb & 3)) * cstride;
-    return (unsigned)dd < (unsigned)Dl;
-  }
 };
 
 // Same, but the volume is the cost volume computed on the fly from the two feature maps:
@@ -166,14 +138,6 @@ struct LoadCostVol {
     const unsigned li = ((unsigned)(2 * n) * kC + ci) * plane + (unsigned)y * W + x;
     return feat[li] - feat[li + kC * plane - dd];
   }
-  static constexpr bool kVec = false;        // two differently aligned reads per element: scalar staging
-  static constexpr bool kSlots = false;
-  __device__ __forceinline__ bool slot_base(int, int, const uint4*&) const { return false; }
-  __device__ __forceinline__ int plane_off(int) const { return 0; }
-  __device__ __forceinline__ bool plane_valid(int, int) const { return false; }
-  __device__ __forceinline__ const uint4* image_base(int) const { return nullptr; }
-  __device__ __forceinline__ bool vec_aligned() const { return false; }
-  __device__ __forceinline__ bool cb_base(int, int, const float*&, unsigned&) const { return false; }
 };
 
 // Split-slot activations of the low-resolution branch (fp16 modes): [image][channel block (4)][hi | lo][H][W]
@@ -185,11 +149,6 @@ struct LoadCostVol {
 struct SlotIn {
   const uint4* p;
   int Dl, H, W;
-  static constexpr bool kVec = false;
-  static constexpr bool kSlots = true;
-  __device__ __forceinline__ bool vec_aligned() const { return false; }
-  __device__ __forceinline__ float operator()(int, int, int, int) const { return 0.f; }
-  __device__ __forceinline__ bool cb_base(int, int, const float*&, unsigned&) const { return false; }
   // k_conv_x3s staging: slot offset of virtual block vb relative to block 0 of image img, and its validity
   __device__ __forceinline__ int plane_off(int vb) const {
     const int hw2 = 2 * H * W;
@@ -201,19 +160,6 @@ struct SlotIn {
     return (unsigned)(d + (vb >> 2) - 1) < (unsigned)Dl;
   }
   __device__ __forceinline__ const uint4* image_base(int img) const { return p + (size_t)img * 8 * ((size_t)H * W); }
-  // hi plane of virtual block vb of image img (lo plane = hi + H * W); false = zero padding plane
-  __device__ __forceinline__ bool slot_base(int img, int vb, const uint4*& hi) const {
-    int image = img, cb = vb;
-    if (Dl > 0) {
-      const int n = img / Dl, d = img - n * Dl;
-      const int dd = d + (vb >> 2) - 1;
-      if ((unsigned)dd >= (unsigned)Dl) return false;
-      image = n * Dl + dd;
-      cb = vb & 3;
-    }
-    hi = p + ((size_t)image * 4 + cb) * 2 * ((size_t)H * W);
-    return true;
-  }
 };
 __device__ __forceinline__ size_t low_slot_index(int img, int cb, int part, int y, int x, int H, int W) {
   return ((((size_t)img * 4 + cb) * 2 + part) * H + y) * (size_t)W + x;
@@ -299,11 +245,9 @@ struct ConvArgs {
   int dil, pad;
   int lrelu;
   int tiles_x, tiles_y;
-  int f16_Hs, f16_Ws;  // OUTF >= 1 only: padded plane dims of the fp16 NCHW8c output
-  size_t f16_lo_off;   // OUTF == 2 only: byte offset from the hi tensor to the lo tensor
 };
 
-template <int KS, int STRIDE, int DIL, int CH, int TR, int TC, class Loader, int OUTF = 0, bool PF = true, int MINW = 1>
+template <int KS, int STRIDE, int DIL, int CH, int TR, int TC, class Loader, bool PF = true, int MINW = 1>
 __global__ __launch_bounds__(256, MINW) void k_conv_c32_mfma(ConvArgs a, Loader ld) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int TAPS = KS * KS;
@@ -434,44 +378,7 @@ __global__ __launch_bounds__(256, MINW) void k_conv_c32_mfma(ConvArgs a, Loader 
     const int seg = wave * SPW + s;
     const int srow = seg / CSEG, scol = (seg - srow * CSEG) * 32;
     const int y = ty * TR + srow, x = tx * TC + scol + j;
-    if (OUTF == 2) {
-      // split fp16 pair (SN_PREC_F16X3): hi = fp16(v), lo = fp16((v - hi) * 2^11), two NCHW8c tensors
-      if (y < a.Ho && x < a.Wo) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          half4 hh, hl;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float v = acc[s][4 * q + e] + a.bias[8 * q + 4 * kh + e];
-            if (a.lrelu) v = v > 0.f ? v : v * kSlope;
-            const _Float16 hi = (_Float16)v;
-            hh[e] = hi;
-            hl[e] = (_Float16)((v - (float)hi) * kSplitScale);
-          }
-          const size_t slot = (((size_t)img * 4 + q) * a.f16_Hs + (y + kRefPad)) * a.f16_Ws + (x + kRefPad);
-          char* p0 = reinterpret_cast<char*>(a.out) + slot * 16 + kh * 8;
-          *reinterpret_cast<half4*>(p0) = hh;
-          *reinterpret_cast<half4*>(p0 + a.f16_lo_off) = hl;
-        }
-      }
-    } else if (OUTF == 1) {
-      // fp16 NCHW8c with zero border (RefGeom, below): channel block q = r>>2 holds couts 8q..8q+7,
-      // this lane owns 4 of them (4*kh + (r&3)) -> one 8-byte store per block, 512 B per wave-store.
-      if (y < a.Ho && x < a.Wo) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          half4 hv;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float v = acc[s][4 * q + e] + a.bias[8 * q + 4 * kh + e];
-            if (a.lrelu) v = v > 0.f ? v : v * kSlope;
-            hv[e] = (_Float16)v;
-          }
-          const size_t slot = (((size_t)img * 4 + q) * a.f16_Hs + (y + kRefPad)) * a.f16_Ws + (x + kRefPad);
-          *reinterpret_cast<half4*>(reinterpret_cast<char*>(a.out) + slot * 16 + kh * 8) = hv;
-        }
-      }
-    } else if (y < a.Ho && x < a.Wo) {
+    if (y < a.Ho && x < a.Wo) {
       const size_t base = (size_t)img * kC * plane_o + (size_t)y * a.Wo + x;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -487,191 +394,20 @@ __global__ __launch_bounds__(256, MINW) void k_conv_c32_mfma(ConvArgs a, Loader 
 }
 
 // ------------------------------------------------------------------------------------------
-// Split-operand variant of the implicit GEMM (3x3 stride 1, 5x5 stride 2) for the LOW-RESOLUTION layers (32->32
-// down-convs, feature res-blocks, cost-volume / 3-D aggregation convs) in the fp16 modes: the fp32 activations are split on the fly into
-// (hi, lo) fp16 pairs while being staged into LDS, weights are pre-split on the host, and each product is
-// three v_mfma_f32_32x32x16_f16 (see k_ref_conv_f16x3): 22-bit operands, fp32 accumulation, at 3/16 of the
-// cost of the exact-fp32 MFMA the fp32 mode uses.  Inputs/outputs stay fp32 NCHW in HBM.
-//   LDS image: [hi|lo][channel block of 8][row][col] 16-byte slots -> the B fragment of lane (pixel j, half g)
-//   is one conflict-free ds_read_b128; A fragments [tap][hi|lo][lane] are a straight copy of the host packing.
-//   K chunk = 16 (virtual) input channels = one MFMA K step; register staging as in k_conv_c32_mfma.
-// ------------------------------------------------------------------------------------------
-template <int KS, int STRIDE, int DIL, int TR, int TC, class Loader>
-__global__ __launch_bounds__(256) void k_conv_c32_x3(ConvArgs a, Loader ld) {
-  extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
-  constexpr int CH = 16, TAPS = KS * KS;
-  constexpr bool WLDS = TAPS <= 9;                     // 3x3: A fragments staged in LDS; 5x5: read through L1
-  constexpr int CSEG = TC / 32, NSEG = TR * CSEG;
-  static_assert(NSEG % 4 == 0, "tile must split evenly over 4 waves");
-  static_assert(STRIDE == 1 || DIL == 1, "strided convs are not dilated");
-  constexpr int SPW = NSEG / 4;
-  constexpr int ROWS_IN = (TR - 1) * STRIDE + (KS - 1) * DIL + 1;
-  constexpr int COLS_IN = (TC - 1) * STRIDE + (KS - 1) * DIL + 1;
-  constexpr int HALF = (COLS_IN + 1) / 2;
-  constexpr int PITCH = STRIDE == 1 ? COLS_IN : 2 * HALF;   // stride 2: columns split by parity, as in the fp32 kernel
-  constexpr int PLANE = ROWS_IN * PITCH;               // slots per channel block
-  constexpr int NW4 = TAPS * 2 * 64;                   // weight slots per chunk
-  constexpr int WPT = WLDS ? (NW4 + 255) / 256 : 1;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nwg = a.tiles_x * a.tiles_y * a.nimg;
-  const int b = xcd_remap(blockIdx.x, nwg);
-  const int tx = b % a.tiles_x;
-  const int t2 = b / a.tiles_x;
-  const int ty = t2 % a.tiles_y;
-  const int img = t2 / a.tiles_y;
-
-  uint4* s_w = smem4;                                  // [TAPS][hi|lo][64] (WLDS only)
-  uint4* s_xh = smem4 + (WLDS ? NW4 : 0);              // [2 blocks][PLANE]
-  uint4* s_xl = s_xh + 2 * PLANE;
-  const int iy0 = ty * TR * STRIDE - a.pad, ix0 = tx * TC * STRIDE - a.pad;
-
-  f32x16 acc0[SPW], acc1[SPW];
-#pragma unroll
-  for (int s = 0; s < SPW; ++s)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      acc0[s][r] = 0.f;
-      acc1[s][r] = 0.f;
-    }
-  const int gh = lane >> 5, j = lane & 31;
-
-  // Staging unit = one pixel of one 8-channel block: eight coalesced 4-byte loads (one per channel plane), split
-  // into (hi, lo) in registers and committed as ONE 16-byte LDS write each -- the per-element 2-byte writes this
-  // replaces were 8-way bank conflicted and cost more LDS time than the MFMAs of the chunk.
-  constexpr int NSLOT = 2 * ROWS_IN * COLS_IN;
-  constexpr int SPT = (NSLOT + 255) / 256;
-  float pre[SPT][8];
-  uint4 wpre[WPT];
-  auto fetch = [&](int c0) {
-    int tq = tid;
-    asm volatile("" : "+v"(tq));
-#pragma unroll
-    for (int e = 0; e < SPT; ++e) {
-      const int idx = e * 256 + tq;
-      const int cb = idx / (ROWS_IN * COLS_IN);
-      const int rem = idx - cb * (ROWS_IN * COLS_IN);
-      const int r = rem / COLS_IN;
-      const int cc = rem - r * COLS_IN;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) pre[e][k] = idx < NSLOT ? ld(img, c0 + cb * 8 + k, iy0 + r, ix0 + cc) : 0.f;
-    }
-    if (WLDS) {
-      const uint4* wsrc = reinterpret_cast<const uint4*>(a.wpk) + (size_t)(c0 / CH) * NW4;
-#pragma unroll
-      for (int e = 0; e < WPT; ++e) {
-        const int idx = e * 256 + tq;
-        wpre[e] = idx < NW4 ? wsrc[idx] : make_uint4(0, 0, 0, 0);
-      }
-    }
-  };
-  auto commit = [&]() {
-    int tq = tid;
-    asm volatile("" : "+v"(tq));
-#pragma unroll
-    for (int e = 0; e < SPT; ++e) {
-      const int idx = e * 256 + tq;
-      const int cb = idx / (ROWS_IN * COLS_IN);
-      const int rem = idx - cb * (ROWS_IN * COLS_IN);
-      const int r = rem / COLS_IN;
-      const int cc = rem - r * COLS_IN;
-      if (idx < NSLOT) {
-        half8 hi, lo;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const float v = pre[e][k];
-          hi[k] = (_Float16)v;
-          lo[k] = (_Float16)((v - (float)hi[k]) * kSplitScale);
-        }
-        const int di = STRIDE == 1 ? cc : (cc & 1) * HALF + (cc >> 1);
-        const int off = cb * PLANE + r * PITCH + di;
-        s_xh[off] = *reinterpret_cast<const uint4*>(&hi);
-        s_xl[off] = *reinterpret_cast<const uint4*>(&lo);
-      }
-    }
-    if (WLDS) {
-#pragma unroll
-      for (int e = 0; e < WPT; ++e) {
-        const int idx = e * 256 + tq;
-        if (idx < NW4) s_w[idx] = wpre[e];
-      }
-    }
-  };
-
-  fetch(0);
-  commit();
-  __syncthreads();
-
-  for (int c0 = 0; c0 < a.cin_pad; c0 += CH) {
-    const bool more = c0 + CH < a.cin_pad;
-    if (more) fetch(c0 + CH);
-    const uint4* bh = s_xh + gh * PLANE + j;
-    const uint4* bl = s_xl + gh * PLANE + j;
-    const uint4* wg = reinterpret_cast<const uint4*>(a.wpk) + (size_t)(c0 / CH) * NW4 + lane;
-#pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
-      const int ky = tap / KS, kx = tap - ky * KS;
-      const uint4 wa = WLDS ? s_w[(tap * 2 + 0) * 64 + lane] : wg[(tap * 2 + 0) * 64];
-      const uint4 wb = WLDS ? s_w[(tap * 2 + 1) * 64 + lane] : wg[(tap * 2 + 1) * 64];
-      const half8 whi = *reinterpret_cast<const half8*>(&wa);
-      const half8 wlo = *reinterpret_cast<const half8*>(&wb);
-#pragma unroll
-      for (int s = 0; s < SPW; ++s) {
-        const int seg = wave * SPW + s;
-        const int srow = seg / CSEG, scol = (seg - srow * CSEG) * 32;
-        const int off = STRIDE == 1 ? (srow + ky * DIL) * PITCH + scol + kx * DIL
-                                    : (srow * STRIDE + ky) * PITCH + (kx & 1) * HALF + scol + (kx >> 1);
-        const uint4 xa = bh[off], xb = bl[off];
-        const half8 xh = *reinterpret_cast<const half8*>(&xa);
-        const half8 xl = *reinterpret_cast<const half8*>(&xb);
-        acc0[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, xh, acc0[s], 0, 0, 0);
-        acc1[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, xh, acc1[s], 0, 0, 0);
-        acc1[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, xl, acc1[s], 0, 0, 0);
-      }
-    }
-    __syncthreads();
-    if (more) {
-      commit();
-      __syncthreads();
-    }
-  }
-
-  const size_t plane_o = (size_t)a.Ho * a.Wo;
-#pragma unroll
-  for (int s = 0; s < SPW; ++s) {
-    const int seg = wave * SPW + s;
-    const int srow = seg / CSEG, scol = (seg - srow * CSEG) * 32;
-    const int y = ty * TR + srow, x = tx * TC + scol + j;
-    if (y < a.Ho && x < a.Wo) {
-      const size_t base = (size_t)img * kC * plane_o + (size_t)y * a.Wo + x;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = (r & 3) + 8 * (r >> 2) + 4 * gh;
-        float v = acc0[s][r] + acc1[s][r] * kSplitInv + a.bias[co];
-        const size_t idx = base + (size_t)co * plane_o;
-        if (a.res) v += a.res[idx];
-        if (a.lrelu) v = v > 0.f ? v : v * kSlope;
-        a.out[idx] = v;
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// Weights-stationary split-operand implicit GEMM for the LOW-RESOLUTION layers of the fp16 modes (second
-// generation of k_conv_c32_x3; same operands, same arithmetic: three fp16 MFMAs per product on hi/lo pairs).
-// k_conv_c32_x3 re-reads the A fragments of every tap for every 32-pixel segment (5x5: 51 KB of weights per wave
-// and 16-channel chunk through L1/L2 for 75 MFMAs) and is bound by that traffic.  Here
+// Weights-stationary split-operand implicit GEMM for the LOW-RESOLUTION layers of the fp16 modes: three fp16 MFMAs
+// per product on hi/lo operand pairs (x * w ~ xh*wh + (xh*wl + xl*wh) * 2^-11, two fp32 accumulators).  A kernel
+// that re-reads the A fragments of every tap for every 32-pixel segment (5x5: 51 KB of weights per wave and
+// 16-channel chunk through L1/L2 for 75 MFMAs) is bound by that traffic.  Here
 //   * the workgroup is persistent and each wave keeps ITS weights in registers for the whole launch: K is split
 //     across the two wave pairs by virtual channel halves (waves 0,1: channels [0, VCH/2), waves 2,3: the rest),
 //     so a wave holds TAPS * VCH/32 K-steps x (hi, lo) fragments (5x5 C=32: 200 VGPRs, 3x3x3: 216, 3x3: 72);
-//   * the whole VCH-channel halo tile is staged once per tile (fp32 loads one tile ahead in registers, split to
-//     hi/lo and committed as 16-byte pixel slots), each wave pair works on its own channel blocks of it;
+//   * the whole VCH-channel halo tile is staged once per tile (16-byte slot copies, one tile ahead in registers),
+//     each wave pair works on its own channel blocks of it;
 //   * the two K-halves of a segment are summed through LDS: a wave owns one of its pair-partner's two segments,
 //     writes the partial of the other one, reads the partner's, and finishes (bias, residual, LeakyReLU, store).
 // A segment is 32 output pixels = (32 / SEGW) rows x SEGW columns (SEGW = 16 tiles an 80-column map exactly).
-// Inputs/outputs stay fp32 NCHW in HBM; Loader supplies zero padding and the virtual-channel mapping.
+// The input is a split-slot tensor (SlotIn supplies the virtual-channel mapping of the 3-D layers); the output is a
+// split-slot tensor (OUTSLOT) or fp32 NCHW (the feature map and the last aggregation volume).
 // ------------------------------------------------------------------------------------------
 template <int KS, int STRIDE, int VCH, int TR, int TC, int SEGW>
 struct X3sTile {
@@ -686,19 +422,13 @@ struct X3sTile {
   static constexpr int PLANE = ROWS_IN * PITCH;
   static constexpr int NSLOT = NCB * ROWS_IN * COLS_IN;
   static constexpr int SPT = (NSLOT + 255) / 256;
-  // vector staging: rows are read as float4 quads from the first halo column (global_load_dwordx4 only needs
-  // 4-byte alignment); a quad that straddles the image border falls back to per-element loads
-  static constexpr int SH = 0;
-  static constexpr int NQ = (SH + COLS_IN + 3) / 4;
-  static constexpr int NU = NCB * ROWS_IN * NQ;
-  static constexpr int UPT = (NU + 255) / 256;
   static constexpr int RED_FLOATS = 4 * 16 * 64;           // one segment partial per wave
   static constexpr size_t LDS_BYTES = (size_t)2 * NCB * PLANE * 16 + (size_t)RED_FLOATS * 4 + 32 * 4 + 16;
   static_assert(VCH % 32 == 0 && SPW == 2, "two segments per wave pair member");
   static_assert(TR % SEGH == 0 && TC % SEGW == 0, "tile must be whole segments");
 };
 
-// Loader::kSlots: the input is a split-slot tensor (SlotIn) and staging is a 16-byte copy per (block, part, pixel);
+// Staging is a 16-byte copy per (block, part, pixel) of the SlotIn tensor;
 // OUTSLOT: the epilogue writes (and reads the residual from) a split-slot tensor instead of fp32 NCHW.
 // HASRES: a residual tensor (same format as the output) is added before the activation.
 template <int KS, int STRIDE, int VCH, int TR, int TC, int SEGW, int MINB, bool OUTSLOT, bool HASRES, class Loader>
@@ -738,26 +468,19 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
   }
   if (tid < kC) s_bias[tid] = a.bias[tid];
   const int total = a.tiles_x * a.tiles_y * a.nimg;
-  // Staging.  Vector path (plain NCHW / 3-D volume loaders, W % 4 == 0): a unit is 8 channels x 4 consecutive
-  // columns = eight aligned 16-byte loads and four pixel slots, with ONE address / bounds computation per unit
-  // (the per-element loader costs ~40 instructions per value, which a 1-wave-per-SIMD kernel cannot hide).
-  // Scalar path (cost-volume loader, odd widths): one pixel slot = 8 loader calls, as in k_conv_c32_x3.
-  // Slot path (SlotIn): a unit is one 16-byte slot of (virtual block, part, row, column): load -> LDS, no VALU.
-  constexpr bool VEC = Loader::kVec;
-  constexpr bool SLOTS = Loader::kSlots;
+  // Staging: a unit is one 16-byte slot of (virtual block, part, row, column): load -> LDS, no VALU.
+  static_assert(std::is_same<Loader, SlotIn>::value, "k_conv_x3s reads split-slot tensors");
   constexpr int NSL = 2 * T::NSLOT, LPT = (NSL + 255) / 256;       // slots per tile (hi and lo) / per thread
-  constexpr int NPRE = SLOTS ? LPT * 4 : (VEC ? T::UPT * 32 : T::SPT * 8);
-  float pre[NPRE];
-  const bool vec_ok = VEC && ld.vec_aligned();
-  // Slot path: which slot a thread copies in round e never changes, so (block, part, row, column, LDS offset) are
+  float pre[LPT * 4];
+  // Which slot a thread copies in round e never changes, so (block, part, row, column, LDS offset) are
   // decoded ONCE into one packed register per round; per tile a copy is then ~10 instructions of address math
   // (decoding idx -> coordinates per tile cost 9,000 of the 21,000 cycles a 5x5 tile took).
   //   bits 0..12 LDS slot offset (inside s_xh / s_xl), 13..19 column, 20..24 row, 25..28 virtual block, 29 part,
   //   30 valid
-  unsigned stab[SLOTS ? LPT : 1];
-  int srel[SLOTS ? LPT : 1];            // slot offset of the copy relative to (image, block 0, hi, row iy0, column ix0)
+  unsigned stab[LPT];
+  int srel[LPT];            // slot offset of the copy relative to (image, block 0, hi, row iy0, column ix0)
   constexpr int DUMMY = 2 * T::NCB * T::PLANE + T::RED_FLOATS / 4 + 8;     // spare LDS slot behind the bias
-  if (SLOTS) {
+  {
     static_assert(DUMMY < 8192 && T::COLS_IN < 128 && T::ROWS_IN < 32 && T::NCB <= 16, "packed staging table");
     static_assert(LPT <= 32, "one validity bit per staging round");
 #pragma unroll
@@ -778,7 +501,7 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
   const char* f_ibase = nullptr;
   int f_iy0 = 0, f_ix0 = 0, f_toff = 0;
   unsigned f_pmask = 0;
-  auto fetch_one = [&](int e) {         // SLOTS only: copy number e of the tile prepared by fetch()
+  auto fetch_one = [&](int e) {         // copy number e of the tile prepared by fetch()
     unsigned t = stab[e];
     int rel = srel[e];
     asm volatile("" : "+v"(t), "+v"(rel));      // keep the unpacking inside the tile loop (hoisted it spills)
@@ -794,9 +517,7 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
     const int tx = tile % a.tiles_x, t2 = tile / a.tiles_x;
     const int ty = t2 % a.tiles_y, img = t2 / a.tiles_y;
     const int iy0 = ty * TR * STRIDE - a.pad, ix0 = tx * TC * STRIDE - a.pad;
-    int tq = tid;
-    asm volatile("" : "+v"(tq));
-    if (SLOTS) {
+    {
       // branch-free: every lane loads; a slot outside the tensor (zero padding, missing depth plane) reads slot 0
       // of the image instead and is replaced by zeros when it is committed to LDS.  Only the per-tile constants
       // are set up here; the LPT copies themselves are issued from inside the MFMA loop (fetch_one), where their
@@ -809,68 +530,10 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
 #pragma unroll
       for (int vb = 0; vb < T::NCB; ++vb) f_pmask |= ld.plane_valid(img, vb) ? (1u << vb) : 0u;
       vmask = 0;
-    } else if (VEC && vec_ok) {
-#pragma unroll
-      for (int u = 0; u < T::UPT; ++u) {
-        const int idx = u * 256 + tq;
-        const int cb = idx / (T::ROWS_IN * T::NQ);
-        const int rem = idx - cb * (T::ROWS_IN * T::NQ);
-        const int r = rem / T::NQ, q = rem - r * T::NQ;
-        const int y = iy0 + r, x = ix0 - T::SH + 4 * q;
-        const float* base = nullptr;
-        unsigned cs = 0;
-        const bool row_ok = idx < T::NU && ld.cb_base(img, cb, base, cs) && (unsigned)y < (unsigned)ld.H;
-        const bool inside = row_ok && x >= 0 && x + 3 < ld.W;
-        const bool edge = row_ok && !inside && x + 3 >= 0 && x < ld.W;
-        const float* src = base + (ptrdiff_t)y * ld.W + x;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (inside) {
-            v = *reinterpret_cast<const float4*>(src + (size_t)k * cs);
-          } else if (edge) {
-            const float* sk = src + (size_t)k * cs;
-            if ((unsigned)(x + 0) < (unsigned)ld.W) v.x = sk[0];
-            if ((unsigned)(x + 1) < (unsigned)ld.W) v.y = sk[1];
-            if ((unsigned)(x + 2) < (unsigned)ld.W) v.z = sk[2];
-            if ((unsigned)(x + 3) < (unsigned)ld.W) v.w = sk[3];
-          }
-          pre[u * 32 + k * 4 + 0] = v.x;
-          pre[u * 32 + k * 4 + 1] = v.y;
-          pre[u * 32 + k * 4 + 2] = v.z;
-          pre[u * 32 + k * 4 + 3] = v.w;
-        }
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < T::SPT; ++e) {
-        const int idx = e * 256 + tq;
-        const int cb = idx / (T::ROWS_IN * T::COLS_IN);
-        const int rem = idx - cb * (T::ROWS_IN * T::COLS_IN);
-        const int r = rem / T::COLS_IN;
-        const int cc = rem - r * T::COLS_IN;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) pre[e * 8 + k] = idx < T::NSLOT ? ld(img, cb * 8 + k, iy0 + r, ix0 + cc) : 0.f;
-      }
     }
-  };
-  auto put_slot = [&](int cb, int r, int cc, const float* v, int vstride) {
-    half8 hi, lo;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const float f = v[k * vstride];
-      hi[k] = (_Float16)f;
-      lo[k] = (_Float16)((f - (float)hi[k]) * kSplitScale);
-    }
-    const int di = STRIDE == 1 ? cc : (cc & 1) * T::HALF + (cc >> 1);
-    const int off = cb * T::PLANE + r * T::PITCH + di;
-    s_xh[off] = *reinterpret_cast<const uint4*>(&hi);
-    s_xl[off] = *reinterpret_cast<const uint4*>(&lo);
   };
   auto commit = [&]() {
-    int tq = tid;
-    asm volatile("" : "+v"(tq));
-    if (SLOTS) {
+    {
 #pragma unroll
       for (int e = 0; e < LPT; ++e) {
         unsigned t = stab[e];
@@ -878,31 +541,6 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
         uint4 v = *reinterpret_cast<const uint4*>(&pre[e * 4]);
         if (!((vmask >> e) & 1u)) v = make_uint4(0, 0, 0, 0);
         s_xh[t & 8191u] = v;            // rounds past the tile's last slot write a spare slot
-      }
-    } else if (VEC && vec_ok) {
-#pragma unroll
-      for (int u = 0; u < T::UPT; ++u) {
-        const int idx = u * 256 + tq;
-        const int cb = idx / (T::ROWS_IN * T::NQ);
-        const int rem = idx - cb * (T::ROWS_IN * T::NQ);
-        const int r = rem / T::NQ, q = rem - r * T::NQ;
-        if (idx < T::NU) {
-#pragma unroll
-          for (int pp = 0; pp < 4; ++pp) {
-            const int cc = 4 * q + pp - T::SH;
-            if (cc >= 0 && cc < T::COLS_IN) put_slot(cb, r, cc, &pre[u * 32 + pp], 4);
-          }
-        }
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < T::SPT; ++e) {
-        const int idx = e * 256 + tq;
-        const int cb = idx / (T::ROWS_IN * T::COLS_IN);
-        const int rem = idx - cb * (T::ROWS_IN * T::COLS_IN);
-        const int r = rem / T::COLS_IN;
-        const int cc = rem - r * T::COLS_IN;
-        if (idx < T::NSLOT) put_slot(cb, r, cc, &pre[e * 8], 1);
       }
     }
   };
@@ -914,10 +552,8 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
   int tile = (int)((long)xcd * total / 8) + lb;
   if (tile >= t_end) return;
   fetch(tile);
-  if (SLOTS) {
 #pragma unroll
-    for (int e = 0; e < LPT; ++e) fetch_one(e);
-  }
+  for (int e = 0; e < LPT; ++e) fetch_one(e);
   commit();
   __syncthreads();
   const size_t plane_o = (size_t)a.Ho * a.Wo;
@@ -993,10 +629,10 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
         acc1[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[k], xh, acc1[s], 0, 0, 0);
         acc1[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[k], xl, acc1[s], 0, 0, 0);
       }
-      if (SLOTS && k < LPT && nxt < t_end) fetch_one(k);     // one staging copy of the next tile per K-step
+      if (k < LPT && nxt < t_end) fetch_one(k);     // one staging copy of the next tile per K-step
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (SLOTS && nxt < t_end) {
+    if (nxt < t_end) {
 #pragma unroll
       for (int e = T::NK; e < LPT; ++e) fetch_one(e);         // (only when a tile has more copies than K-steps)
     }
@@ -1078,7 +714,7 @@ struct Down0Tile {
   static constexpr int CSEG = TC / 32, SPW = TR * CSEG / 4;
 };
 
-template <int TC, bool OUTSLOT>
+template <int TC>
 __global__ __launch_bounds__(256) void k_down0_f16(const int8_t* __restrict__ in6, int H, int W,
                                                    const uint4* __restrict__ wfrag,   // [8][hi|lo][64]
                                                    const float* __restrict__ bias, float* __restrict__ out, int Ho,
@@ -1203,7 +839,7 @@ __global__ __launch_bounds__(256) void k_down0_f16(const int8_t* __restrict__ in
         const int seg = wave * T::SPW + s;
         const int y = ty * T::TR + seg / T::CSEG, x = tx * TC + (seg % T::CSEG) * 32 + j;
         if (y < Ho && x < Wo) {
-          if (OUTSLOT) {        // split-slot tensor for the next down-conv (see SlotIn)
+          {                     // split-slot tensor for the next down-conv (see SlotIn)
             char* o = reinterpret_cast<char*>(out);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -1219,15 +855,6 @@ __global__ __launch_bounds__(256) void k_down0_f16(const int8_t* __restrict__ in
               }
               *reinterpret_cast<half4*>(o + bh_) = hh;
               *reinterpret_cast<half4*>(o + bh_ + plane_o * 16) = hl;
-            }
-          } else {
-            float* o = out + (size_t)img * kC * plane_o + (size_t)y * Wo + x;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int co = (r & 3) + 8 * (r >> 2) + 4 * g;
-              float v = acc0[s][r] + acc1[s][r] * kSplitInv;
-              if (lrelu) v = v > 0.f ? v : v * kSlope;
-              o[(size_t)co * plane_o] = v;
             }
           }
         }
@@ -1400,150 +1027,6 @@ struct RefGeom {
   int tiles_x, tiles_y;
 };
 
-template <int DIL>
-struct RefTile {
-  static constexpr int TH = 8, TW = 64;
-  static constexpr int ROWS = TH + 2 * DIL, COLS = TW + 2 * DIL;
-  static constexpr int PLANE = ROWS * COLS;             // slots per channel block
-  static constexpr int HALF = 2 * PLANE;                // slots per phase (2 channel blocks)
-  static constexpr int NINST = (HALF + 63) / 64;        // DMA wave-instructions per phase
-  static constexpr int BUF = NINST * 64;                // slots per LDS buffer (padded)
-  static constexpr int LDS_BYTES = 2 * BUF * 16;
-};
-
-template <int DIL>
-__device__ __forceinline__ void ref_issue_dma(const uint4* __restrict__ in, uint4* lds_buf, const RefGeom& g,
-                                              int img, int y0, int x0, int kk, int wave, int lane) {
-  using T = RefTile<DIL>;
-  for (int i = wave; i < T::NINST; i += 4) {
-    int s = i * 64 + lane;
-    s = s < T::HALF ? s : T::HALF - 1;                   // tail lanes re-fetch the last slot into the pad
-    const int pc = s / T::PLANE;
-    const int rem = s - pc * T::PLANE;
-    const int r = rem / T::COLS;
-    const int c = rem - r * T::COLS;
-    const size_t slot = (((size_t)img * 4 + (2 * kk + pc)) * g.Hs + (y0 + r - DIL + kRefPad)) * g.Ws +
-                        (x0 + c - DIL + kRefPad);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(in + slot),
-                                     (__attribute__((address_space(3))) void*)(lds_buf + i * 64), 16, 0, 0);
-  }
-}
-
-template <int DIL, int KK>
-__device__ __forceinline__ void ref_compute(const uint4* lds_lane, const half8 (&wf)[18], f32x16 (&acc)[4]) {
-  using T = RefTile<DIL>;
-#pragma unroll
-  for (int tap = 0; tap < 9; ++tap) {
-    const int ky = tap / 3, kx = tap - ky * 3;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int off = ((s >> 1) + ky * DIL) * T::COLS + (s & 1) * 32 + kx * DIL;
-      const half8 xb = *reinterpret_cast<const half8*>(lds_lane + off);
-      acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[tap * 2 + KK], xb, acc[s], 0, 0, 0);
-    }
-  }
-}
-
-template <int DIL>
-__global__ __launch_bounds__(256, 2) void k_ref_conv_f16(const uint4* __restrict__ in, uint4* out,
-                                                         const uint4* res,                   // nullable (may alias out)
-                                                         const uint4* __restrict__ wfrag,    // [9][2][64] slots
-                                                         const float* __restrict__ bias, RefGeom g, int nimg,
-                                                         int lrelu) {
-  using T = RefTile<DIL>;
-  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int j = lane & 31, gh = lane >> 5;
-
-  // weights: 18 MFMA A-fragments, resident in registers
-  half8 wf[18];
-#pragma unroll
-  for (int i = 0; i < 18; ++i) {
-    const uint4 v = wfrag[i * 64 + lane];
-    wf[i] = *reinterpret_cast<const half8*>(&v);
-  }
-  float bv[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) bv[r] = bias[(r & 3) + 8 * (r >> 2) + 4 * gh];
-
-  // persistent tile loop; XCD x (= blockIdx % 8) walks a contiguous band of tiles
-  const int per_img = g.tiles_x * g.tiles_y;
-  const int total = per_img * nimg;
-  const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, nlb = gridDim.x >> 3;
-  const int t_begin = (int)((long)xcd * total / 8), t_end = (int)((long)(xcd + 1) * total / 8);
-
-  uint4* buf0 = lds;
-  uint4* buf1 = lds + T::BUF;
-  // this lane's read base inside a buffer: channel block gh, pixel j, first row of this wave
-  const int lane_off = gh * T::PLANE + (2 * wave) * T::COLS + j;
-
-  int t = t_begin + lb;
-  if (t >= t_end) return;
-  int img = t / per_img, rem = t - img * per_img;
-  int ty = rem / g.tiles_x, tx = rem - ty * g.tiles_x;
-  ref_issue_dma<DIL>(in, buf0, g, img, ty * T::TH, tx * T::TW, 0, wave, lane);
-  __syncthreads();
-
-  while (true) {
-    const int y0 = ty * T::TH, x0 = tx * T::TW;
-    ref_issue_dma<DIL>(in, buf1, g, img, y0, x0, 1, wave, lane);
-    f32x16 acc[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
-    ref_compute<DIL, 0>(buf0 + lane_off, wf, acc);
-    __syncthreads();                         // phase-1 data landed; everyone is done with buf0
-
-    const int tn = t + nlb;
-    int nimg_i = 0, nty = 0, ntx = 0;
-    const bool more = tn < t_end;
-    if (more) {
-      nimg_i = tn / per_img;
-      const int r2 = tn - nimg_i * per_img;
-      nty = r2 / g.tiles_x;
-      ntx = r2 - nty * g.tiles_x;
-      ref_issue_dma<DIL>(in, buf0, g, nimg_i, nty * T::TH, ntx * T::TW, 0, wave, lane);
-    }
-    ref_compute<DIL, 1>(buf1 + lane_off, wf, acc);
-
-    // epilogue: bias (+ residual) (+ LeakyReLU) -> fp16, 8-byte stores
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int y = y0 + 2 * wave + (s >> 1), x = x0 + (s & 1) * 32 + j;
-      if (y < g.H && x < g.W) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const size_t slot = (((size_t)img * 4 + q) * g.Hs + (y + kRefPad)) * g.Ws + (x + kRefPad);
-          float v[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc[s][4 * q + e] + bv[4 * q + e];
-          if (res) {
-            const half4 rv = *reinterpret_cast<const half4*>(reinterpret_cast<const char*>(res) + slot * 16 + gh * 8);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
-          }
-          half4 hv;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float u = v[e];
-            if (lrelu) u = u > 0.f ? u : u * kSlope;
-            hv[e] = (_Float16)u;
-          }
-          *reinterpret_cast<half4*>(reinterpret_cast<char*>(out) + slot * 16 + gh * 8) = hv;
-        }
-      }
-    }
-    __syncthreads();                         // next tile's phase-0 data landed; everyone is done with buf1
-    if (!more) break;
-    t = tn;
-    img = nimg_i;
-    ty = nty;
-    tx = ntx;
-  }
-}
-
 // ------------------------------------------------------------------------------------------
 // v2 of the tower kernel: same tile math, deeper memory pipeline.
 //   * ring of THREE phase buffers; the DMA group of phase g+2 is issued right after the barrier that
@@ -1594,27 +1077,6 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int DIL, int TW>
-__device__ __forceinline__ void ref2_issue_dma(const uint4* __restrict__ in, uint4* lds_buf, const RefGeom& g,
-                                               int img, int y0, int x0, int kk, int wave, int lane) {
-  using T = RefTile2<DIL, TW>;
-#pragma unroll
-  for (int k = 0; k < T::KW; ++k) {
-    int i = wave + 4 * k;
-    i = i < T::NINST ? i : T::NINST - 1;                 // constant op count per wave: repeat the last chunk
-    int s = i * 64 + lane;
-    s = s < T::HALF ? s : T::HALF - 1;
-    const int pc = s / T::PLANE;
-    const int rem = s - pc * T::PLANE;
-    const int r = rem / T::COLS;
-    const int c = rem - r * T::COLS;
-    const size_t slot = (((size_t)img * 4 + (2 * kk + pc)) * g.Hs + (y0 + r - DIL + kRefPad)) * g.Ws +
-                        (x0 + c - DIL + kRefPad);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(in + slot),
-                                     (__attribute__((address_space(3))) void*)(lds_buf + i * 64), 16, 0, 0);
-  }
-}
-
 template <int DIL, int TW, int KK, int TH = 8>
 __device__ __forceinline__ void ref2_compute(const uint4* lds_lane, const half8 (&wf)[18],
                                              f32x16 (&acc)[RefTile2<DIL, TW, TH>::SPW]) {
@@ -1631,8 +1093,8 @@ __device__ __forceinline__ void ref2_compute(const uint4* lds_lane, const half8 
   }
 }
 
-// DYN = true: tiles beyond the first two rounds are handed out by one device-scope counter per XCD band
-// (tile_ctr[16 * xcd], zeroed by the host before the launch) instead of the static stride.  When the
+// Tiles beyond the first two rounds are handed out by one device-scope counter per XCD band
+// (tile_ctr[16 * xcd], zeroed by the host before the launch) instead of a static stride.  When the
 // low-resolution branch runs on the other stream the hardware places the tower's workgroups unevenly (two on one
 // CU, none on a CU that is full of other kernels' waves); a static partition then waits for the slowest CU.
 // Wave 0 fetches tile ti+2 during tile ti: the returning atomic is issued right after the phase-g0 barrier,
@@ -1646,7 +1108,7 @@ __device__ __forceinline__ void ref2_compute(const uint4* lds_lane, const half8 
 // group in flight across the barrier does (dilation 4 went 76 -> 58 us per launch by the same move to two
 // workgroups per CU).  Schedule with NB = 2: group g+1 is issued after the barrier of phase g (its buffer was
 // read in phase g-1) and must be complete at the barrier of phase g+1.
-template <int DIL, int TW, bool RES, bool DYN, int TH = 8, int MINW = 2, int NB = 3>
+template <int DIL, int TW, bool RES, int TH = 8, int MINW = 2, int NB = 3>
 __global__ __launch_bounds__(256, MINW) void k_ref_conv_f16_v2(const uint4* __restrict__ in, uint4* out,
                                                             const uint4* res, const uint4* __restrict__ wfrag,
                                                             const float* __restrict__ bias, RefGeom g, int nimg,
@@ -1739,7 +1201,7 @@ __global__ __launch_bounds__(256, MINW) void k_ref_conv_f16_v2(const uint4* __re
   for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(bv[r]));
   wait_vmcnt<0>();
   int t_next = t0 + nlb;                                      // tile ti+1 (second round is static as well)
-  int t_next2 = t0 + 2 * nlb;                                 // tile ti+2 (static schedule; DYN overwrites it)
+  int t_next2 = t0 + 2 * nlb;                                 // tile ti+2: handed out by the queue from here on
   unsigned* tile_slot = reinterpret_cast<unsigned*>(lds + NB * T::BUF);  // not volatile: that would drain vmcnt
   unsigned* const my_ctr = tile_ctr + 16 * xcd;
 
@@ -1761,7 +1223,7 @@ __global__ __launch_bounds__(256, MINW) void k_ref_conv_f16_v2(const uint4* __re
     // read-write into the asm so that hipcc keeps it in one register and never copies it before the wait below.
     unsigned fetched;
     asm volatile("" : "=v"(fetched));
-    if (DYN && has_next && wave == 0) {                       // wave-uniform branch; lane 0 only inside the asm
+    if (has_next && wave == 0) {                              // wave-uniform branch; lane 0 only inside the asm
       unsigned one = 1;
       unsigned long long saved_exec;
       asm volatile(
@@ -1789,7 +1251,7 @@ __global__ __launch_bounds__(256, MINW) void k_ref_conv_f16_v2(const uint4* __re
     // ---- phase g0+1 (channels 16..31) ----
     if (NB == 3 && has_next) wait_vmcnt<T::KW>();             // younger than group g0+1: group g0+2
     else wait_vmcnt<0>();                                     // last phase of this block / two-buffer ring
-    if (DYN && has_next && wave == 0) {                       // the atomic is older than group g0+2: it has returned
+    if (has_next && wave == 0) {                              // the atomic is older than group g0+2: it has returned
       asm volatile("" : "+v"(fetched));
       // belt and braces: should a returning atomic ever be retired out of order with the DMA groups, the sentinel
       // is still there -> drain and read again (never taken in practice; costs one readfirstlane + compare per tile)
@@ -1803,10 +1265,8 @@ __global__ __launch_bounds__(256, MINW) void k_ref_conv_f16_v2(const uint4* __re
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     block_barrier();
-    if (DYN) {
-      if (has_next) t_next2 = t_begin + 2 * nlb + (int)__builtin_amdgcn_readfirstlane(tile_slot[ti & 1]);
-      else t_next2 = t_end;
-    }
+    if (has_next) t_next2 = t_begin + 2 * nlb + (int)__builtin_amdgcn_readfirstlane(tile_slot[ti & 1]);
+    else t_next2 = t_end;
 
     // residual: NSTORE 8-byte loads issued as inline asm BEFORE the next DMA group, so they are older
     // than it and the counted wait below (all but the newest KW ops) retires them without draining
@@ -1870,228 +1330,7 @@ __global__ __launch_bounds__(256, MINW) void k_ref_conv_f16_v2(const uint4* __re
     y0 = ny0;
     x0 = nx0;
     t_next = t_next2;
-    t_next2 = DYN ? t_end : t_next2 + nlb;
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// Fused residual block (dilation DIL, built for DIL = 1):  y = lrelu(x + conv2(lrelu(conv1(x) + b1)) + b2)
-// in ONE kernel: the intermediate activation t lives only in LDS, so a block costs one read of x and one
-// write of y (118 MB / pair at 1280x720) instead of 295 MB for two separate convolutions.
-//   output tile 8 x (64 - 2*DIL); t is needed on (8 + 2*DIL) rows x 64 columns (= whole 32-px MFMA
-//   segments), x on (8 + 4*DIL) x (64 + 2*DIL).  t outside the image is forced to 0 (conv2's zero padding).
-//   LDS: four x half-tiles (two per tile, full double buffering: the NEXT tile's x streams in by LDS-DMA
-//   during the whole current tile) + the fp16 t tile.  Both weight sets (36 MFMA A-fragments) and biases
-//   stay in registers: one workgroup per CU, one wave per SIMD, so each wave may use the whole 512-entry
-//   register file.  The residual x is re-read from the LDS x tile, not from HBM.
-//   y goes to a different tensor than x (neighbouring tiles still read x's halo).
-// vmcnt discipline as in v2: per tile every wave issues 2*KW DMA instructions and exactly 16 stores
-// (masked lanes store a zero into a pad slot that is zero anyway), so "everything but the last 16 ops"
-// at the top of a tile retires the tile's own x.
-// ------------------------------------------------------------------------------------------
-template <int DIL>
-struct FusedTile {
-  static constexpr int TH = 8, TWO = 64 - 2 * DIL;            // output tile
-  static constexpr int RT = TH + 2 * DIL, CT = 64;            // t region
-  static constexpr int RX = TH + 4 * DIL, CX = 64 + 2 * DIL;  // x region
-  static constexpr int PX = RX * CX, PT = RT * CT;            // slots per channel block
-  static constexpr int XHALF = 2 * PX;
-  static constexpr int NINST = (XHALF + 63) / 64;
-  static constexpr int KW = (NINST + 3) / 4;
-  static constexpr int XBUF = NINST * 64;
-  static constexpr int TBUF = 4 * PT + 64;                    // + slack: discarded lanes read past the last row
-  static constexpr int LDS_BYTES = (4 * XBUF + TBUF) * 16;
-  static constexpr int S1 = RT * 2 / 4;                       // stage-1 segments per wave
-  static constexpr int S2 = TH * 2 / 4;                       // stage-2 segments per wave
-  static constexpr int NSTORE = 4 * S2;
-  static_assert((RT * 2) % 4 == 0, "t rows must split over 4 waves");
-  static_assert(LDS_BYTES <= 160 * 1024, "fused block does not fit the LDS at this dilation");
-};
-
-template <int DIL>
-__global__ __launch_bounds__(256, 1) void k_ref_block_f16(const uint4* __restrict__ xin, uint4* __restrict__ yout,
-                                                          const uint4* __restrict__ wfrag1, const float* __restrict__ bias1,
-                                                          const uint4* __restrict__ wfrag2, const float* __restrict__ bias2,
-                                                          RefGeom g, int nimg, uint4* zero_slot) {
-  using T = FusedTile<DIL>;
-  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
-  uint4* xbuf = lds;                       // 4 half-tile buffers
-  uint4* tbuf = lds + 4 * T::XBUF;         // t tile [4 blocks][RT][CT]
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int j = lane & 31, gh = lane >> 5;
-
-  half8 w1[18], w2[18];
-  float b1[16], b2[16];
-#pragma unroll
-  for (int i = 0; i < 18; ++i) {
-    const uint4 a = wfrag1[i * 64 + lane], b = wfrag2[i * 64 + lane];
-    w1[i] = *reinterpret_cast<const half8*>(&a);
-    w2[i] = *reinterpret_cast<const half8*>(&b);
-  }
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int co = (r & 3) + 8 * (r >> 2) + 4 * gh;
-    b1[r] = bias1[co];
-    b2[r] = bias2[co];
-  }
-#pragma unroll
-  for (int i = 0; i < 18; ++i) {
-    asm volatile("" : "+v"(w1[i]));
-    asm volatile("" : "+v"(w2[i]));
-  }
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    asm volatile("" : "+v"(b1[r]));
-    asm volatile("" : "+v"(b2[r]));
-  }
-
-  const int per_img = g.tiles_x * g.tiles_y;
-  const int total = per_img * nimg;
-  const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, nlb = gridDim.x >> 3;
-  const int t_begin = (int)((long)xcd * total / 8), t_end = (int)((long)(xcd + 1) * total / 8);
-  const int t0 = t_begin + lb;
-  if (t0 >= t_end) return;
-  const int ntiles = (t_end - t0 + nlb - 1) / nlb;
-
-  auto tile_xy = [&](int ti, int& img, int& y0, int& x0) {
-    const int t = t0 + ti * nlb;
-    img = t / per_img;
-    const int rem = t - img * per_img;
-    const int ty = rem / g.tiles_x;
-    y0 = ty * T::TH;
-    x0 = (rem - ty * g.tiles_x) * T::TWO;
-  };
-  // both x half-tiles of tile ti into buffers 2*(ti&1), 2*(ti&1)+1
-  auto issue_x = [&](int ti) {
-    int img, y0, x0;
-    tile_xy(ti, img, y0, x0);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      uint4* dst = xbuf + (2 * (ti & 1) + kk) * T::XBUF;
-#pragma unroll
-      for (int k = 0; k < T::KW; ++k) {
-        int i = wave + 4 * k;
-        i = i < T::NINST ? i : T::NINST - 1;
-        int s = i * 64 + lane;
-        s = s < T::XHALF ? s : T::XHALF - 1;
-        const int pc = s / T::PX;
-        const int rem = s - pc * T::PX;
-        const int r = rem / T::CX;
-        const int c = rem - r * T::CX;
-        const size_t slot = (((size_t)img * 4 + (2 * kk + pc)) * g.Hs + (y0 + r - 2 * DIL + kRefPad)) * g.Ws +
-                            (x0 + c - 2 * DIL + kRefPad);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xin + slot),
-                                         (__attribute__((address_space(3))) void*)(dst + i * 64), 16, 0, 0);
-      }
-    }
-  };
-
-  wait_vmcnt<0>();
-  issue_x(0);
-
-  for (int ti = 0; ti < ntiles; ++ti) {
-    int img, y0, x0;
-    tile_xy(ti, img, y0, x0);
-    if (ti == 0) wait_vmcnt<0>();
-    else wait_vmcnt<T::NSTORE>();                 // younger than this tile's x: the previous tile's stores
-    block_barrier();                 // x tile visible; everyone is done with the previous tile
-    if (ti + 1 < ntiles) issue_x(ti + 1);
-    const uint4* xa = xbuf + (2 * (ti & 1)) * T::XBUF;
-    const uint4* xb = xa + T::XBUF;
-
-    // ---- stage 1: t = lrelu(conv1(x) + b1) on RT x 64, S1 segments per wave ----
-    {
-      f32x16 acc[T::S1];
-#pragma unroll
-      for (int s = 0; s < T::S1; ++s)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
-      const int seg0 = wave * T::S1;
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const uint4* base = (kk ? xb : xa) + gh * T::PX + j;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-          const int ky = tap / 3, kx = tap - ky * 3;
-#pragma unroll
-          for (int s = 0; s < T::S1; ++s) {
-            const int seg = seg0 + s;                                   // runtime (wave) + constant
-            const int off = ((seg >> 1) + ky * DIL) * T::CX + (seg & 1) * 32 + kx * DIL;
-            const half8 v = *reinterpret_cast<const half8*>(base + off);
-            acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[tap * 2 + kk], v, acc[s], 0, 0, 0);
-          }
-        }
-      }
-      // t -> LDS (fp16); positions outside the image are conv2's zero padding
-#pragma unroll
-      for (int s = 0; s < T::S1; ++s) {
-        const int seg = seg0 + s;
-        const int tr = seg >> 1, tc = (seg & 1) * 32 + j;
-        const int gy = y0 - DIL + tr, gx = x0 - DIL + tc;
-        const bool inside = (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          half4 hv;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float u = acc[s][4 * q + e] + b1[4 * q + e];
-            u = u > 0.f ? u : u * kSlope;
-            hv[e] = inside ? (_Float16)u : (_Float16)0.f;
-          }
-          *reinterpret_cast<half4*>(reinterpret_cast<char*>(tbuf + q * T::PT + tr * T::CT + tc) + gh * 8) = hv;
-        }
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    block_barrier();                 // t tile complete
-
-    // ---- stage 2: y = lrelu(x + conv2(t) + b2) on 8 x TWO, S2 segments per wave ----
-    {
-      f32x16 acc[T::S2];
-#pragma unroll
-      for (int s = 0; s < T::S2; ++s)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
-      const int seg0 = wave * T::S2;
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const uint4* base = tbuf + (2 * kk + gh) * T::PT + j;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-          const int ky = tap / 3, kx = tap - ky * 3;
-#pragma unroll
-          for (int s = 0; s < T::S2; ++s) {
-            const int seg = seg0 + s;
-            const int off = ((seg >> 1) + ky * DIL) * T::CT + (seg & 1) * 32 + kx * DIL;
-            const half8 v = *reinterpret_cast<const half8*>(base + off);
-            acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2[tap * 2 + kk], v, acc[s], 0, 0, 0);
-          }
-        }
-      }
-#pragma unroll
-      for (int s = 0; s < T::S2; ++s) {
-        const int seg = seg0 + s;
-        const int orow = seg >> 1, ocol = (seg & 1) * 32 + j;
-        const int y = y0 + orow, x = x0 + ocol;
-        const bool ok = ocol < T::TWO && y < g.H && x < g.W;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          // residual: x at the output pixel = x tile position (orow + 2*DIL, ocol + 2*DIL), channel block q
-          const uint4* xs = (q < 2 ? xa : xb) + (q & 1) * T::PX + (orow + 2 * DIL) * T::CX + (ocol + 2 * DIL);
-          const half4 rv = *reinterpret_cast<const half4*>(reinterpret_cast<const char*>(xs) + gh * 8);
-          half4 hv;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float u = acc[s][4 * q + e] + b2[4 * q + e] + (float)rv[e];
-            u = u > 0.f ? u : u * kSlope;
-            hv[e] = ok ? (_Float16)u : (_Float16)0.f;
-          }
-          uint4* dst = ok ? yout + ((((size_t)img * 4 + q) * g.Hs + (y + kRefPad)) * g.Ws + (x + kRefPad)) : zero_slot;
-          *reinterpret_cast<half4*>(reinterpret_cast<char*>(dst) + gh * 8) = hv;
-        }
-      }
-    }
+    t_next2 = t_end;
   }
 }
 
@@ -2348,283 +1587,6 @@ __global__ __launch_bounds__(256, 2) void k_ref_block_f16_h(const uint4* __restr
     img = nimg_;
     y0 = ny0;
     x0 = nx0;
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// Wave-specialised fused residual block (second generation).  One 512-thread workgroup per CU:
-//   waves 0-3 ("stage 1"): conv1 of tile k   — x half-tiles stream through a 3-deep LDS-DMA ring (as v2),
-//                          t = lrelu(conv1(x)+b1) is written to LDS buffer T[k & 1];
-//   waves 4-7 ("stage 2"): conv2 of tile k-1 — reads T[(k-1) & 1], adds bias + residual x (8-byte global
-//                          loads, L2-resident: the same lines were just streamed in), LeakyReLU, stores y.
-// Every SIMD therefore holds one wave of each role: while one wave is in its epilogue / address math the
-// other one feeds the matrix pipe — this is what the single-role fused kernel above lacks.  Both roles
-// meet at two s_barriers per tile (one per 16-channel phase of stage 1); T is double buffered so stage 2
-// of tile k-1 and stage 1 of tile k never touch the same buffer.  HBM traffic per block: one read of x (plus
-// halo, L2-absorbed) and one write of y.
-// vmcnt bookkeeping is per wave, so each role counts only its own VMEM ops: stage 1 issues KW LDS-DMA
-// instructions per phase and nothing else; stage 2 issues 16 asm residual loads and 16 stores per tile.
-// ------------------------------------------------------------------------------------------
-template <int DIL>
-struct FusedWsTile {
-  // TH = 6: 8 t rows = 16 segments = 4 per stage-1 wave (64 accumulator registers) and 12 output segments
-  // = 3 per stage-2 wave; with TH = 8 (5 + 4 segments) the kernel needs > 256 registers per wave and spills.
-  static constexpr int TH = 6, TWO = 64 - 2 * DIL;
-  static constexpr int RT = TH + 2 * DIL, CT = 64;
-  static constexpr int RX = TH + 4 * DIL, CX = 64 + 2 * DIL;
-  static constexpr int PX = RX * CX, PT = RT * CT;
-  static constexpr int XHALF = 2 * PX;
-  static constexpr int NINST = (XHALF + 63) / 64;
-  static constexpr int KW = (NINST + 3) / 4;                  // per stage-1 wave per phase
-  static constexpr int XBUF = NINST * 64;
-  static constexpr int TBUF = 4 * PT + 64;
-  static constexpr int LDS_BYTES = (3 * XBUF + 2 * TBUF) * 16 + 256;   // + 64 bias floats
-  static constexpr int S1 = RT * 2 / 4, S2 = TH * 2 / 4;
-  static constexpr int NSTORE = 4 * S2;
-  static_assert((RT * 2) % 4 == 0 && (TH * 2) % 4 == 0, "segments must split over the 4 waves of each role");
-  static_assert(LDS_BYTES <= 160 * 1024, "does not fit the LDS at this dilation");
-};
-
-
-template <int DIL>
-__global__ __launch_bounds__(512, 2) void k_ref_block_f16_ws(const uint4* __restrict__ xin, uint4* __restrict__ yout,
-                                                             const uint4* __restrict__ wfrag1, const float* __restrict__ bias1,
-                                                             const uint4* __restrict__ wfrag2, const float* __restrict__ bias2,
-                                                             RefGeom g, int nimg, uint4* zero_slot) {
-  using T = FusedWsTile<DIL>;
-  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
-  uint4* xring = lds;                        // 3 half-tile buffers
-  uint4* tbase = lds + 3 * T::XBUF;          // T[0], T[1]
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool s1 = wave8 < 4;                 // wave-uniform role
-  const int wave = wave8 & 3;                // index inside the role
-  const int j_ = lane & 31, gh_ = lane >> 5;
-
-  // role-specific weights / bias live in the SAME registers
-  const uint4* wsrc = s1 ? wfrag1 : wfrag2;
-  const float* bsrc = s1 ? bias1 : bias2;
-  half8 wf[18];
-#pragma unroll
-  for (int i = 0; i < 18; ++i) {
-    const uint4 v = wsrc[i * 64 + lane];
-    wf[i] = *reinterpret_cast<const half8*>(&v);
-  }
-  // biases go to LDS (read back as float4 in the epilogues): 16 fewer live registers per wave
-  float* bl = reinterpret_cast<float*>(tbase + 2 * T::TBUF);
-  if (tid < 32) bl[tid] = bias1[tid];
-  else if (tid < 64) bl[tid] = bias2[tid - 32];
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  block_barrier();
-  const float* bmine0 = bl + (s1 ? 0 : 32);
-  (void)bsrc;
-#pragma unroll
-  for (int i = 0; i < 18; ++i) asm volatile("" : "+v"(wf[i]));
-
-  const int per_img = g.tiles_x * g.tiles_y;
-  const int total = per_img * nimg;
-  const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, nlb = gridDim.x >> 3;
-  const int t_begin = (int)((long)xcd * total / 8), t_end = (int)((long)(xcd + 1) * total / 8);
-  const int t0 = t_begin + lb;
-  if (t0 >= t_end) return;
-  const int ntiles = (t_end - t0 + nlb - 1) / nlb;
-  const int G = 2 * ntiles;                  // stage-1 phases
-
-  auto tile_xy = [&](int ti, int& img, int& y0, int& x0) {
-    const int t = t0 + ti * nlb;
-    img = t / per_img;
-    const int rem = t - img * per_img;
-    const int ty = rem / g.tiles_x;
-    y0 = ty * T::TH;
-    x0 = (rem - ty * g.tiles_x) * T::TWO;
-  };
-  auto issue = [&](int gp) {                 // stage-1 waves only: x half-tile of phase gp -> ring slot gp % 3
-    int img, y0, x0;
-    tile_xy(gp >> 1, img, y0, x0);
-    const int kk = gp & 1;
-    uint4* dst = xring + (gp % 3) * T::XBUF;
-    int lq = lane;
-    asm volatile("" : "+v"(lq));             // keep the per-lane slot decomposition out of the loop-invariant set
-#pragma unroll
-    for (int k = 0; k < T::KW; ++k) {
-      int i = wave + 4 * k;
-      i = i < T::NINST ? i : T::NINST - 1;
-      int s = i * 64 + lq;
-      s = s < T::XHALF ? s : T::XHALF - 1;
-      const int pc = s / T::PX;
-      const int rem = s - pc * T::PX;
-      const int r = rem / T::CX;
-      const int c = rem - r * T::CX;
-      const size_t slot = (((size_t)img * 4 + (2 * kk + pc)) * g.Hs + (y0 + r - 2 * DIL + kRefPad)) * g.Ws +
-                          (x0 + c - 2 * DIL + kRefPad);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xin + slot),
-                                       (__attribute__((address_space(3))) void*)(dst + i * 64), 16, 0, 0);
-    }
-  };
-
-  wait_vmcnt<0>();
-  if (s1) {
-    issue(0);
-    issue(1);
-  }
-
-  f32x16 acc[T::S1];                         // stage 2 uses the first S2 of them
-  uint2 rres[T::NSTORE];
-  for (int k = 0; k <= ntiles; ++k) {
-    const bool a1 = s1 && k < ntiles;        // stage 1 works on tile k
-    const bool a2 = !s1 && k >= 1;           // stage 2 works on tile k-1
-    int j = j_, gh = gh_;                    // opaque copies: per-lane addresses are recomputed per tile instead of
-    asm volatile("" : "+v"(j), "+v"(gh));    // being hoisted out of the loop (that spilled ~25 VGPRs to scratch)
-    const int g0 = 2 * k;
-    int img = 0, y0 = 0, x0 = 0;
-    if (a1) tile_xy(k, img, y0, x0);
-    if (a2) tile_xy(k - 1, img, y0, x0);
-    uint4* tw = tbase + (k & 1) * T::TBUF;               // stage 1 writes
-    const uint4* tr = tbase + ((k - 1) & 1) * T::TBUF;   // stage 2 reads
-
-    // ================= phase A (input channels 0..15) =================
-    if (a1) {
-      if (g0 + 1 < G) wait_vmcnt<T::KW>(); else wait_vmcnt<0>();     // group g0 landed (g0+1 may fly)
-    }
-    block_barrier();
-    if (a1) {
-      if (g0 + 2 < G) issue(g0 + 2);
-#pragma unroll
-      for (int s = 0; s < T::S1; ++s)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
-      const uint4* base = xring + (g0 % 3) * T::XBUF + gh * T::PX + j;
-      const int seg0 = wave * T::S1;
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int ky = tap / 3, kx = tap - ky * 3;
-        if (kx == 0 && ky > 0) __builtin_amdgcn_sched_barrier(0);   // bound the B fragments in flight (VGPRs)
-#pragma unroll
-        for (int s = 0; s < T::S1; ++s) {
-          const int seg = seg0 + s;
-          const int off = ((seg >> 1) + ky * DIL) * T::CX + (seg & 1) * 32 + kx * DIL;
-          const half8 v = *reinterpret_cast<const half8*>(base + off);
-          acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[tap * 2 + 0], v, acc[s], 0, 0, 0);
-        }
-      }
-    } else if (a2) {
-      // residual x of tile k-1: 16 eight-byte loads, hidden from hipcc (they must not drain anything)
-      const int seg0 = wave * T::S2;
-#pragma unroll
-      for (int s = 0; s < T::S2; ++s) {
-        const int seg = seg0 + s;
-        const int y = y0 + (seg >> 1), x = x0 + (seg & 1) * 32 + j;
-        const size_t slot0 = ((size_t)img * 4 * g.Hs + (y + kRefPad)) * g.Ws + (x + kRefPad);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const char* rp = reinterpret_cast<const char*>(xin) + (slot0 + (size_t)q * g.Hs * g.Ws) * 16 + gh * 8;
-          asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rres[s * 4 + q]) : "v"(rp) : "memory");
-        }
-      }
-#pragma unroll
-      for (int s = 0; s < T::S2; ++s)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
-      const uint4* base = tr + gh * T::PT + j;
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int ky = tap / 3, kx = tap - ky * 3;
-        if (kx == 0 && ky > 0) __builtin_amdgcn_sched_barrier(0);   // bound the B fragments in flight (VGPRs)
-#pragma unroll
-        for (int s = 0; s < T::S2; ++s) {
-          const int seg = seg0 + s;
-          const int off = ((seg >> 1) + ky * DIL) * T::CT + (seg & 1) * 32 + kx * DIL;
-          const half8 v = *reinterpret_cast<const half8*>(base + off);
-          acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[tap * 2 + 0], v, acc[s], 0, 0, 0);
-        }
-      }
-    }
-
-    // ================= phase B (input channels 16..31) =================
-    if (a1) {
-      if (g0 + 2 < G) wait_vmcnt<T::KW>(); else wait_vmcnt<0>();     // group g0+1 landed (g0+2 may fly)
-    }
-    block_barrier();
-    if (a1) {
-      if (g0 + 3 < G) issue(g0 + 3);
-      const uint4* base = xring + ((g0 + 1) % 3) * T::XBUF + gh * T::PX + j;
-      const int seg0 = wave * T::S1;
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int ky = tap / 3, kx = tap - ky * 3;
-        if (kx == 0 && ky > 0) __builtin_amdgcn_sched_barrier(0);   // bound the B fragments in flight (VGPRs)
-#pragma unroll
-        for (int s = 0; s < T::S1; ++s) {
-          const int seg = seg0 + s;
-          const int off = ((seg >> 1) + ky * DIL) * T::CX + (seg & 1) * 32 + kx * DIL;
-          const half8 v = *reinterpret_cast<const half8*>(base + off);
-          acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[tap * 2 + 1], v, acc[s], 0, 0, 0);
-        }
-      }
-      // t -> T[k & 1]; positions outside the image are conv2's zero padding
-#pragma unroll
-      for (int s = 0; s < T::S1; ++s) {
-        const int seg = seg0 + s;
-        const int trow = seg >> 1, tcol = (seg & 1) * 32 + j;
-        const int gy = y0 - DIL + trow, gx = x0 - DIL + tcol;
-        const bool inside = (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 b4 = *reinterpret_cast<const float4*>(bmine0 + 4 * gh + 8 * q);
-          const float bq[4] = {b4.x, b4.y, b4.z, b4.w};
-          half4 hv;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float u = acc[s][4 * q + e] + bq[e];
-            u = fmaxf(u, u * kSlope);
-            hv[e] = inside ? (_Float16)u : (_Float16)0.f;
-          }
-          *reinterpret_cast<half4*>(reinterpret_cast<char*>(tw + q * T::PT + trow * T::CT + tcol) + gh * 8) = hv;
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // T[k&1] complete before the next barrier
-    } else if (a2) {
-      const int seg0 = wave * T::S2;
-      const uint4* base = tr + (2 + gh) * T::PT + j;
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int ky = tap / 3, kx = tap - ky * 3;
-        if (kx == 0 && ky > 0) __builtin_amdgcn_sched_barrier(0);   // bound the B fragments in flight (VGPRs)
-#pragma unroll
-        for (int s = 0; s < T::S2; ++s) {
-          const int seg = seg0 + s;
-          const int off = ((seg >> 1) + ky * DIL) * T::CT + (seg & 1) * 32 + kx * DIL;
-          const half8 v = *reinterpret_cast<const half8*>(base + off);
-          acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[tap * 2 + 1], v, acc[s], 0, 0, 0);
-        }
-      }
-      wait_vmcnt<0>();                                        // residual loads (and older stores) retired
-#pragma unroll
-      for (int i = 0; i < T::NSTORE; ++i) asm volatile("" : "+v"(rres[i]));
-#pragma unroll
-      for (int s = 0; s < T::S2; ++s) {
-        const int seg = seg0 + s;
-        const int orow = seg >> 1, ocol = (seg & 1) * 32 + j;
-        const int y = y0 + orow, x = x0 + ocol;
-        const bool ok = ocol < T::TWO && y < g.H && x < g.W;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const uint2 rw = rres[s * 4 + q];
-          const half4 rv = *reinterpret_cast<const half4*>(&rw);
-          const float4 b4 = *reinterpret_cast<const float4*>(bmine0 + 4 * gh + 8 * q);
-          const float bq[4] = {b4.x, b4.y, b4.z, b4.w};
-          half4 hv;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float u = acc[s][4 * q + e] + bq[e] + (float)rv[e];
-            u = fmaxf(u, u * kSlope);
-            hv[e] = ok ? (_Float16)u : (_Float16)0.f;
-          }
-          uint4* dst = ok ? yout + ((((size_t)img * 4 + q) * g.Hs + (y + kRefPad)) * g.Ws + (x + kRefPad)) : zero_slot;
-          *reinterpret_cast<half4*>(reinterpret_cast<char*>(dst) + gh * 8) = hv;
-        }
-      }
-    }
   }
 }
 

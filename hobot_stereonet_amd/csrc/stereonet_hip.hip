@@ -114,10 +114,7 @@ struct sn_handle {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_tow_join[kMaxTowerStreams] = {}, ev_piece[kMaxPieceEvents] = {};
   bool overlap = true;
   int tower_streams = kMaxTowerStreams;
-  bool low_slots = false;    // low-resolution branch on split-slot activations (lowres_slots)
-  int ovl_cap = 0;           // cap on tower workgroups per CU while the low-res branch runs beside it (SN_OVL_CAP; 0 = none:
-                             // the weights-stationary low-res kernels cannot share a CU with a tower workgroup anyway)
-  bool ref_dyn = true;       // dynamic tile queue in the fp16 tower (SN_REF_DYN=0: static stride)
+  bool fuse_dil1 = false;    // SN_FUSE=3: dilation-1 residual blocks through the fused kernel (opt-in)
   bool use_graphs = true;    // hipGraph replay for the async single-pair path (SN_NO_GRAPH disables)
   ConvLayer down[kNDown], fres[kNFeatRes][2], fout, agg[kNAgg], rin, rres[kNRefRes][2];
   Down0F16 down0, refin;
@@ -300,51 +297,24 @@ hipError_t launch_refin_f16(hipStream_t st, const Down0F16& L, const float* bias
   return hipGetLastError();
 }
 
-template <int TC, bool OUTSLOT = false>
 hipError_t launch_down0_f16(hipStream_t st, const Down0F16& L, const float* bias, const int8_t* in6, int H, int W,
                             int nimg, int Ho, int Wo, float* out, int num_cu) {
+  constexpr int TC = 32;
   using T = Down0Tile<TC>;
   const int tiles_x = (Wo + TC - 1) / TC, tiles_y = (Ho + T::TR - 1) / T::TR;
   const int total = tiles_x * tiles_y * nimg;
-  int blocks = (TC == 64 ? 1 : 2) * num_cu;      // register budget: one (TC = 64) or two workgroups per CU
+  int blocks = 2 * num_cu;                        // register budget: two workgroups per CU
   if (blocks > total) blocks = total;
   const int al4 = (W % 4 == 0) && (reinterpret_cast<uintptr_t>(in6) % 4 == 0);
-  hipLaunchKernelGGL((k_down0_f16<TC, OUTSLOT>), dim3(blocks), dim3(256), T::LDS_BYTES, st, in6, H, W, L.wfrag, bias, out, Ho, Wo,
+  hipLaunchKernelGGL((k_down0_f16<TC>), dim3(blocks), dim3(256), T::LDS_BYTES, st, in6, H, W, L.wfrag, bias, out, Ho, Wo,
                      tiles_x, tiles_y, nimg, 0, al4);
-  return hipGetLastError();
-}
-
-template <int KS, int STRIDE, int DIL, int TR, int TC, class Loader>
-hipError_t launch_conv_x3g(hipStream_t st, const ConvLayer& L, const Loader& ld, int nimg, int Ho, int Wo, float* out,
-                           const float* res, bool lrelu) {
-  ConvArgs a{};
-  a.wpk = reinterpret_cast<const float*>(L.wx3);
-  a.bias = L.bias;
-  a.out = out;
-  a.res = res;
-  a.nimg = nimg;
-  a.cin_pad = L.cin_pad;
-  a.Ho = Ho;
-  a.Wo = Wo;
-  a.dil = DIL;
-  a.pad = (KS / 2) * DIL;
-  a.lrelu = lrelu ? 1 : 0;
-  a.tiles_x = (Wo + TC - 1) / TC;
-  a.tiles_y = (Ho + TR - 1) / TR;
-  constexpr int rows_in = (TR - 1) * STRIDE + (KS - 1) * DIL + 1;
-  constexpr int cols_in = (TC - 1) * STRIDE + (KS - 1) * DIL + 1;
-  constexpr int pitch = STRIDE == 1 ? cols_in : 2 * ((cols_in + 1) / 2);
-  constexpr size_t lds = ((size_t)(KS * KS <= 9 ? KS * KS * 2 * 64 : 0) + 4 * rows_in * pitch) * 16;
-  static_assert(lds <= 64 * 1024, "x3 conv tile too large for the default LDS limit");
-  hipLaunchKernelGGL((k_conv_c32_x3<KS, STRIDE, DIL, TR, TC, Loader>), dim3(a.tiles_x * a.tiles_y * nimg), dim3(256),
-                     lds, st, a, ld);
   return hipGetLastError();
 }
 
 template <class K>
 hipError_t ensure_lds_attr(K kern, int bytes);
 
-// second generation (weights-stationary, K split across wave pairs): persistent grid of MINB workgroups per CU
+// weights-stationary split-operand conv on split-slot tensors: persistent grid of MINB workgroups per CU
 template <int KS, int STRIDE, int VCH, int TR, int TC, int SEGW, int MINB, bool OUTSLOT, class Loader, bool HASRES = false>
 hipError_t launch_conv_x3s(hipStream_t st, const ConvLayer& L, const Loader& ld, int nimg, int Ho, int Wo, float* out,
                            const float* res, bool lrelu, int num_cu) {
@@ -379,30 +349,6 @@ hipError_t launch_conv_x3s(hipStream_t st, const ConvLayer& L, const Loader& ld,
   return hipGetLastError();
 }
 
-inline bool use_x3s() {
-  static const bool on = getenv("SN_X3_V1") == nullptr;
-  return on;
-}
-inline int x3s_cus() {                 // CU count for the persistent grids (the launchers have no handle)
-  static const int n = [] {
-    int dev = 0;
-    hipDeviceProp_t p;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 256;
-    return p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
-  }();
-  return n;
-}
-
-template <int DIL, int TR, int TC, class Loader>
-hipError_t launch_conv_x3(hipStream_t st, const ConvLayer& L, const Loader& ld, int nimg, int Ho, int Wo, float* out,
-                          const float* res, bool lrelu) {
-  if (DIL == 1 && use_x3s()) {
-    if (L.cin_pad == 96) return launch_conv_x3s<3, 1, 96, 8, 16, 16, 1, false, Loader>(st, L, ld, nimg, Ho, Wo, out, res, lrelu, x3s_cus());
-    if (L.cin_pad == 32) return launch_conv_x3s<3, 1, 32, 8, 16, 16, 1, false, Loader>(st, L, ld, nimg, Ho, Wo, out, res, lrelu, x3s_cus());
-  }
-  return launch_conv_x3g<3, 1, DIL, TR, TC, Loader>(st, L, ld, nimg, Ho, Wo, out, res, lrelu);
-}
-
 int upload_head(sn_handle* h, const HostLayer& l, HeadLayer* out) {   // [1][32][taps] as-is
   HIP_TRY(h, dalloc(&out->w, (size_t)kC * l.taps));
   HIP_TRY(h, hipMemcpy(out->w, l.w, (size_t)kC * l.taps * sizeof(float), hipMemcpyHostToDevice));
@@ -429,15 +375,11 @@ hipError_t ensure_lds_attr(K kern, int bytes) {
 }
 
 // ---- convolution launcher ------------------------------------------------------------------------
-template <int KS, int STRIDE, int DIL, int CH, int TR, int TC, class Loader, int OUTF = 0, bool PF = true, int MINW = 1>
+template <int KS, int STRIDE, int DIL, int CH, int TR, int TC, class Loader, bool PF = true, int MINW = 1>
 hipError_t launch_conv(hipStream_t st, const ConvLayer& L, const Loader& ld, int nimg, int Ho, int Wo,
-                       float* out, const float* res, bool lrelu, int f16_Hs = 0, int f16_Ws = 0,
-                       size_t f16_lo_off = 0) {
+                       float* out, const float* res, bool lrelu) {
   constexpr int dil = DIL;
   ConvArgs a{};
-  a.f16_Hs = f16_Hs;
-  a.f16_Ws = f16_Ws;
-  a.f16_lo_off = f16_lo_off;
   a.wpk = L.wpk;
   a.bias = L.bias;
   a.out = out;
@@ -455,7 +397,7 @@ hipError_t launch_conv(hipStream_t st, const ConvLayer& L, const Loader& ld, int
   const int cols_in = (TC - 1) * STRIDE + (KS - 1) * dil + 1;
   const int pitch = STRIDE == 1 ? cols_in : 2 * ((cols_in + 1) / 2);
   const size_t lds = ((size_t)CH * KS * KS * 32 + (size_t)CH * rows_in * pitch) * sizeof(float);
-  auto kern = k_conv_c32_mfma<KS, STRIDE, DIL, CH, TR, TC, Loader, OUTF, PF, MINW>;
+  auto kern = k_conv_c32_mfma<KS, STRIDE, DIL, CH, TR, TC, Loader, PF, MINW>;
   if (lds > 64 * 1024) {
     hipError_t e = ensure_lds_attr(kern, (int)lds);
     if (e != hipSuccess) return e;
@@ -471,7 +413,6 @@ hipError_t conv3x3_d(hipStream_t st, const ConvLayer& L, const float* in, int ni
                      const float* res, bool lrelu) {
   LoadF32 ld{in, kC, H, W};
   // (chunk sizes 8/16 and tile heights 4/8 measured equal within noise on the 45x80 low-resolution maps)
-  if (DIL == 1 && L.wx3) return launch_conv_x3<1, 8, 32>(st, L, ld, nimg, H, W, out, res, lrelu);   // fp16 modes
   if (H * W <= 64 * 128) return launch_conv<3, 1, DIL, 8, 4, 32>(st, L, ld, nimg, H, W, out, res, lrelu);
   if (DIL >= 4) return launch_conv<3, 1, DIL, 4, 16, 64>(st, L, ld, nimg, H, W, out, res, lrelu);
   return launch_conv<3, 1, DIL, 8, 8, 64>(st, L, ld, nimg, H, W, out, res, lrelu);
@@ -492,8 +433,6 @@ hipError_t conv5x5s2(hipStream_t st, const ConvLayer& L, const float* in, int ni
                      float* out) {
   LoadF32 ld{in, kC, Hin, Win};
   const int Ho = Hin / 2, Wo = Win / 2;
-  if (L.wx3 && use_x3s()) return launch_conv_x3s<5, 2, 32, 4, 32, 32, 1, false, LoadF32>(st, L, ld, nimg, Ho, Wo, out, nullptr, false, x3s_cus());
-  if (L.wx3) return launch_conv_x3g<5, 2, 1, 4, 32>(st, L, ld, nimg, Ho, Wo, out, nullptr, false);   // fp16 modes
   if (Ho * Wo <= 64 * 128) return launch_conv<5, 2, 1, 4, 4, 32>(st, L, ld, nimg, Ho, Wo, out, nullptr, false);
   return launch_conv<5, 2, 1, 4, 8, 64>(st, L, ld, nimg, Ho, Wo, out, nullptr, false);
 }
@@ -583,84 +522,35 @@ hipError_t ref_conv_f16x3(hipStream_t st, const RefLayerF16& L, const RefGeom& g
   }
 }
 
-template <int DIL>
-hipError_t launch_ref_f16(hipStream_t st, const RefLayerF16& L, const RefGeom& g, int num_cu, const uint4* in,
-                          uint4* out, const uint4* res, int nimg, bool lrelu) {
-  using T = RefTile<DIL>;
-  auto kern = k_ref_conv_f16<DIL>;
-  static bool attr_done = false;
-  if (!attr_done && T::LDS_BYTES > 64 * 1024) {
-    hipError_t e = ensure_lds_attr(kern, T::LDS_BYTES);
-    if (e != hipSuccess) return e;
-    attr_done = true;
-  }
-  const int total = g.tiles_x * g.tiles_y * nimg;
-  const int per_cu = T::LDS_BYTES * 2 <= 160 * 1024 ? 2 : 1;
-  int blocks = num_cu * per_cu;
-  if (blocks > total) blocks = total;
-  blocks = (blocks + 7) / 8 * 8;
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), T::LDS_BYTES, st, in, out, res, L.wfrag, L.bias, g, nimg,
-                     lrelu ? 1 : 0);
-  return hipGetLastError();
-}
-
-template <int DIL, int TW, int TH = 8, int MINW = 2, int NB = 3>
+template <int DIL, int TW, int NB = 3>
 hipError_t launch_ref_f16_v2(hipStream_t st, const RefLayerF16& L, const RefGeom& g, int num_cu, const uint4* in,
-                             uint4* out, const uint4* res, int nimg, bool lrelu, int per_cu_cap, unsigned* tile_ctr) {
-  using T = RefTile2<DIL, TW, TH, NB>;
-  // tile_ctr != nullptr: dynamic tile queue (8 zeroed counters, 64 B apart); nullptr: static stride
-  auto kern = tile_ctr ? (res ? k_ref_conv_f16_v2<DIL, TW, true, true, TH, MINW, NB> : k_ref_conv_f16_v2<DIL, TW, false, true, TH, MINW, NB>)
-                       : (res ? k_ref_conv_f16_v2<DIL, TW, true, false, TH, MINW, NB> : k_ref_conv_f16_v2<DIL, TW, false, false, TH, MINW, NB>);
+                             uint4* out, const uint4* res, int nimg, bool lrelu, unsigned* tile_ctr) {
+  using T = RefTile2<DIL, TW, 8, NB>;
+  // tile_ctr: the launch's tile queue (8 zeroed counters, 64 B apart)
+  auto kern = res ? k_ref_conv_f16_v2<DIL, TW, true, 8, 2, NB> : k_ref_conv_f16_v2<DIL, TW, false, 8, 2, NB>;
+  if (tile_ctr == nullptr) return hipErrorInvalidValue;
   if (T::LDS_BYTES > 64 * 1024) {
     hipError_t e = ensure_lds_attr(kern, T::LDS_BYTES);
     if (e != hipSuccess) return e;
   }
+  static_assert(2 * T::LDS_BYTES <= 160 * 1024, "two tower workgroups per CU");
   RefGeom gt = g;                      // tile grid of this variant (the buffer geometry is for 8x64 tiles)
   gt.tiles_x = (g.W + TW - 1) / TW;
-  gt.tiles_y = (g.H + TH - 1) / TH;
+  gt.tiles_y = (g.H + 7) / 8;
   const int total = gt.tiles_x * gt.tiles_y * nimg;
-  // per_cu_cap = 1 while the low-resolution branch of the next piece runs on the other stream: one tower
-  // workgroup per CU leaves half of the register file / LDS for those kernels to co-reside (+2-3 %)
-  int per_cu = (160 * 1024) / T::LDS_BYTES;
-  if (per_cu > MINW) per_cu = MINW;
-  if (per_cu < 1) per_cu = 1;
-  if (per_cu_cap > 0 && per_cu_cap < per_cu) per_cu = per_cu_cap;
-  // persistent grid: 8 XCD bands; pick the block count per band so that every block walks the same number
-  // of tiles (e.g. 225 tiles per band -> 57 blocks x 4 tiles, not 64 blocks x 3.5)
+  // persistent grid: 8 XCD bands, two workgroups per CU, every slot filled (the queue balances the bands)
   const int band = (total + 7) / 8;
-  int cap = num_cu * per_cu / 8;
+  int cap = num_cu * 2 / 8;
   if (cap < 1) cap = 1;
-  const int rounds = (band + cap - 1) / cap;
-  int nlb = (band + rounds - 1) / rounds;
-  if (tile_ctr) nlb = cap < band ? cap : band;     // dynamic queue: fill every slot, the counter balances
-  const int blocks = nlb * 8;
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), T::LDS_BYTES, st, in, out, res, L.wfrag, L.bias, gt, nimg,
+  const int nlb = cap < band ? cap : band;
+  hipLaunchKernelGGL(kern, dim3(nlb * 8), dim3(256), T::LDS_BYTES, st, in, out, res, L.wfrag, L.bias, gt, nimg,
                      lrelu ? 1 : 0, tile_ctr);
   return hipGetLastError();
 }
 
-// fused residual block (conv1 + conv2 + residual in one launch); x and y must be different tensors
-template <int DIL>
-hipError_t launch_ref_block_f16(hipStream_t st, const RefLayerF16& L1, const RefLayerF16& L2, const RefGeom& g,
-                                int num_cu, const uint4* x, uint4* y, int nimg) {
-  using T = FusedTile<DIL>;
-  auto kern = k_ref_block_f16<DIL>;
-  hipError_t e = ensure_lds_attr(kern, T::LDS_BYTES);
-  if (e != hipSuccess) return e;
-  RefGeom gt = g;
-  gt.tiles_x = (g.W + T::TWO - 1) / T::TWO;
-  const int total = gt.tiles_x * gt.tiles_y * nimg;
-  const int band = (total + 7) / 8;
-  int cap = num_cu / 8;                    // one workgroup per CU
-  if (cap < 1) cap = 1;
-  const int rounds = (band + cap - 1) / cap;
-  const int nlb = (band + rounds - 1) / rounds;
-  hipLaunchKernelGGL(kern, dim3(nlb * 8), dim3(256), T::LDS_BYTES, st, x, y, L1.wfrag, L1.bias, L2.wfrag, L2.bias, gt,
-                     nimg, y /* slot 0 = top-left pad corner, zero by construction */);
-  return hipGetLastError();
-}
-
-// third form: 77 KB of LDS, two workgroups per CU (SN_FUSE=3)
+// Fused residual block (conv1 + conv2 + residual in one launch, t only in LDS); x and y must be different tensors.
+// 77 KB of LDS, two workgroups per CU.  Opt-in (SN_FUSE=3): 40 % of the HBM traffic of the two launches it replaces
+// at the same run time.
 hipError_t launch_ref_block_f16_h(hipStream_t st, const RefLayerF16& L1, const RefLayerF16& L2, const RefGeom& g,
                                   int num_cu, const uint4* x, uint4* y, int nimg) {
   using T = FusedHTile;
@@ -681,108 +571,36 @@ hipError_t launch_ref_block_f16_h(hipStream_t st, const RefLayerF16& L1, const R
   return hipGetLastError();
 }
 
-template <int DIL>
-hipError_t launch_ref_block_f16_ws(hipStream_t st, const RefLayerF16& L1, const RefLayerF16& L2, const RefGeom& g,
-                                   int num_cu, const uint4* x, uint4* y, int nimg) {
-  using T = FusedWsTile<DIL>;
-  auto kern = k_ref_block_f16_ws<DIL>;
-  hipError_t e = ensure_lds_attr(kern, T::LDS_BYTES);
-  if (e != hipSuccess) return e;
-  RefGeom gt = g;
-  gt.tiles_x = (g.W + T::TWO - 1) / T::TWO;
-  gt.tiles_y = (g.H + T::TH - 1) / T::TH;
-  const int total = gt.tiles_x * gt.tiles_y * nimg;
-  const int band = (total + 7) / 8;
-  int cap = num_cu / 8;
-  if (cap < 1) cap = 1;
-  const int rounds = (band + cap - 1) / cap;
-  const int nlb = (band + rounds - 1) / rounds;
-  hipLaunchKernelGGL(kern, dim3(nlb * 8), dim3(512), T::LDS_BYTES, st, x, y, L1.wfrag, L1.bias, L2.wfrag, L2.bias, gt,
-                     nimg, y);
-  return hipGetLastError();
-}
-
-int fuse_mode() {   // 0 = two v2 launches, 1 = single-role fused kernel, 2 = wave-specialised fused kernel
-  static const int m = getenv("SN_FUSE") ? atoi(getenv("SN_FUSE")) : 0;
-  return getenv("SN_REF_V1") ? 0 : m;
-}
-
-// Opt-in (SN_FUSE=1): correct and parity-tested, but with one wave per SIMD its per-tile VALU work is exposed
-// and it is currently ~12 % slower than the two v2 launches it replaces ("fused block").
-int g_force_fused = 0;   // the parity hook sets this to exercise a fused kernel regardless of the env
-int use_fused_block(int dil) {
-  if (dil != 1) return 0;
-  return g_force_fused ? g_force_fused : fuse_mode();
-}
-
-// One residual block of the fp16 tower on `*cur` (input and, on return, output); `*oth` is scratch.
-bool use_ref_v1() {
-  static const bool v = getenv("SN_REF_V1") != nullptr;   // A/B switch for the first-generation tower kernel
-  return v;
-}
-
-inline int narrow_tiles() {            // SN_REF_NARROW=3|4: 8x32 tiles with 3 / 4 workgroups per CU for the dilation-1 layers
-  static const int v = getenv("SN_REF_NARROW") ? atoi(getenv("SN_REF_NARROW")) : 0;
-  return v;
-}
-inline bool wide_d4() {                // SN_REF_D4_TW64: 8x64 tiles for dilation 4 (110 KB ring: one workgroup per CU)
-  static const bool on = getenv("SN_REF_D4_TW64") != nullptr;
-  return on;
-}
-inline bool ring3_d8() {               // SN_REF_D8_RING3: three ring buffers for dilation 8 (110 KB: one workgroup per CU)
-  static const bool on = getenv("SN_REF_D8_RING3") != nullptr;
-  return on;
-}
-inline bool tall_tiles() {
-  static const bool on = getenv("SN_REF_TALL") != nullptr;
+bool fuse_env() {        // SN_FUSE=3: the dilation-1 blocks of the pipeline run through the fused kernel
+  static const bool on = getenv("SN_FUSE") != nullptr && atoi(getenv("SN_FUSE")) == 3;
   return on;
 }
 
 hipError_t ref_conv_f16(hipStream_t st, const RefLayerF16& L, const RefGeom& g, int num_cu, int dil, const uint4* in,
-                        uint4* out, const uint4* res, int nimg, bool lrelu, int per_cu_cap = 0,
-                        unsigned* tile_ctr = nullptr) {
-  if (!use_ref_v1()) {
-    switch (dil) {
-      case 1:
-        if (narrow_tiles() == 4) return launch_ref_f16_v2<1, 32, 8, 4>(st, L, g, num_cu, in, out, res, nimg, lrelu, per_cu_cap, tile_ctr);
-        if (narrow_tiles() == 3) return launch_ref_f16_v2<1, 32, 8, 3>(st, L, g, num_cu, in, out, res, nimg, lrelu, per_cu_cap, tile_ctr);
-        return launch_ref_f16_v2<1, 64>(st, L, g, num_cu, in, out, res, nimg, lrelu, per_cu_cap, tile_ctr);
-      case 2: return launch_ref_f16_v2<2, 64>(st, L, g, num_cu, in, out, res, nimg, lrelu, per_cu_cap, tile_ctr);
-      case 4:
-        if (tall_tiles()) return launch_ref_f16_v2<4, 32, 16>(st, L, g, num_cu, in, out, res, nimg, lrelu, per_cu_cap, tile_ctr);
-        if (wide_d4()) return launch_ref_f16_v2<4, 64>(st, L, g, num_cu, in, out, res, nimg, lrelu, per_cu_cap, tile_ctr);
-        return launch_ref_f16_v2<4, 32>(st, L, g, num_cu, in, out, res, nimg, lrelu, per_cu_cap, tile_ctr);   // 61 KB: two per CU
-      case 8:
-        if (tall_tiles()) return launch_ref_f16_v2<8, 32, 16>(st, L, g, num_cu, in, out, res, nimg, lrelu, per_cu_cap, tile_ctr);
-        if (ring3_d8()) return launch_ref_f16_v2<8, 32>(st, L, g, num_cu, in, out, res, nimg, lrelu, per_cu_cap, tile_ctr);
-        return launch_ref_f16_v2<8, 32, 8, 2, 2>(st, L, g, num_cu, in, out, res, nimg, lrelu, per_cu_cap, tile_ctr);   // 74 KB: two per CU
-      default: return hipErrorInvalidValue;
-    }
-  }
+                        uint4* out, const uint4* res, int nimg, bool lrelu, unsigned* tile_ctr) {
   switch (dil) {
-    case 1: return launch_ref_f16<1>(st, L, g, num_cu, in, out, res, nimg, lrelu);
-    case 2: return launch_ref_f16<2>(st, L, g, num_cu, in, out, res, nimg, lrelu);
-    case 4: return launch_ref_f16<4>(st, L, g, num_cu, in, out, res, nimg, lrelu);
-    case 8: return launch_ref_f16<8>(st, L, g, num_cu, in, out, res, nimg, lrelu);
+    case 1: return launch_ref_f16_v2<1, 64>(st, L, g, num_cu, in, out, res, nimg, lrelu, tile_ctr);
+    case 2: return launch_ref_f16_v2<2, 64>(st, L, g, num_cu, in, out, res, nimg, lrelu, tile_ctr);
+    case 4: return launch_ref_f16_v2<4, 32>(st, L, g, num_cu, in, out, res, nimg, lrelu, tile_ctr);      // 61 KB ring
+    case 8: return launch_ref_f16_v2<8, 32, 2>(st, L, g, num_cu, in, out, res, nimg, lrelu, tile_ctr);   // 74 KB, two buffers
     default: return hipErrorInvalidValue;
   }
 }
 
+// One residual block of the fp16 tower on `*cur` (input and, on return, output); `*oth` is scratch.  tile_ctr: the
+// block's two tile queues (kTileCtrStride apart).
 hipError_t ref_block_f16(hipStream_t st, const RefLayerF16& L1, const RefLayerF16& L2, const RefGeom& g, int num_cu,
-                         int dil, uint4** cur, uint4** oth, int nimg, int per_cu_cap = 0, unsigned* tile_ctr = nullptr) {
-  if (const int fm = use_fused_block(dil)) {
-    hipError_t e = fm == 3   ? launch_ref_block_f16_h(st, L1, L2, g, num_cu, *cur, *oth, nimg)
-                   : fm == 2 ? launch_ref_block_f16_ws<1>(st, L1, L2, g, num_cu, *cur, *oth, nimg)
-                             : launch_ref_block_f16<1>(st, L1, L2, g, num_cu, *cur, *oth, nimg);
+                         int dil, uint4** cur, uint4** oth, int nimg, unsigned* tile_ctr, bool fused) {
+  if (fused && dil == 1) {
+    hipError_t e = launch_ref_block_f16_h(st, L1, L2, g, num_cu, *cur, *oth, nimg);
     uint4* t = *cur;
     *cur = *oth;
     *oth = t;
     return e;
   }
-  hipError_t e = ref_conv_f16(st, L1, g, num_cu, dil, *cur, *oth, nullptr, nimg, true, per_cu_cap, tile_ctr);
+  hipError_t e = ref_conv_f16(st, L1, g, num_cu, dil, *cur, *oth, nullptr, nimg, true, tile_ctr);
   if (e != hipSuccess) return e;
-  return ref_conv_f16(st, L2, g, num_cu, dil, *oth, *cur, *cur, nimg, true, per_cu_cap,   // in-place residual
-                      tile_ctr ? tile_ctr + kTileCtrStride : nullptr);
+  return ref_conv_f16(st, L2, g, num_cu, dil, *oth, *cur, *cur, nimg, true, tile_ctr + kTileCtrStride);   // in-place residual
 }
 
 // ---- workspace -----------------------------------------------------------------------------------
@@ -854,7 +672,7 @@ int lowres_slots(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, con
   const int8_t* in = in6 + (size_t)p0 * 6 * HW;
   const int ncu = h->num_cu, ni = 2 * m;
   auto U4 = [](float* p) { return reinterpret_cast<const uint4*>(p); };
-  HIP_TRY(h, (launch_down0_f16<32, true>(st, h->down0, h->down[0].bias, in, h->H, h->W, ni, Hp / 2, Wp / 2, ws.down[0], ncu)));
+  HIP_TRY(h, launch_down0_f16(st, h->down0, h->down[0].bias, in, h->H, h->W, ni, Hp / 2, Wp / 2, ws.down[0], ncu));
   {
     float* src[3] = {ws.down[0], ws.down[1], ws.down[2]};
     float* dst[3] = {ws.down[1], ws.down[2], ws.low[0]};
@@ -905,18 +723,13 @@ int lowres(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, const int
   const int Hp = h->Hp, Wp = h->Wp, hl = h->hl, wl = h->wl, Dl = h->Dl;
   const size_t HW = (size_t)h->H * h->W;
   const int8_t* in = in6 + (size_t)p0 * 6 * HW;
-  if (h->low_slots) return lowres_slots(h, ws, st, p0, m, in6, want_cost, prof);
+  if (h->precision != SN_PREC_FP32) return lowres_slots(h, ws, st, p0, m, in6, want_cost, prof);
+  // SN_PREC_FP32: every layer on the exact-fp32 MFMA, fp32 NCHW activations
   // --- Siamese feature tower: images = 2m (left, right interleaved), shared weights ---
   {
     LoadI8Eye ld{in, h->H, h->W};
     const int Ho = Hp / 2, Wo = Wp / 2;
-    if (h->down0.wfrag) {
-      static const bool tc64 = getenv("SN_DOWN0_TC64") != nullptr;     // 8 x 64 tiles: one workgroup per CU
-      if (!tc64)
-        HIP_TRY(h, launch_down0_f16<32>(st, h->down0, h->down[0].bias, in, h->H, h->W, 2 * m, Ho, Wo, ws.down[0], h->num_cu));
-      else
-        HIP_TRY(h, launch_down0_f16<64>(st, h->down0, h->down[0].bias, in, h->H, h->W, 2 * m, Ho, Wo, ws.down[0], h->num_cu));
-    } else if (Ho * Wo <= 64 * 128)
+    if (Ho * Wo <= 64 * 128)
       HIP_TRY(h, (launch_conv<5, 2, 1, 4, 4, 32>(st, h->down[0], ld, 2 * m, Ho, Wo, ws.down[0], nullptr, false)));
     else
       HIP_TRY(h, (launch_conv<5, 2, 1, 4, 8, 64>(st, h->down[0], ld, 2 * m, Ho, Wo, ws.down[0], nullptr, false)));
@@ -935,16 +748,10 @@ int lowres(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, const int
 
   // --- cost volume (fused into the first 3-D conv's loader) + 3-D aggregation + soft-argmin ---
   LoadCostVol ld{ws.feat, Dl, hl, wl};
-  if (h->agg[0].wx3)
-    HIP_TRY(h, (launch_conv_x3<1, 8, 32>(st, h->agg[0], ld, m * Dl, hl, wl, ws.vol[0], nullptr, true)));
-  else
-    HIP_TRY(h, (launch_conv<3, 1, 1, 8, 4, 32>(st, h->agg[0], ld, m * Dl, hl, wl, ws.vol[0], nullptr, true)));
+  HIP_TRY(h, (launch_conv<3, 1, 1, 8, 4, 32>(st, h->agg[0], ld, m * Dl, hl, wl, ws.vol[0], nullptr, true)));
   for (int i = 1; i < kNAgg; ++i) {
     LoadVol3D lv{ws.vol[(i - 1) & 1], Dl, hl, wl};
-    if (h->agg[i].wx3)
-      HIP_TRY(h, (launch_conv_x3<1, 8, 32>(st, h->agg[i], lv, m * Dl, hl, wl, ws.vol[i & 1], nullptr, true)));
-    else
-      HIP_TRY(h, (launch_conv<3, 1, 1, 8, 4, 32>(st, h->agg[i], lv, m * Dl, hl, wl, ws.vol[i & 1], nullptr, true)));
+    HIP_TRY(h, (launch_conv<3, 1, 1, 8, 4, 32>(st, h->agg[i], lv, m * Dl, hl, wl, ws.vol[i & 1], nullptr, true)));
   }
   const float* v = ws.vol[(kNAgg - 1) & 1];
   const int npix = m * hl * wl;
@@ -1001,32 +808,17 @@ int refine_chunk(sn_handle* h, Workspace& ws, hipStream_t st, int sidx, int ordi
     const RefGeom& g = h->rg;
     const bool x3 = h->precision == SN_PREC_F16X3;
     const size_t lo_slots = ref16_slots(g, ws.rb) + kRefSlack;       // hi tensor -> lo tensor (F16X3)
-    if (h->refin.wfrag) {
-      HIP_TRY(h, launch_refin_f16(st, h->refin, h->rin.bias, ws.disp_low + (size_t)q0 * hl * wl, in6 + (size_t)q0 * 6 * HW,
-                                  hl, wl, h->H, h->W, 1.0f / (float)h->D, g, c, rx, x3, lo_slots * 16, ncu));
-    } else if (x3) {
-      if (Hp * Wp <= 64 * 128)
-        HIP_TRY(h, (launch_conv<3, 1, 1, 4, 4, 32, LoadRefineIn, 2>(st, h->rin, ld, c, Hp, Wp, reinterpret_cast<float*>(rx),
-                                                                  nullptr, true, g.Hs, g.Ws, lo_slots * 16)));
-      else
-        HIP_TRY(h, (launch_conv<3, 1, 1, 4, 8, 64, LoadRefineIn, 2>(st, h->rin, ld, c, Hp, Wp, reinterpret_cast<float*>(rx),
-                                                                  nullptr, true, g.Hs, g.Ws, lo_slots * 16)));
-    } else if (Hp * Wp <= 64 * 128)
-      HIP_TRY(h, (launch_conv<3, 1, 1, 4, 4, 32, LoadRefineIn, 1>(st, h->rin, ld, c, Hp, Wp, reinterpret_cast<float*>(rx),
-                                                                nullptr, true, g.Hs, g.Ws)));
-    else
-      HIP_TRY(h, (launch_conv<3, 1, 1, 4, 8, 64, LoadRefineIn, 1>(st, h->rin, ld, c, Hp, Wp, reinterpret_cast<float*>(rx),
-                                                                nullptr, true, g.Hs, g.Ws)));
+    HIP_TRY(h, launch_refin_f16(st, h->refin, h->rin.bias, ws.disp_low + (size_t)q0 * hl * wl, in6 + (size_t)q0 * 6 * HW,
+                                hl, wl, h->H, h->W, 1.0f / (float)h->D, g, c, rx, x3, lo_slots * 16, ncu));
     if (pe) HIP_TRY(h, hipEventRecord(h->ev[4], st));
-    const bool dyn = !x3 && h->ref_dyn && ws.tile_ctr != nullptr;
-    unsigned* const chunk_ctr = dyn ? ws.tile_ctr + (size_t)ordinal * (kTileCtrBytes / sizeof(unsigned)) : nullptr;
+    unsigned* const chunk_ctr = ws.tile_ctr + (size_t)ordinal * (kTileCtrBytes / sizeof(unsigned));
     for (int i = 0; i < kNRefRes; ++i) {
       if (x3) {
         HIP_TRY(h, ref_conv_f16x3(st, h->rres16[i][0], g, ncu, kRefDil[i], rx, rt, nullptr, lo_slots, c, true));
         HIP_TRY(h, ref_conv_f16x3(st, h->rres16[i][1], g, ncu, kRefDil[i], rt, rx, rx, lo_slots, c, true));
       } else {
-        HIP_TRY(h, ref_block_f16(st, h->rres16[i][0], h->rres16[i][1], g, ncu, kRefDil[i], &rx, &rt, c, h->ovl_cap,
-                                 dyn ? chunk_ctr + 2 * i * kTileCtrStride : nullptr));
+        HIP_TRY(h, ref_block_f16(st, h->rres16[i][0], h->rres16[i][1], g, ncu, kRefDil[i], &rx, &rt, c,
+                                 chunk_ctr + 2 * i * kTileCtrStride, h->fuse_dil1));
       }
     }
     if (pe) HIP_TRY(h, hipEventRecord(h->ev[5], st));
@@ -1057,7 +849,7 @@ int forward(sn_handle* h, Workspace& ws, hipStream_t st, int n, const int8_t* in
   const bool prof = h->profiling && (&ws == &h->ws);
   const bool multi = !prof && (&ws == &h->ws) && h->overlap && n > ws.rb;
   int rc;
-  if (ws.tile_ctr && h->ref_dyn) HIP_TRY(h, hipMemsetAsync(ws.tile_ctr, 0, kTileCtrBytes * ws.n_chunks, st));
+  if (ws.tile_ctr) HIP_TRY(h, hipMemsetAsync(ws.tile_ctr, 0, kTileCtrBytes * ws.n_chunks, st));
   if (!multi) {
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[0], st));
     for (int p0 = 0; p0 < n; p0 += ws.pb) {
@@ -1288,21 +1080,15 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(SN_ERR_DEVICE);
   h->overlap = getenv("SN_NO_OVERLAP") == nullptr;
   h->use_graphs = getenv("SN_NO_GRAPH") == nullptr;
-  h->low_slots = h->precision != SN_PREC_FP32 && getenv("SN_LOW_FP32") == nullptr && getenv("SN_DOWN_FP32") == nullptr &&
-                 getenv("SN_DOWN0_FP32") == nullptr && getenv("SN_X3_V1") == nullptr && getenv("SN_LOW_NCHW") == nullptr;
-  {
-    const char* e = getenv("SN_REF_DYN");     // dynamic tile queue of the fp16 tower (default on)
-    h->ref_dyn = e ? atoi(e) != 0 : true;
-    if (const char* c = getenv("SN_OVL_CAP")) h->ovl_cap = atoi(c);
-  }
+  h->fuse_dil1 = fuse_env();
 
   BlobWalker bw{blob.data()};
-  const bool low_x3 = h->precision != SN_PREC_FP32 && getenv("SN_LOW_FP32") == nullptr;
+  const bool low_x3 = h->precision != SN_PREC_FP32;     // fp16 modes: low-resolution layers on split fp16 operands
   for (int i = 0; i < kNDown; ++i) {
     const HostLayer hl_ = bw.next(kC, i == 0 ? 3 : kC, 25);
     if ((rc = upload_conv2d(h, hl_, 4, &h->down[i]))) return fail(rc);
-    if (low_x3 && i == 0 && getenv("SN_DOWN0_FP32") == nullptr && (rc = upload_down0_f16(h, hl_, &h->down0))) return fail(rc);
-    if (low_x3 && i > 0 && getenv("SN_DOWN_FP32") == nullptr &&
+    if (low_x3 && i == 0 && (rc = upload_down0_f16(h, hl_, &h->down0))) return fail(rc);
+    if (low_x3 && i > 0 &&
         (rc = upload_x3(h, kC, [&](int co, int c, int tap) { return hl_.w[((size_t)co * kC + c) * 25 + tap]; },
                         &h->down[i], 25)))
       return fail(rc);
@@ -1331,7 +1117,7 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
   {
     const HostLayer hl_ = bw.next(kC, 4, 9);
     if ((rc = upload_conv2d(h, hl_, 4, &h->rin))) return fail(rc);
-    if (h->precision != SN_PREC_FP32 && getenv("SN_REFIN_FP32") == nullptr && (rc = upload_refin_f16(h, hl_, &h->refin)))
+    if (h->precision != SN_PREC_FP32 && (rc = upload_refin_f16(h, hl_, &h->refin)))
       return fail(rc);
   }
   for (int i = 0; i < kNRefRes; ++i)
@@ -1790,9 +1576,8 @@ int sn_dbg_conv2d(sn_handle* h, const float* in, int cin, int h_px, int w, const
   if (stride == 2 && ((h_px & 1) || (w & 1))) return SN_ERR_ARG;
   const bool x3 = (lrelu & 2) != 0, slots = (lrelu & 4) != 0;
   lrelu &= 1;
-  if (x3 && !(cin == kC && dil == 1)) return SN_ERR_ARG;
+  if (x3 != slots || (x3 && !(cin == kC && dil == 1))) return SN_ERR_ARG;     // the split-operand kernel reads slots
   if (slots) {          // split-slot tensors in and out through the weights-stationary kernel (fp16 modes' low-res path)
-    if (!x3) return SN_ERR_ARG;
     ConvLayer Ls;
     HostLayer hls{wt, bias, kC, cin, taps};
     if ((rc = upload_conv2d(h, hls, 8, &Ls))) return rc;
@@ -1827,9 +1612,6 @@ int sn_dbg_conv2d(sn_handle* h, const float* in, int cin, int h_px, int w, const
   ConvLayer L;
   HostLayer hl{wt, bias, kC, cin, taps};
   if ((rc = upload_conv2d(h, hl, (k == 5 || cin <= 4) ? 4 : 8, &L))) return rc;
-  if (x3 && (rc = upload_x3(h, kC, [&](int co, int c, int tap) { return wt[((size_t)co * kC + c) * taps + tap]; }, &L,
-                            taps)))
-    return rc;
   float *din = nullptr, *dout = nullptr;
   const size_t nin = (size_t)cin * h_px * w, nout = (size_t)kC * Ho * Wo;
   HIP_TRY(h, dalloc(&din, nin));
@@ -1843,10 +1625,7 @@ int sn_dbg_conv2d(sn_handle* h, const float* in, int cin, int h_px, int w, const
   hipStream_t st = h->stream;
   LoadF32 ld{din, cin, h_px, w};
   hipError_t e;
-  if (k == 5 && x3) {
-    e = use_x3s() ? launch_conv_x3s<5, 2, 32, 4, 32, 32, 1, false, LoadF32>(st, L, ld, 1, Ho, Wo, dout, dres, lrelu != 0, h->num_cu)
-                  : launch_conv_x3g<5, 2, 1, 4, 32>(st, L, ld, 1, Ho, Wo, dout, dres, lrelu != 0);
-  } else if (k == 5) {
+  if (k == 5) {
     e = (Ho * Wo <= 64 * 128) ? launch_conv<5, 2, 1, 4, 4, 32>(st, L, ld, 1, Ho, Wo, dout, dres, lrelu != 0)
                               : launch_conv<5, 2, 1, 4, 8, 64>(st, L, ld, 1, Ho, Wo, dout, dres, lrelu != 0);
   } else if (cin <= 4) {
@@ -1869,7 +1648,7 @@ int sn_dbg_conv2d(sn_handle* h, const float* in, int cin, int h_px, int w, const
 
 int sn_dbg_down0(sn_handle* h, const int8_t* in6, int h_px, int w, const float* wt, const float* bias, int tc,
                  float* out) {
-  if (!h || !in6 || !wt || !bias || !out || h_px <= 0 || w <= 0 || (tc != 32 && tc != 64)) return SN_ERR_ARG;
+  if (!h || !in6 || !wt || !bias || !out || h_px <= 0 || w <= 0 || tc != 32) return SN_ERR_ARG;
   int rc = check_device(h);
   if (rc) return rc;
   const int Hp = (h_px + 15) / 16 * 16, Wp = (w + 15) / 16 * 16, Ho = Hp / 2, Wo = Wp / 2;
@@ -1878,16 +1657,17 @@ int sn_dbg_down0(sn_handle* h, const int8_t* in6, int h_px, int w, const float* 
   if ((rc = upload_down0_f16(h, hl, &L))) return rc;
   int8_t* din = nullptr;
   float *dout = nullptr, *dbias = nullptr;
-  const size_t nin = (size_t)6 * h_px * w, nout = (size_t)2 * kC * Ho * Wo;
+  const size_t nin = (size_t)6 * h_px * w, nout = (size_t)2 * kC * Ho * Wo;     // split slots: same bytes as fp32
   HIP_TRY(h, dalloc(&din, nin));
   HIP_TRY(h, dalloc(&dout, nout));
   HIP_TRY(h, dalloc(&dbias, kC));
   HIP_TRY(h, hipMemcpy(din, in6, nin, hipMemcpyHostToDevice));
   HIP_TRY(h, hipMemcpy(dbias, bias, kC * 4, hipMemcpyHostToDevice));
-  HIP_TRY(h, tc == 32 ? launch_down0_f16<32>(h->stream, L, dbias, din, h_px, w, 2, Ho, Wo, dout, h->num_cu)
-                      : launch_down0_f16<64>(h->stream, L, dbias, din, h_px, w, 2, Ho, Wo, dout, h->num_cu));
+  HIP_TRY(h, launch_down0_f16(h->stream, L, dbias, din, h_px, w, 2, Ho, Wo, dout, h->num_cu));   // the pipeline's kernel
   HIP_TRY(h, hipStreamSynchronize(h->stream));
-  HIP_TRY(h, hipMemcpy(out, dout, nout * 4, hipMemcpyDeviceToHost));
+  std::vector<_Float16> hs(nout * 2);
+  HIP_TRY(h, hipMemcpy(hs.data(), dout, nout * 4, hipMemcpyDeviceToHost));
+  host_from_slots(hs, 2, Ho, Wo, out);
   hipFree(din);
   hipFree(dout);
   hipFree(dbias);
@@ -1955,7 +1735,7 @@ int sn_dbg_conv3d(sn_handle* h, const float* in, int d, int h_px, int w, const f
   if (rc) return rc;
   const bool x3 = (lrelu & 2) != 0, slots = (lrelu & 4) != 0;
   lrelu &= 1;
-  if (slots && !x3) return SN_ERR_ARG;
+  if (slots != x3) return SN_ERR_ARG;        // the split-operand kernel reads split-slot volumes
   ConvLayer L;
   HostLayer hl{wt, bias, kC, kC, 27};
   if ((rc = upload_conv3d(h, hl, &L))) return rc;
@@ -1984,8 +1764,7 @@ int sn_dbg_conv3d(sn_handle* h, const float* in, int d, int h_px, int w, const f
   } else {
   HIP_TRY(h, hipMemcpy(din, tmp.data(), n * 4, hipMemcpyHostToDevice));
   LoadVol3D lv{din, d, h_px, w};
-  if (x3) HIP_TRY(h, (launch_conv_x3<1, 8, 32>(h->stream, L, lv, d, h_px, w, dout, nullptr, lrelu != 0)));
-  else HIP_TRY(h, (launch_conv<3, 1, 1, 8, 4, 32>(h->stream, L, lv, d, h_px, w, dout, nullptr, lrelu != 0)));
+  HIP_TRY(h, (launch_conv<3, 1, 1, 8, 4, 32>(h->stream, L, lv, d, h_px, w, dout, nullptr, lrelu != 0)));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   HIP_TRY(h, hipMemcpy(tmp.data(), dout, n * 4, hipMemcpyDeviceToHost));
   }
@@ -2033,9 +1812,13 @@ int sn_dbg_ref_conv_f16(sn_handle* h, const float* in, int h_px, int w, const fl
   } else {
     HIP_TRY(h, hipMemset(dout, 0, slots * 16));
   }
-  unsigned* ctr = h->ref_dyn ? h->ws.tile_ctr : nullptr;
-  if (ctr) HIP_TRY(h, hipMemsetAsync(ctr, 0, kTileCtrBytes, h->stream));
-  HIP_TRY(h, ref_conv_f16(h->stream, L, g, h->num_cu, dil, din, dout, dres, 1, lrelu != 0, 0, ctr));
+  unsigned* ctr = h->ws.tile_ctr;
+  if (!ctr) {
+    set_err(h, "sn_dbg_ref_conv_f16 needs an engine created in an fp16 mode");
+    return SN_ERR_ARG;
+  }
+  HIP_TRY(h, hipMemsetAsync(ctr, 0, kTileCtrBytes, h->stream));
+  HIP_TRY(h, ref_conv_f16(h->stream, L, g, h->num_cu, dil, din, dout, dres, 1, lrelu != 0, ctr));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   std::vector<_Float16> hout(slots * 8);
   HIP_TRY(h, hipMemcpy(hout.data(), dout, slots * 16, hipMemcpyDeviceToHost));
@@ -2129,7 +1912,7 @@ int sn_dbg_ref_conv_f16x3(sn_handle* h, const float* in, int h_px, int w, const 
 int sn_dbg_ref_block_f16(sn_handle* h, const float* in, int h_px, int w, const float* w1, const float* b1,
                          const float* w2, const float* b2, int dil, float* out) {
   if (!h || !in || !w1 || !b1 || !w2 || !b2 || !out || h_px <= 0 || w <= 0) return SN_ERR_ARG;
-  const int fmode = dil >> 8;          // tests: bits 8.. select the fused variant (1 single-role, 2 wave-specialised)
+  const bool fused = (dil >> 8) != 0;  // tests: bit 8 selects the fused kernel (dilation 1)
   dil &= 0xff;
   if (dil != 1 && dil != 2 && dil != 4 && dil != 8) return SN_ERR_ARG;
   int rc = check_device(h);
@@ -2151,10 +1934,13 @@ int sn_dbg_ref_block_f16(sn_handle* h, const float* in, int h_px, int w, const f
   HIP_TRY(h, hipMemset(db, 0, (slots + kRefSlack) * 16));
   HIP_TRY(h, hipMemcpy(da, hin.data(), slots * 16, hipMemcpyHostToDevice));
   uint4 *cur = da, *oth = db;
-  g_force_fused = fmode;    // dilation 1 can go through a fused kernel here even when the pipeline does not use it
-  const hipError_t e_blk = ref_block_f16(h->stream, L1, L2, g, h->num_cu, dil, &cur, &oth, 1);
-  g_force_fused = 0;
-  HIP_TRY(h, e_blk);
+  if (!h->ws.tile_ctr) {
+    set_err(h, "sn_dbg_ref_block_f16 needs an engine created in an fp16 mode");
+    return SN_ERR_ARG;
+  }
+  HIP_TRY(h, hipMemsetAsync(h->ws.tile_ctr, 0, kTileCtrBytes, h->stream));
+  // dilation 1 can go through the fused kernel here even when the pipeline does not use it
+  HIP_TRY(h, ref_block_f16(h->stream, L1, L2, g, h->num_cu, dil, &cur, &oth, 1, h->ws.tile_ctr, fused));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   std::vector<_Float16> hout(slots * 8);
   HIP_TRY(h, hipMemcpy(hout.data(), cur, slots * 16, hipMemcpyDeviceToHost));

@@ -114,12 +114,12 @@ def test_ragged_chunks_get_their_own_tile_queue(model_factory, rc, piece, n):
         assert (singles[i % 3][0] == disp[i]).all() and (singles[i % 3][1] == raw[i]).all(), i
 
 
-@pytest.mark.parametrize("fused", [0, 1, 2, 3])
+@pytest.mark.parametrize("fused", [0, 1])
 @pytest.mark.parametrize("h,w,dil", [(8, 62, 1), (64, 96, 1), (45, 80, 1), (100, 129, 1), (37, 250, 1), (720, 1280, 1),
                                      (40, 70, 2)])
 def test_residual_block_f16(eng16, oracle, h, w, dil, fused):
-    """y = lrelu(x + conv2(lrelu(conv1(x)+b1)) + b2): fused single-kernel form for dilation 1 (t never leaves LDS),
-    two launches otherwise.  Reference: oracle convs on fp16-rounded operands with t rounded to fp16."""
+    """y = lrelu(x + conv2(lrelu(conv1(x)+b1)) + b2): fused = 1 runs the single-kernel form for dilation 1 (t never
+    leaves LDS; opt-in SN_FUSE=3 in the pipeline), two launches otherwise.  Reference: oracle convs on fp16-rounded operands with t rounded to fp16."""
     rng = np.random.default_rng(h * 7 + w + dil)
     x = q16(rng.standard_normal((32, h, w)))
     w1 = q16(rng.standard_normal((32, 32, 3, 3)) / 17.0)
@@ -197,8 +197,8 @@ def test_full_size_epe_f16x3(model_factory, oracle, weights_blob):
     assert epe < 2e-4
 
 
-@pytest.mark.parametrize("h,w,tc", [(32, 64, 32), (64, 96, 64), (96, 160, 32), (52, 100, 32), (52, 102, 64),
-                                    (90, 130, 32), (720, 1280, 32), (720, 1280, 64)])
+@pytest.mark.parametrize("h,w,tc", [(32, 64, 32), (64, 96, 32), (96, 160, 32), (52, 100, 32), (52, 102, 32),
+                                    (90, 130, 32), (720, 1280, 32)])
 def test_down0_f16_kernel(eng16, oracle, h, w, tc):
     """First down-conv (3->32, 5x5, stride 2) on the fp16 MFMA with densely packed K: the int8 input / 128 is
     exact in fp16 and the weights are split hi/lo (22 bits), so it must match the fp32 oracle to fp32 round-off

@@ -256,46 +256,43 @@ def test_baseline_config_c5_kitti_1242x375_d256(model_factory, oracle, weights_b
     assert (raw == np.rint(disp * inv_q).astype(np.int32)).all()
 
 
-@pytest.mark.parametrize("slots", [False, True])
 @pytest.mark.parametrize("h,w", [(45, 80), (34, 60), (24, 78), (64, 96), (9, 33)])
-def test_lowres_split_conv3x3(small_engine, oracle, h, w, slots):
-    """Low-resolution 3x3 layers of the fp16 modes: 22-bit split operands (k_conv_x3s).  slots=False: fp32 NCHW in/out;
-    slots=True: hi/lo fp16 slot tensors in/out (the production format; the hook converts), so the reference is
-    evaluated on the 22-bit rounded input and the output carries one more 22-bit rounding."""
+def test_lowres_split_conv3x3(small_engine, oracle, h, w):
+    """Low-resolution 3x3 layers of the fp16 modes: 22-bit split operands (k_conv_x3s) on hi/lo fp16 slot tensors (the
+    production format; the hook converts), so the input is rounded to 22 bits and the output carries one more 22-bit
+    rounding."""
     rng = np.random.default_rng(h * 5 + w)
     x = rng.standard_normal((32, h, w)).astype(np.float32)
     wt = (rng.standard_normal((32, 32, 3, 3)) / 17.0).astype(np.float32)
     b = rng.standard_normal(32).astype(np.float32)
     ref = oracle.conv2d(x, wt, b, 1, 1, 1)
-    got = small_engine.dbg_conv2d(x, wt, b, 3, 1, 1, x3=True, slots=slots)
+    got = small_engine.dbg_conv2d(x, wt, b, 3, 1, 1, x3=True, slots=True)
     assert rel_err(got, ref) < 4e-6
     res = rng.standard_normal((32, h, w)).astype(np.float32)
     v = ref + res
     ref2 = np.where(v > 0, v, v * np.float32(0.2))
-    got2 = small_engine.dbg_conv2d(x, wt, b, 3, 1, 1, lrelu=True, residual=res, x3=True, slots=slots)
+    got2 = small_engine.dbg_conv2d(x, wt, b, 3, 1, 1, lrelu=True, residual=res, x3=True, slots=True)
     assert rel_err(got2, ref2) < 4e-6
 
 
-@pytest.mark.parametrize("slots", [False, True])
 @pytest.mark.parametrize("d,h,w", [(3, 4, 6), (12, 45, 80), (16, 24, 78)])
-def test_lowres_split_conv3d(small_engine, oracle, d, h, w, slots):
+def test_lowres_split_conv3d(small_engine, oracle, d, h, w):
     rng = np.random.default_rng(d + h + w)
     x = rng.standard_normal((32, d, h, w)).astype(np.float32)
     wt = (rng.standard_normal((32, 32, 3, 3, 3)) / 30.0).astype(np.float32)
     b = rng.standard_normal(32).astype(np.float32)
     ref = oracle.conv3d(x, wt, b)
-    got = small_engine.dbg_conv3d(x, wt, b, x3=True, slots=slots)
+    got = small_engine.dbg_conv3d(x, wt, b, x3=True, slots=True)
     assert rel_err(got, ref) < 4e-6
 
 
-@pytest.mark.parametrize("slots", [False, True])
 @pytest.mark.parametrize("h,w", [(90, 160), (46, 82), (360, 640), (64, 96)])
-def test_lowres_split_conv5x5_stride2(small_engine, oracle, h, w, slots):
+def test_lowres_split_conv5x5_stride2(small_engine, oracle, h, w):
     rng = np.random.default_rng(h * 3 + w)
     x = rng.standard_normal((32, h, w)).astype(np.float32)
     wt = (rng.standard_normal((32, 32, 5, 5)) / 28.0).astype(np.float32)
     b = rng.standard_normal(32).astype(np.float32)
     ref = oracle.conv2d(x, wt, b, 2, 2, 1)
-    got = small_engine.dbg_conv2d(x, wt, b, 5, 2, 1, x3=True, slots=slots)
+    got = small_engine.dbg_conv2d(x, wt, b, 5, 2, 1, x3=True, slots=True)
     assert got.shape == ref.shape
     assert rel_err(got, ref) < 4e-6
