@@ -870,34 +870,48 @@ __global__ __launch_bounds__(256) void k_down0_f16(const int8_t* __restrict__ in
 // K6: final 3x3x3 conv 32->1 fused with soft-argmin.
 //   cost[d] = b + sum_{ci,dz,ky,kx} w[ci][dz][ky][kx] * vol[n][d+dz-1][ci][y+ky-1][x+kx-1]
 //   disp    = sum_d d * softmax_d(-cost)
-// Workgroup = 8 waves x 64 consecutive pixels: wave g accumulates the partial costs of all Dl planes over its 4
-// input channels (every load is a 256-byte run of one channel plane, weights are wave-uniform scalar loads), the 8
-// partials meet in LDS and wave 0 finishes (softmax / expectation in registers).  Splitting the channels over 8
-// waves instead of 4 lanes-groups of a wave doubles the waves in flight (the kernel is latency bound: ~37 MFLOP
-// per pair) and makes the loads coalesced.
+// Workgroup = 16 waves x 64 consecutive pixels: wave g accumulates the partial costs of all Dl planes over its 2
+// input channels (every load is a 256-byte run of one channel plane, weights are wave-uniform scalar loads), the 16
+// partials meet in LDS and wave 0 finishes (softmax / expectation in registers).  The kernel is latency bound
+// (~37 MFLOP per pair), so what matters is waves in flight and loads in flight per wave: the plane loop is fully
+// unrolled (cost[] stays in registers) but fenced every second plane, which keeps 18 loads per lane in flight and the
+// register count near 64 — unfenced, hipcc hoisted all 16 x 9 loads of a channel and spilled 300 B per lane
+// (68 MB of scratch writes per launch against 1.4 MB of output).
 // ------------------------------------------------------------------------------------------
+constexpr int kSamWaves = 16;
 template <int DLMAX>
-__global__ __launch_bounds__(512) void k_head_softargmin(const float* __restrict__ vol,   // [n][Dl][32][H][W]
-                                                         const float* __restrict__ w,     // [32][27] (ci, dz*9+ky*3+kx)
-                                                         float bias, int Dl, int H, int W, int npix_total,
-                                                         float* __restrict__ disp_low,    // [n][H][W]
-                                                         float* __restrict__ cost_out) {  // nullable [n][Dl][H][W]
-  __shared__ float s_part[8][DLMAX][64];
+__global__ __launch_bounds__(64 * kSamWaves) void k_head_softargmin(const float* __restrict__ vol,   // [n][Dl][32][H][W]
+                                                                    const float* __restrict__ w,     // [32][27] (ci, dz*9+ky*3+kx)
+                                                                    float bias, int Dl, int H, int W, int npix_total,
+                                                                    float* __restrict__ disp_low,    // [n][H][W]
+                                                                    float* __restrict__ cost_out) {  // nullable [n][Dl][H][W]
+  __shared__ float s_part[kSamWaves][DLMAX][64];
+  constexpr int CPW = kC / kSamWaves;           // channels per wave
   const int lane = threadIdx.x & 63;
-  const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // channel group 0..7 (4 channels each)
+  const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // channel group
   const int gp = blockIdx.x * 64 + lane;        // global pixel index over n*H*W
   const int plane = H * W;
   const bool live = gp < npix_total;
   const int n = live ? gp / plane : 0;
   const int pix = live ? gp - n * plane : 0;
   const int y = pix / W, x = pix - y * W;
+  // the nine taps of this pixel: element offset inside a channel plane, or -1 outside the image (zero padding)
+  int toff[9];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int yy = y + ky - 1, xx = x + kx - 1;
+      toff[ky * 3 + kx] = (live && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) ? yy * W + xx : -1;
+    }
 
   float cost[DLMAX];
 #pragma unroll
   for (int d = 0; d < DLMAX; ++d) cost[d] = 0.f;
 
-  for (int cg = 0; cg < 4; ++cg) {
-    const int ci = grp * 4 + cg;
+#pragma unroll 1
+  for (int cg = 0; cg < CPW; ++cg) {
+    const int ci = grp * CPW + cg;
     const float* wc = w + ci * 27;
 #pragma unroll
     for (int p = 0; p < DLMAX; ++p) {
@@ -905,13 +919,7 @@ __global__ __launch_bounds__(512) void k_head_softargmin(const float* __restrict
         const float* src = vol + (((size_t)n * Dl + p) * kC + ci) * plane;
         float v[9];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-          for (int kx = 0; kx < 3; ++kx) {
-            const int yy = y + ky - 1, xx = x + kx - 1;
-            const bool ok = live && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-            v[ky * 3 + kx] = ok ? src[yy * W + xx] : 0.f;
-          }
+        for (int t = 0; t < 9; ++t) v[t] = toff[t] >= 0 ? src[toff[t]] : 0.f;
 #pragma unroll
         for (int dz = 0; dz < 3; ++dz) {
           const int d = p - dz + 1;           // output plane fed by input plane p through tap dz
@@ -923,6 +931,7 @@ __global__ __launch_bounds__(512) void k_head_softargmin(const float* __restrict
           }
         }
       }
+      if (p & 1) asm volatile("" ::: "memory");       // bound the load hoisting: two planes (18 loads) at a time
     }
   }
 #pragma unroll
@@ -933,7 +942,7 @@ __global__ __launch_bounds__(512) void k_head_softargmin(const float* __restrict
   for (int d = 0; d < DLMAX; ++d) {
     float c = bias;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) c += s_part[g][d][lane];
+    for (int g = 0; g < kSamWaves; ++g) c += s_part[g][d][lane];
     cost[d] = c;
   }
   // soft-argmin over the Dl planes (max-subtracted), in registers
@@ -2005,45 +2014,117 @@ __global__ __launch_bounds__(256) void k_refin_f16(const float* __restrict__ dis
 }
 
 // K8 for the fp16 tower: 3x3 conv 32->1 on the NCHW8c tensor, disp = relu(up + D*r), outputs as k_head_final.
-template <bool SPLIT>
+// A per-pixel VALU kernel moves every input slot through L1 nine times (36 16-byte loads and 576 cvt / fma per pixel:
+// 40 us per two pairs, 1.78x the tensor's bytes from HBM).  Here the contraction over the 32 channels runs on the
+// matrix core with the nine TAPS as the M dimension:
+//     P[tap][pixel] = sum_c w[c][tap] * x[c][pixel]            one 32x32x16 MFMA per 16 channels and 32 pixels
+//     r(y, x)       = bias + sum_tap P[tap][y + ky - 1][x + kx - 1]
+// x is read ONCE, straight from global memory as the MFMA's B operand (lane (j, g) of K-step kk needs the 8 fp16
+// channels of block 2 kk + g of pixel j = one 16-byte slot of the NCHW8c tensor: no LDS staging, no conversion);
+// the fp32 weights are split hi / lo (22 bits) into two A fragments built in registers, so the products are exact
+// and only the fp32 summation order differs from the scalar form.  P of a (TH + 2) x 64 pixel window goes to LDS
+// (rows 0..8 of the accumulator tile are the nine taps), then every thread sums nine shifted P values per output
+// pixel of the TH x 62 tile, adds the upsampled disparity and writes both outputs.
+// SPLIT (SN_PREC_F16X3): x = hi + lo / 2048 from the two tensors, three MFMAs per K-step.
+// ------------------------------------------------------------------------------------------
+template <int TH_>
+struct HeadTile {
+  static constexpr int TH = TH_, TWO = 62;                   // output tile
+  static constexpr int RP = TH + 2, CP = 64;                 // P window
+  static constexpr int NSEG = RP * 2, SPW = (NSEG + 3) / 4;  // 32-pixel segments, per wave
+  static constexpr int PLANE = RP * CP;
+  static constexpr int LDS_BYTES = 9 * PLANE * 4;
+};
+
+template <bool SPLIT, int TH>
 __global__ __launch_bounds__(256) void k_head_final_f16(const uint4* __restrict__ xin, size_t lo_slots, RefGeom g,
                                                         const float* __restrict__ w,      // [32][9]
                                                         float bias, const float* __restrict__ disp_low, int hl,
                                                         int wl, int H, int W, float dmax, float inv_q,
-                                                        float* __restrict__ out_disp, int32_t* __restrict__ out_raw) {
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  const int n = blockIdx.z;
-  if (x >= W || y >= H) return;
-  float acc = bias;
+                                                        float* __restrict__ out_disp, int32_t* __restrict__ out_raw,
+                                                        int tiles_x, int tiles_y) {
+  using T = HeadTile<TH>;
+  extern __shared__ __attribute__((aligned(16))) float s_p[];           // [9][RP][CP]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, gh = lane >> 5;
+  int t = blockIdx.x;
+  const int tx = t % tiles_x;
+  t /= tiles_x;
+  const int ty = t % tiles_y, n = t / tiles_y;
+  const int y0 = ty * T::TH, x0 = tx * T::TWO;
+
+  // B operands of this wave's segments: issued first, all of them in flight together
+  const size_t plane_s = (size_t)g.Hs * g.Ws;
+  const uint4* img = xin + (size_t)n * 4 * plane_s;
+  uint4 xb[T::SPW][2], xl[SPLIT ? T::SPW : 1][2];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int s = 0; s < T::SPW; ++s) {
+    int seg = wave * T::SPW + s;
+    seg = seg < T::NSEG ? seg : T::NSEG - 1;                 // tail waves repeat the last segment (same P values)
+    const int prow = seg >> 1, pcol = (seg & 1) * 32 + j;
+    const size_t slot = (size_t)(y0 - 1 + prow + kRefPad) * g.Ws + (x0 - 1 + pcol + kRefPad);
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const uint4* row = xin + (((size_t)n * 4 + q) * g.Hs + (y + ky - 1 + kRefPad)) * g.Ws + (x - 1 + kRefPad);
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const uint4 raw = row[kx];
-        const half8 hv = *reinterpret_cast<const half8*>(&raw);
-        if (SPLIT) {
-          const uint4 rawl = row[kx + lo_slots];
-          const half8 lv = *reinterpret_cast<const half8*>(&rawl);
-#pragma unroll
-          for (int e = 0; e < 8; ++e)
-            acc = fmaf(w[(8 * q + e) * 9 + ky * 3 + kx], (float)hv[e] + (float)lv[e] * kSplitInv, acc);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) acc = fmaf(w[(8 * q + e) * 9 + ky * 3 + kx], (float)hv[e], acc);
-        }
-      }
+    for (int kk = 0; kk < 2; ++kk) {
+      xb[s][kk] = img[(size_t)(2 * kk + gh) * plane_s + slot];
+      if (SPLIT) xl[s][kk] = img[(size_t)(2 * kk + gh) * plane_s + slot + lo_slots];
     }
   }
-  const float up = upsample16(disp_low + (size_t)n * hl * wl, hl, wl, y, x);
-  float d = up + dmax * acc;
-  d = d > 0.f ? d : 0.f;
-  const size_t o = ((size_t)n * H + y) * W + x;
-  if (out_disp) out_disp[o] = d;
-  if (out_raw) out_raw[o] = (int32_t)__float2int_rn(d * inv_q);
+  // A fragments: row i = tap (rows 9.. are zero), k = 8 gh + e <-> channel 16 kk + 8 gh + e
+  half8 ah[2], al[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float wv = j < 9 ? w[(16 * kk + 8 * gh + e) * 9 + j] : 0.f;
+      const _Float16 hi = (_Float16)wv;
+      ah[kk][e] = hi;
+      al[kk][e] = (_Float16)((wv - (float)hi) * kSplitScale);
+    }
+#pragma unroll
+  for (int s = 0; s < T::SPW; ++s) {
+    int seg = wave * T::SPW + s;
+    seg = seg < T::NSEG ? seg : T::NSEG - 1;
+    f32x16 a0, a1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      a0[r] = 0.f;
+      a1[r] = 0.f;
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const half8 xh = *reinterpret_cast<const half8*>(&xb[s][kk]);
+      a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk], xh, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[kk], xh, a1, 0, 0, 0);
+      if (SPLIT) {
+        const half8 xlo = *reinterpret_cast<const half8*>(&xl[SPLIT ? s : 0][kk]);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk], xlo, a1, 0, 0, 0);
+      }
+    }
+    // accumulator row (r & 3) + 8 (r >> 2) + 4 gh: lanes gh = 0 hold taps 0..3 (r 0..3) and 8 (r 4), gh = 1 taps 4..7
+    float* dst = s_p + (seg >> 1) * T::CP + (seg & 1) * 32 + j;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dst[(4 * gh + r) * T::PLANE] = a0[r] + a1[r] * kSplitInv;
+    if (gh == 0) dst[8 * T::PLANE] = a0[4] + a1[4] * kSplitInv;
+  }
+  __syncthreads();
+  const float* dl = disp_low + (size_t)n * hl * wl;
+  for (int p = tid; p < T::TH * T::TWO; p += 256) {
+    const int oy = p / T::TWO, ox = p - oy * T::TWO;
+    const int y = y0 + oy, x = x0 + ox;
+    if (y >= H || x >= W) continue;
+    float acc = bias;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) acc += s_p[(ky * 3 + kx) * T::PLANE + (oy + ky) * T::CP + ox + kx];
+    const float up = upsample16(dl, hl, wl, y, x);
+    float d = up + dmax * acc;
+    d = d > 0.f ? d : 0.f;
+    const size_t o = ((size_t)n * H + y) * W + x;
+    if (out_disp) out_disp[o] = d;
+    if (out_raw) out_raw[o] = (int32_t)__float2int_rn(d * inv_q);
+  }
 }
 
 }  // namespace sn

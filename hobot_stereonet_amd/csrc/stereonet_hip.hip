@@ -571,6 +571,22 @@ hipError_t launch_ref_block_f16_h(hipStream_t st, const RefLayerF16& L1, const R
   return hipGetLastError();
 }
 
+hipError_t launch_head_final_f16(hipStream_t st, bool split, const uint4* x, size_t lo_slots, const RefGeom& g,
+                                 const float* w, float bias, const float* disp_low, int hl, int wl, int H, int W, float dmax,
+                                 float inv_q, float* out_disp, int32_t* out_raw, int nimg) {
+  constexpr int TH = 16;
+  using T = HeadTile<TH>;
+  const int tiles_x = (W + T::TWO - 1) / T::TWO, tiles_y = (H + TH - 1) / TH;
+  const dim3 grid((unsigned)(tiles_x * tiles_y * nimg));
+  if (split)
+    hipLaunchKernelGGL((k_head_final_f16<true, TH>), grid, dim3(256), T::LDS_BYTES, st, x, lo_slots, g, w, bias, disp_low, hl,
+                       wl, H, W, dmax, inv_q, out_disp, out_raw, tiles_x, tiles_y);
+  else
+    hipLaunchKernelGGL((k_head_final_f16<false, TH>), grid, dim3(256), T::LDS_BYTES, st, x, (size_t)0, g, w, bias, disp_low,
+                       hl, wl, H, W, dmax, inv_q, out_disp, out_raw, tiles_x, tiles_y);
+  return hipGetLastError();
+}
+
 bool fuse_env() {        // SN_FUSE=3: the dilation-1 blocks of the pipeline run through the fused kernel
   static const bool on = getenv("SN_FUSE") != nullptr && atoi(getenv("SN_FUSE")) == 3;
   return on;
@@ -712,7 +728,7 @@ int lowres_slots(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, con
   }
   const float* v = ws.vol[(kNAgg - 1) & 1];
   const int npix = m * hl * wl;
-  hipLaunchKernelGGL(k_head_softargmin<16>, dim3((npix + 63) / 64), dim3(512), 0, st, v, h->aout.w, h->aout.bias, Dl,
+  hipLaunchKernelGGL(k_head_softargmin<16>, dim3((npix + 63) / 64), dim3(64 * kSamWaves), 0, st, v, h->aout.w, h->aout.bias, Dl,
                      hl, wl, npix, ws.disp_low + (size_t)p0 * hl * wl,
                      want_cost ? ws.cost + (size_t)p0 * Dl * hl * wl : nullptr);
   HIP_TRY(h, hipGetLastError());
@@ -755,7 +771,7 @@ int lowres(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, const int
   }
   const float* v = ws.vol[(kNAgg - 1) & 1];
   const int npix = m * hl * wl;
-  hipLaunchKernelGGL(k_head_softargmin<16>, dim3((npix + 63) / 64), dim3(512), 0, st, v, h->aout.w, h->aout.bias, Dl,
+  hipLaunchKernelGGL(k_head_softargmin<16>, dim3((npix + 63) / 64), dim3(64 * kSamWaves), 0, st, v, h->aout.w, h->aout.bias, Dl,
                      hl, wl, npix, ws.disp_low + (size_t)p0 * hl * wl,
                      want_cost ? ws.cost + (size_t)p0 * Dl * hl * wl : nullptr);
   HIP_TRY(h, hipGetLastError());
@@ -822,12 +838,8 @@ int refine_chunk(sn_handle* h, Workspace& ws, hipStream_t st, int sidx, int ordi
       }
     }
     if (pe) HIP_TRY(h, hipEventRecord(h->ev[5], st));
-    if (x3)
-      hipLaunchKernelGGL(k_head_final_f16<true>, grid, dim3(256), 0, st, rx, lo_slots, g, h->rout.w, h->rout.bias, dl,
-                         hl, wl, h->H, h->W, (float)h->D, inv_q, od, orw);
-    else
-      hipLaunchKernelGGL(k_head_final_f16<false>, grid, dim3(256), 0, st, rx, (size_t)0, g, h->rout.w, h->rout.bias,
-                         dl, hl, wl, h->H, h->W, (float)h->D, inv_q, od, orw);
+    HIP_TRY(h, launch_head_final_f16(st, x3, rx, lo_slots, g, h->rout.w, h->rout.bias, dl, hl, wl, h->H, h->W, (float)h->D,
+                                     inv_q, od, orw, c));
   }
   HIP_TRY(h, hipGetLastError());
   return SN_OK;

@@ -72,7 +72,8 @@ def test_bench_json_line_contract():
         assert k in d, k
     assert d["verified"] is True
     e2e = d["end_to_end"]
-    assert e2e["unit"] == "pairs/s" and 0 < e2e["value"] < d["value"] * 1.05 and e2e["async_single_pair"]["value"] > 0
+    assert e2e["unit"] == "pairs/s" and e2e["value"] > 0 and e2e["async_single_pair"]["value"] > 0
+    assert e2e["h2d_bytes_per_pair"] == 3 * 1280 * 720 and e2e["d2h_bytes_per_pair"] == 4 * 1280 * 720
     assert d["unit"] == "pairs/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert "workload" in d["config"] and "model" not in d["config"]
