@@ -50,7 +50,7 @@ def load_library(path: Optional[str] = None):
     global _lib
     if _lib is not None:
         return _lib
-    path = path or _build.LIB
+    path = path or os.environ.get("STEREONET_HIP_LIB") or _build.LIB      # STEREONET_HIP_LIB: A/B builds of the library
     # One HIP runtime per process: the PyTorch wheel bundles its own libamdhip64/libhsa-runtime64.  If this library
     # came in first it would bind the system ROCm copies, torch would later add its own, and whichever runtime
     # opened the device second would report "no ROCm-capable device".  Importing torch first makes both share

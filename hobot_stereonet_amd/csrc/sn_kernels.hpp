@@ -10,6 +10,10 @@
 
 #include <type_traits>
 
+#ifndef SN_X3S_FPK
+#define SN_X3S_FPK 2
+#endif
+
 namespace sn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -471,6 +475,7 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
   // Staging: a unit is one 16-byte slot of (virtual block, part, row, column): load -> LDS, no VALU.
   static_assert(std::is_same<Loader, SlotIn>::value, "k_conv_x3s reads split-slot tensors");
   constexpr int NSL = 2 * T::NSLOT, LPT = (NSL + 255) / 256;       // slots per tile (hi and lo) / per thread
+  constexpr int FPK = SN_X3S_FPK;                                   // staging copies issued per K-step
   float pre[LPT * 4];
   // Which slot a thread copies in round e never changes, so (block, part, row, column, LDS offset) are
   // decoded ONCE into one packed register per round; per tile a copy is then ~10 instructions of address math
@@ -629,12 +634,18 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
         acc1[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[k], xh, acc1[s], 0, 0, 0);
         acc1[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[k], xl, acc1[s], 0, 0, 0);
       }
-      if (k < LPT && nxt < t_end) fetch_one(k);     // one staging copy of the next tile per K-step
+      // staging copies of the next tile: FPK per K-step from the start of the loop, so that the last of them still
+      // has most of the loop's MFMAs (not one K-step) between its issue and the commit that waits for it
+      if (nxt < t_end) {
+#pragma unroll
+        for (int f = 0; f < FPK; ++f)
+          if (FPK * k + f < LPT) fetch_one(FPK * k + f);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     if (nxt < t_end) {
 #pragma unroll
-      for (int e = T::NK; e < LPT; ++e) fetch_one(e);         // (only when a tile has more copies than K-steps)
+      for (int e = FPK * T::NK; e < LPT; ++e) fetch_one(e);   // (only when a tile has more copies than the loop takes)
     }
     // ship the partial of the segment the pair partner finishes
     {

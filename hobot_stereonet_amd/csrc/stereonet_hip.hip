@@ -624,7 +624,7 @@ int alloc_ws(sn_handle* h, Workspace* ws, int nb, int rb, int ns) {
   ws->nb = nb;
   ws->rb = rb;
   ws->ns = (ns > 1 && nb > rb) ? (ns < kMaxTowerStreams ? ns : kMaxTowerStreams) : 1;
-  ws->pb = h->piece > 0 ? h->piece : 8;
+  ws->pb = h->piece > 0 ? h->piece : 16;
   if (ws->pb > nb) ws->pb = nb;
   if (ws->pb < rb) ws->pb = rb;
   const int pb = ws->pb;
@@ -646,9 +646,9 @@ int alloc_ws(sn_handle* h, Workspace* ws, int nb, int rb, int ns) {
       HIP_TRY(h, hipMemset(ws->ref16[k], 0, slots * sizeof(uint4)));   // the zero border is never written again
     }
     // fine-grained: the queue words must be coherent across the 8 XCD L2s at device scope and with the memset
-    // one counter block per tower chunk: chunks never straddle a low-resolution piece, so a piece of pb pairs
-    // holds ceil(pb / rb) of them (the last one short when pb % rb != 0) — see chunk_ordinal()
-    ws->n_chunks = ((nb + pb - 1) / pb) * ((pb + rb - 1) / rb);
+    // one counter block per tower chunk of a forward(): chunks never straddle a low-resolution piece, so every
+    // piece may end with one short chunk (forward() numbers the chunks with a running ordinal)
+    ws->n_chunks = (nb + rb - 1) / rb + (nb + pb - 1) / pb + 2;
     HIP_TRY(h, hipExtMallocWithFlags(reinterpret_cast<void**>(&ws->tile_ctr), kTileCtrBytes * ws->n_chunks, hipDeviceMallocFinegrained));
   }
   HIP_TRY(h, dalloc(&ws->out_disp, (size_t)nb * HW));
@@ -778,11 +778,13 @@ int lowres(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, const int
   return SN_OK;
 }
 
-// Ordinal of the tower chunk that starts at pair q0 of the piece that starts at pair p0 (pieces start at multiples of
-// ws.pb, chunks at p0 + k * ws.rb): indexes the per-chunk tile-queue counters, which are zeroed once per forward() and
-// never reset by the kernel, so two chunks of one forward must never share an ordinal.
-inline int chunk_ordinal(const Workspace& ws, int p0, int q0) {
-  return (p0 / ws.pb) * ((ws.pb + ws.rb - 1) / ws.rb) + (q0 - p0) / ws.rb;
+// Pieces of one forward(): [p0, p0 + m).  The first piece is short (the towers can only start when its low-resolution
+// branch is done: nothing overlaps that time), the others take ws.pb pairs (the low-resolution launches are dominated by
+// fixed costs: 13 of the 23 launches of a piece do ~1 us of matrix work in ~9 us).
+inline int first_piece(const Workspace& ws, int n) {
+  int m = ws.rb * ws.ns > 2 ? ws.rb * ws.ns : 2;
+  if (m > ws.pb) m = ws.pb;
+  return m < n ? m : n;
 }
 
 // Refinement of ONE tower chunk: pairs [q0, q0+c), c <= ws.rb, on stream `st` with the activation pair of tower
@@ -864,14 +866,14 @@ int forward(sn_handle* h, Workspace& ws, hipStream_t st, int n, const int8_t* in
   if (ws.tile_ctr) HIP_TRY(h, hipMemsetAsync(ws.tile_ctr, 0, kTileCtrBytes * ws.n_chunks, st));
   if (!multi) {
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[0], st));
-    for (int p0 = 0; p0 < n; p0 += ws.pb) {
-      const int m = (n - p0) < ws.pb ? (n - p0) : ws.pb;
+    int chunk = 0;
+    for (int p0 = 0, m = 0; p0 < n; p0 += m) {
+      m = (n - p0) < ws.pb ? (n - p0) : ws.pb;
       if ((rc = lowres(h, ws, st, p0, m, in6, want_cost, prof && p0 == 0))) return rc;
       if (prof && p0 == 0) HIP_TRY(h, hipEventRecord(h->ev[2], st));
-      for (int q0 = p0; q0 < p0 + m; q0 += ws.rb) {
+      for (int q0 = p0; q0 < p0 + m; q0 += ws.rb, ++chunk) {
         const int c = (p0 + m - q0) < ws.rb ? (p0 + m - q0) : ws.rb;
-        if ((rc = refine_chunk(h, ws, st, 0, chunk_ordinal(ws, p0, q0), q0, c, in6, out_disp, out_raw, prof && q0 == 0)))
-          return rc;
+        if ((rc = refine_chunk(h, ws, st, 0, chunk, q0, c, in6, out_disp, out_raw, prof && q0 == 0))) return rc;
       }
     }
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[3], st));
@@ -882,8 +884,8 @@ int forward(sn_handle* h, Workspace& ws, hipStream_t st, int n, const int8_t* in
   HIP_TRY(h, hipStreamWaitEvent(h->s_low, h->ev_fork, 0));
   for (int s = 0; s < ns; ++s) HIP_TRY(h, hipStreamWaitEvent(h->s_tow[s], h->ev_fork, 0));
   int k = 0, chunk = 0;
-  for (int p0 = 0; p0 < n; p0 += ws.pb, ++k) {
-    const int m = (n - p0) < ws.pb ? (n - p0) : ws.pb;
+  for (int p0 = 0, m = 0; p0 < n; p0 += m, ++k) {
+    m = p0 == 0 ? first_piece(ws, n) : ((n - p0) < ws.pb ? (n - p0) : ws.pb);
     // the piece-local low-res buffers are reused by the next piece: only disp_low crosses streams
     if ((rc = lowres(h, ws, h->s_low, p0, m, in6, want_cost, false))) return rc;
     hipEvent_t e = h->ev_piece[k % kMaxPieceEvents];
@@ -896,8 +898,7 @@ int forward(sn_handle* h, Workspace& ws, hipStream_t st, int n, const int8_t* in
         HIP_TRY(h, hipStreamWaitEvent(h->s_tow[s], e, 0));
         waited[s] = true;
       }
-      if ((rc = refine_chunk(h, ws, h->s_tow[s], s, chunk_ordinal(ws, p0, q0), q0, c, in6, out_disp, out_raw, false)))
-        return rc;
+      if ((rc = refine_chunk(h, ws, h->s_tow[s], s, chunk, q0, c, in6, out_disp, out_raw, false))) return rc;
     }
   }
   HIP_TRY(h, hipEventRecord(h->ev_join, h->s_low));
@@ -1047,7 +1048,7 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
   h->task_num = c.task_num > 0 ? c.task_num : 4;
   h->refine_chunk = c.refine_chunk > 0 ? c.refine_chunk : 1;   // one pair per tower launch, two chunks in flight
                                                                // (forward()); SN_TOWER_STREAMS=1 wants 2 here
-  h->piece = c.piece > 0 ? c.piece : 8;
+  h->piece = c.piece > 0 ? c.piece : 16;
   h->rg = make_ref_geom(h->Hp, h->Wp);
   h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (h->refine_chunk > h->max_batch) h->refine_chunk = h->max_batch;

@@ -78,7 +78,8 @@ typedef struct sn_config {
   int precision;     /* SN_PREC_*; 0 = SN_PREC_F16                                                */
   int task_num;      /* async slots for sn_submit; <=0 -> 4 (stereonet_node.cpp:144)              */
   int refine_chunk;  /* pairs per refinement-tower launch; <=0 -> 1 (two such chunks are in flight)  */
-  int piece;         /* pairs per low-resolution piece of the two-stream pipeline; <=0 -> 8       */
+  int piece;         /* pairs per low-resolution piece of the pipeline; <=0 -> 16 (the first piece of */
+                     /* a call is 2 pairs: nothing overlaps its low-resolution branch)               */
 } sn_config;
 
 typedef struct sn_io_info {
