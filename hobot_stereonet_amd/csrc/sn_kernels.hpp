@@ -163,7 +163,6 @@ struct SlotIn {
     const int d = img % Dl;
     return (unsigned)(d + (vb >> 2) - 1) < (unsigned)Dl;
   }
-  __device__ __forceinline__ const uint4* image_base(int img) const { return p + (size_t)img * 8 * ((size_t)H * W); }
 };
 __device__ __forceinline__ size_t low_slot_index(int img, int cb, int part, int y, int x, int H, int W) {
   return ((((size_t)img * 4 + cb) * 2 + part) * H + y) * (size_t)W + x;
@@ -483,7 +482,7 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
   //   bits 0..12 LDS slot offset (inside s_xh / s_xl), 13..19 column, 20..24 row, 25..28 virtual block, 29 part,
   //   30 valid
   unsigned stab[LPT];
-  int srel[LPT];            // slot offset of the copy relative to (image, block 0, hi, row iy0, column ix0)
+  unsigned srel[LPT];       // byte offset of the copy relative to (image, block 0, hi, row iy0, column ix0), mod 2^32
   constexpr int DUMMY = 2 * T::NCB * T::PLANE + T::RED_FLOATS / 4 + 8;     // spare LDS slot behind the bias
   {
     static_assert(DUMMY < 8192 && T::COLS_IN < 128 && T::ROWS_IN < 32 && T::NCB <= 16, "packed staging table");
@@ -499,24 +498,34 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
       const unsigned off = (vp & 1) * (T::NCB * T::PLANE) + (vp >> 1) * T::PLANE + r * T::PITCH + di;
       const bool ok = idx < NSL;
       stab[e] = ok ? (off | (cc << 13) | (r << 20) | ((vp >> 1) << 25) | (1u << 30)) : (unsigned)DUMMY;
-      srel[e] = ok ? ld.plane_off(vp >> 1) + (vp & 1) * (ld.H * ld.W) + r * ld.W + cc : 0;
+      srel[e] = ok ? (unsigned)(ld.plane_off(vp >> 1) + (vp & 1) * (ld.H * ld.W) + r * ld.W + cc) * 16u : 0u;
     }
   }
   unsigned vmask = 0;                   // bit e: the slot fetched in round e lies inside the tensor (else LDS gets 0)
-  const char* f_ibase = nullptr;
-  int f_iy0 = 0, f_ix0 = 0, f_toff = 0;
-  unsigned f_pmask = 0;
+  // Every global address of the staging is  tensor base (SGPR pair)  +  32-bit byte offset (one VGPR):
+  //   offset = f_toff (uniform: image, row iy0, column ix0 of the tile, mod 2^32)  +  srel[e] (per lane, fixed)
+  // (the host keeps every tensor below 4 GiB; the previous depth plane of a volume lies BEFORE the image base, which
+  // the modular arithmetic handles).  The loop around the MFMAs is ISSUE bound — the first form of this copy cost 45
+  // instructions (64-bit address math, four short-circuit branches), i.e. 4.5 non-matrix instructions per MFMA and
+  // 64 cycles per MFMA instead of 32 — so the validity test is branch-free integer arithmetic, and tiles that lie
+  // inside the image with all their depth planes present (f_fast, wave-uniform) skip it altogether.
+  const char* const f_base = reinterpret_cast<const char*>(ld.p);
+  int f_iy0 = 0, f_ix0 = 0;
+  unsigned f_toff = 0, f_pmask = 0;
+  bool f_fast = false;
   auto fetch_one = [&](int e) {         // copy number e of the tile prepared by fetch()
     unsigned t = stab[e];
-    int rel = srel[e];
+    unsigned rel = srel[e];
     asm volatile("" : "+v"(t), "+v"(rel));      // keep the unpacking inside the tile loop (hoisted it spills)
-    const int cc = (t >> 13) & 127, r = (t >> 20) & 31, vb = (t >> 25) & 15;
-    const bool ok = (unsigned)(f_iy0 + r) < (unsigned)ld.H && (unsigned)(f_ix0 + cc) < (unsigned)ld.W &&
-                    ((f_pmask >> vb) & 1u) && (t >> 30);
-    // signed: the previous depth plane of a volume lies BEFORE the image base
-    const int soff = ok ? rel + f_toff : 0;
-    vmask |= ok ? (1u << e) : 0u;
-    *reinterpret_cast<uint4*>(&pre[e * 4]) = *reinterpret_cast<const uint4*>(f_ibase + (ptrdiff_t)soff * 16);
+    unsigned off = rel + f_toff;
+    if (!f_fast) {                              // wave-uniform
+      const unsigned cc = (t >> 13) & 127u, r = (t >> 20) & 31u, vb = (t >> 25) & 15u;
+      const unsigned ok = (unsigned)((unsigned)(f_iy0 + (int)r) < (unsigned)ld.H) & (unsigned)((unsigned)(f_ix0 + (int)cc) < (unsigned)ld.W) &
+                          ((f_pmask >> vb) & 1u) & (t >> 30);
+      off = ok ? off : 0u;                      // a slot outside the tensor reads slot 0 and is zeroed at commit
+      vmask |= ok << e;
+    }
+    *reinterpret_cast<uint4*>(&pre[e * 4]) = *reinterpret_cast<const uint4*>(f_base + off);
   };
   auto fetch = [&](int tile) {
     const int tx = tile % a.tiles_x, t2 = tile / a.tiles_x;
@@ -527,14 +536,18 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
       // of the image instead and is replaced by zeros when it is committed to LDS.  Only the per-tile constants
       // are set up here; the LPT copies themselves are issued from inside the MFMA loop (fetch_one), where their
       // address arithmetic runs in the shadow of the matrix pipe.
-      f_ibase = reinterpret_cast<const char*>(ld.image_base(img));
       f_iy0 = iy0;
       f_ix0 = ix0;
-      f_toff = iy0 * ld.W + ix0;
+      f_toff = (unsigned)__builtin_amdgcn_readfirstlane((int)(((unsigned)img * 8u * (unsigned)(ld.H * ld.W) +
+                                                                 (unsigned)(iy0 * ld.W + ix0)) * 16u));
       f_pmask = 0;                      // valid virtual blocks of this image (3-D: neighbouring depth planes)
 #pragma unroll
       for (int vb = 0; vb < T::NCB; ++vb) f_pmask |= ld.plane_valid(img, vb) ? (1u << vb) : 0u;
-      vmask = 0;
+      // interior tile with every depth plane present: all NSL slots are valid (rounds past NSL copy slot 0 + srel 0
+      // = a valid address whose value lands in the spare LDS slot)
+      f_fast = iy0 >= 0 && iy0 + T::ROWS_IN <= ld.H && ix0 >= 0 && ix0 + T::COLS_IN <= ld.W &&
+               f_pmask == (1u << T::NCB) - 1u;
+      vmask = f_fast ? 0xffffffffu : 0u;
     }
   };
   auto commit = [&]() {
