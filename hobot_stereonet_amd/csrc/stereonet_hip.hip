@@ -1046,10 +1046,25 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
   h->max_batch = c.max_batch > 0 ? c.max_batch : 1;
   h->precision = c.precision;
   h->task_num = c.task_num > 0 ? c.task_num : 4;
-  h->refine_chunk = c.refine_chunk > 0 ? c.refine_chunk : 1;   // one pair per tower launch, two chunks in flight
-                                                               // (forward()); SN_TOWER_STREAMS=1 wants 2 here
+  h->refine_chunk = c.refine_chunk;                            // <= 0: chosen below from the tensor size
   h->piece = c.piece > 0 ? c.piece : 16;
   h->rg = make_ref_geom(h->Hp, h->Wp);
+  {
+    const char* e = getenv("SN_TOWER_STREAMS");        // 2 = consecutive tower chunks alternate between two streams
+    h->tower_streams = e ? atoi(e) : 1;
+    if (h->tower_streams < 1) h->tower_streams = 1;
+    if (h->tower_streams > kMaxTowerStreams) h->tower_streams = kMaxTowerStreams;
+  }
+  if (h->refine_chunk <= 0) {
+    // Pairs per tower launch: as many as keep the activations in flight — (x, t) per tower stream — inside the
+    // 256 MB Infinity Cache.  A launch costs bytes / ~7 TB/s while its tensors stay cache resident plus ~8 us that do
+    // not depend on its size, and ~5 TB/s per byte once they spill (scripts/mall_probe.hip): 1280x720
+    // -> 2 pairs (4 x 61 MB), 1248x384 -> 4 pairs (8 x 32 MB); measured equal to one-pair chunks alternating on two
+    // streams (SN_TOWER_STREAMS=2), with fewer and fuller launches.
+    const double tensor_mb = 4.0 * h->rg.Hs * h->rg.Ws * 16.0 / 1048576.0 * (c.precision == SN_PREC_F16X3 ? 2.0 : c.precision == SN_PREC_FP32 ? 2.0 : 1.0);
+    int rc_auto = (int)(256.0 / (2.0 * tensor_mb * h->tower_streams) + 0.5);
+    h->refine_chunk = rc_auto < 1 ? 1 : (rc_auto > 8 ? 8 : rc_auto);
+  }
   h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (h->refine_chunk > h->max_batch) h->refine_chunk = h->max_batch;
 
@@ -1079,12 +1094,6 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
       hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess)
     return fail(SN_ERR_DEVICE);
-  {
-    const char* e = getenv("SN_TOWER_STREAMS");        // 1 = every tower chunk on one stream (A/B switch)
-    h->tower_streams = e ? atoi(e) : kMaxTowerStreams;
-    if (h->tower_streams < 1) h->tower_streams = 1;
-    if (h->tower_streams > kMaxTowerStreams) h->tower_streams = kMaxTowerStreams;
-  }
   for (int i = 0; i < kMaxTowerStreams; ++i)
     if (hipStreamCreateWithFlags(&h->s_tow[i], hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_tow_join[i], hipEventDisableTiming) != hipSuccess)

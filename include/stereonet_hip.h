@@ -77,7 +77,8 @@ typedef struct sn_config {
   int dmax;          /* max disparity D (multiple of 16, <= 256); 0 = from the model file        */
   int precision;     /* SN_PREC_*; 0 = SN_PREC_F16                                                */
   int task_num;      /* async slots for sn_submit; <=0 -> 4 (stereonet_node.cpp:144)              */
-  int refine_chunk;  /* pairs per refinement-tower launch; <=0 -> 1 (two such chunks are in flight)  */
+  int refine_chunk;  /* pairs per refinement-tower launch; <=0 -> sized so that the activations in    */
+                     /* flight fill the 256 MB Infinity Cache (2 at 1280x720, 4 at 1248x384, max 8)  */
   int piece;         /* pairs per low-resolution piece of the pipeline; <=0 -> 16 (the first piece of */
                      /* a call is 2 pairs: nothing overlaps its low-resolution branch)               */
 } sn_config;
