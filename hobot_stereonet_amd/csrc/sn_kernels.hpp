@@ -13,6 +13,9 @@
 #ifndef SN_X3S_FPK
 #define SN_X3S_FPK 2
 #endif
+#ifndef SN_X3S_WAGPR
+#define SN_X3S_WAGPR 1
+#endif
 
 namespace sn {
 
@@ -458,6 +461,15 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
       wh[k] = *reinterpret_cast<const half8*>(&x);
       wl[k] = *reinterpret_cast<const half8*>(&y);
     }
+#if SN_X3S_WAGPR
+    // Home the weight fragments in the accumulator half of the (unified) register file when the kernel needs more
+    // than 256 registers: an MFMA reads its A operand from an AGPR directly, whereas fragments that the allocator
+    // SPILLS to AGPRs come back through four v_accvgpr_read each (one extra instruction per MFMA in an issue-bound loop)
+    if (T::NK > 12) {
+#pragma unroll
+      for (int k = 0; k < T::NK; ++k) asm volatile("" : "+a"(wh[k]), "+a"(wl[k]));
+    }
+#endif
   }
   // per-lane slot offset of each of the wave's two segments (pixel j of the segment, channel-block parity gh)
   // slot 0 = the segment this wave finishes (pset * 2 + khalf), slot 1 = the one whose partial it ships to its
