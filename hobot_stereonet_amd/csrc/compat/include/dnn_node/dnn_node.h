@@ -35,6 +35,11 @@ class DnnNode : public rclcpp::Node {
   // runs on the completion thread, requests complete in submission order, at most task_num in flight.
   int Run(std::vector<std::shared_ptr<DNNTensor>>& inputs, const std::shared_ptr<DnnNodeOutput>& output = nullptr,
           bool is_sync_mode = false, int alloc_chn_timeout_ms = -1, int infer_timeout_ms = 1000);
+  // Extension of this backend (not part of the reference's dnn_node): Run() on FeedImg's raw 2W x H side-by-side NV12
+  // message payload.  The split (stereonet_node.cpp:705-738) and CvtNV12Data2Tensors (preprocess.cpp:913-1059) run on
+  // the GPU, bit-identical to the host steps, and the host ships 2.76 MB per frame instead of the 5.53 MB tensor.
+  int RunSbsNv12(const uint8_t* sbs_nv12, int width2, int height, const std::shared_ptr<DnnNodeOutput>& output = nullptr,
+                 bool is_sync_mode = false, int alloc_chn_timeout_ms = -1);
 
  protected:
   virtual int SetNodePara() = 0;

@@ -206,6 +206,45 @@ int DnnNode::Run(std::vector<std::shared_ptr<DNNTensor>>& inputs, const std::sha
   return 0;
 }
 
+int DnnNode::RunSbsNv12(const uint8_t* sbs, int width2, int height, const std::shared_ptr<DnnNodeOutput>& output,
+                        bool is_sync_mode, int alloc_chn_timeout_ms) {
+  if (!engine_ || !model_ || !sbs || width2 != 2 * model_->width() || height != model_->height()) return -1;
+  std::shared_ptr<DnnNodeOutput> out = output ? output : std::make_shared<DnnNodeOutput>();
+  auto ot = MakeOutputTensor();
+  if (!ot) return -1;
+  out->output_tensors.clear();
+  out->output_tensors.push_back(ot);
+  int32_t* raw = static_cast<int32_t*>(ot->sysMem[0].virAddr);
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    ++in_count_;
+  }
+  if (is_sync_mode) {
+    const double t0 = now_s();
+    if (sn_infer_sbs_nv12(engine_, sbs, width2, height, raw, nullptr, nullptr, SN_MEM_HOST, nullptr) != SN_OK) {
+      RCLCPP_ERROR(rclcpp::get_logger("dnn"), "infer failed: %s", sn_last_error(engine_));
+      return -1;
+    }
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      UpdateStat(out, (float)((now_s() - t0) * 1e3));
+    }
+    return PostProcess(out) < 0 ? -1 : 0;
+  }
+  uint64_t ticket = 0;
+  const int rc = sn_submit_nv12(engine_, sbs, width2, height, raw, nullptr, alloc_chn_timeout_ms, &ticket);
+  if (rc != SN_OK) {
+    RCLCPP_ERROR(rclcpp::get_logger("dnn"), "submit failed: %s", sn_strerror(rc));
+    return -1;
+  }
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    pending_.push_back(Pending{ticket, out, ot});
+  }
+  cv_.notify_all();
+  return 0;
+}
+
 void DnnNode::CompletionLoop() {
   for (;;) {
     Pending p;

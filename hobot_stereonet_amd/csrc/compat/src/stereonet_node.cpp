@@ -11,6 +11,7 @@
 #include <unistd.h>
 
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <thread>
@@ -125,16 +126,21 @@ void StereonetNode::OnStereoFrame(const hbm_img_msgs::msg::HbmMsg1080P::ConstSha
   request->msg_header->stamp = frame->time_stamp;
 
   const auto t_pre = std::chrono::steady_clock::now();
+  // STEREONET_INGEST=tensor keeps the reference's host steps (split both eyes, CvtNV12Data2Tensors, Run on the int8
+  // tensor); the default hands the message payload to the backend, which does the same byte mapping on the GPU
+  static const bool host_tensor = getenv("STEREONET_INGEST") != nullptr && !strcmp(getenv("STEREONET_INGEST"), "tensor");
   // de-interleave the eyes: every source row carries w bytes of the left eye, then w bytes of the right eye
-  eye_l_.resize((size_t)w * rows);
-  eye_r_.resize((size_t)w * rows);
   const unsigned char* row = frame->data.data();
-  for (int r = 0; r < rows; ++r, row += pitch) {
-    memcpy(eye_l_.data() + (size_t)r * w, row, w);
-    memcpy(eye_r_.data() + (size_t)r * w, row + w, w);
+  if (host_tensor || cfg_.publish_output) {
+    eye_l_.resize((size_t)w * rows);
+    if (host_tensor) eye_r_.resize((size_t)w * rows);
+    for (int r = 0; r < rows; ++r, row += pitch) {
+      memcpy(eye_l_.data() + (size_t)r * w, row, w);
+      if (host_tensor) memcpy(eye_r_.data() + (size_t)r * w, row + w, w);
+    }
   }
   std::vector<std::shared_ptr<DNNTensor>> tensors;
-  if (pre_->CvtNV12Data2Tensors(tensors, net_, eye_l_.data(), eye_r_.data()) < 0) {
+  if (host_tensor && pre_->CvtNV12Data2Tensors(tensors, net_, eye_l_.data(), eye_r_.data()) < 0) {
     RCLCPP_ERROR(kLog, "Preprocess fail");
     rclcpp::shutdown();
     return;
@@ -153,7 +159,9 @@ void StereonetNode::OnStereoFrame(const hbm_img_msgs::msg::HbmMsg1080P::ConstSha
   request->preprocess_time_ms = elapsed_ms(t_pre);
   RCLCPP_INFO(kLog, "Preprocess done, time cost %d ms", request->preprocess_time_ms);
 
-  if (Run(tensors, request, /*is_sync_mode=*/false, -1, -1) < 0) {
+  const int rc = host_tensor ? Run(tensors, request, /*is_sync_mode=*/false, -1, -1)
+                             : RunSbsNv12(frame->data.data(), 2 * w, h, request, /*is_sync_mode=*/false, -1);
+  if (rc < 0) {
     RCLCPP_ERROR(kLog, "Run infer fail!");
     return;
   }

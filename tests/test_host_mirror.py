@@ -101,8 +101,11 @@ def test_node_init_fails_loudly_without_gpu(hostlib, tmp_path):
 
 
 @pytest.mark.gpu
-def test_stereonet_node_end_to_end(hostlib, oracle, weights_blob, tmp_path):
-    """hbmem NV12 frame in -> /stereonet_node_output message out, payload = int32 tensor || JPEG(left)."""
+@pytest.mark.parametrize("ingest", ["nv12", "tensor"])
+def test_stereonet_node_end_to_end(hostlib, oracle, weights_blob, tmp_path, ingest):
+    """hbmem NV12 frame in -> /stereonet_node_output message out, payload = int32 tensor || JPEG(left).
+    ingest = nv12: the node hands the raw message payload to the backend (split + CvtNV12Data2Tensors on the GPU, the
+    default); tensor: the reference's host steps and Run() on the int8 tensor.  Both must publish the same bytes."""
     from PIL import Image
     w, h, d = 96, 64, 48
     m = str(tmp_path / "m.snw")
@@ -115,7 +118,7 @@ def test_stereonet_node_end_to_end(hostlib, oracle, weights_blob, tmp_path):
     sbs = frame.ravel()
     sbs.tofile(str(tmp_path / "s.bin"))
     nframes = 6          # > task_num: exercises the 4 in-flight slots
-    env = dict(os.environ, STEREONET_PRECISION="fp32")
+    env = dict(os.environ, STEREONET_PRECISION="fp32", STEREONET_INGEST=ingest)
     r = subprocess.run([os.path.join(COMPAT, "build", "node_harness"), m, str(tmp_path / "s.bin"), str(w), str(h),
                         str(nframes), str(tmp_path / "o")], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr
@@ -132,6 +135,7 @@ def test_stereonet_node_end_to_end(hostlib, oracle, weights_blob, tmp_path):
         raw = payload[:w * h * 4].view(np.uint32).reshape(h, w)        # the render node's view (uint32)
         disp = raw.astype(np.float64) * spec.OUT_SCALE * 16 * 12      # the literal factor, whatever D (here 96) is
         assert np.abs(disp - odisp).mean() < 1e-3
+        assert np.abs(raw.astype(np.int64) - oraw).max() <= 2
         jpg = Image.open(io.BytesIO(payload[w * h * 4:].tobytes()))
         assert jpg.size == (w, h)
         # the render node's twin consumes the message as is (it hard-codes the 16*12 of the reference model)
