@@ -6,8 +6,25 @@
 #include "jpeg_nv12.h"
 #include "parser.h"
 #include "preprocess.h"
+#include "render.h"
 
 extern "C" {
+
+// render twin: payload -> disparity, depth, BGR colour map and the stacked RGB canvas (left_rgb given by the caller)
+int snhost_render(const unsigned char* payload, long len, int w, int h, double* disp, double* depth,
+                  unsigned char* color_bgr, const unsigned char* left_rgb, unsigned char* joint_rgb) {
+  hobot::stereonet::RenderConstants k;
+  size_t off = 0;
+  if (!hobot::stereonet::RenderDepth(payload, (size_t)len, w, h, k, disp, depth, color_bgr, &off)) return -1;
+  if (left_rgb && joint_rgb) {
+    std::vector<uint8_t> j;
+    hobot::stereonet::StackJoint(left_rgb, color_bgr, w, h, j);
+    memcpy(joint_rgb, j.data(), j.size());
+  }
+  return (int)off;
+}
+
+void snhost_jet_lut(unsigned char* out) { memcpy(out, hobot::stereonet::JetLutBGR(), 768); }
 
 void snhost_yuv420_to_yuv444(const unsigned char* in, unsigned char* out, int w, int h) {
   hobot::stereonet::Tools::YUV420TOYUV444(in, out, w, h);

@@ -120,6 +120,33 @@ def test_features_identical_eyes(model_factory, oracle, weights_blob):
     assert rel_err(fl.reshape(32, 4, 6), oracle.features(weights_blob, planes)) < 5e-5
 
 
+@pytest.mark.parametrize("prec", [api.PREC_FP32, api.PREC_F16])
+def test_identical_eyes_reference_fixture(model_factory, oracle, weights_blob, prec):
+    """The reference's only image fixture: config/image_left.jpg == image_right.jpg (byte-identical files).  A 160x96
+    crop of it (tests/golden/identical_eyes.npz, made by make_identical_eyes_golden.py) goes through the offline feeder's
+    steps (BGR -> NV12 -> CvtNV12Data2Tensors) for both eyes.  Known answers: the feature maps of the eyes are equal bit
+    for bit, so the cost volume is EXACTLY zero wherever x >= d; and the HIP path still matches the oracle."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "identical_eyes.npz"))
+    assert str(g["source_sha256"]) == "fde9f79716b34223705137cad4c4e027df3bc6f765e1793d65fe6895a33c6b08"
+    bgr = g["bgr"]
+    h, w = bgr.shape[:2]
+    d = 96
+    nv12 = oracle.bgr_to_nv12(bgr)
+    x = oracle.preprocess_nv12(nv12, nv12, w, h)
+    assert (x[:3] == x[3:]).all()
+    with api.StereoNetHIP(model_factory(w, h, d), precision=prec) as eng:
+        disp, raw = eng.infer(x)
+        fl, fr = eng.dbg_read("feat_l"), eng.dbg_read("feat_r")
+    assert (fl == fr).all()                                      # Siamese tower: identical inputs, identical outputs
+    fl = fl.reshape(32, h // 16, w // 16)
+    cv = oracle.cost_volume(fl, fl, d // 16)                     # fL - shift(fL): plane 0 is exactly zero
+    assert (cv[:, 0] == 0).all()
+    odisp, oraw, _ = oracle.forward(weights_blob, x, d)
+    assert np.abs(disp - odisp).mean() < EPE_TOL
+    assert raw.min() >= 0
+
+
 def test_full_size_epe(model_factory, oracle, weights_blob):
     """BASELINE.json configs[1]: 1280x720, D=192, one pair, fp32."""
     w, h, d = 1280, 720, 192

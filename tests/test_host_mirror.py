@@ -145,3 +145,35 @@ def test_stereonet_node_end_to_end(hostlib, oracle, weights_blob, tmp_path, inge
         assert np.abs(rdisp - odisp).mean() < 1e-3
         y = np.asarray(jpg.convert("YCbCr"), np.float32)[..., 0]
         assert np.abs(y - left[:w * h].reshape(h, w)).mean() < 6.0
+
+
+def test_cpp_render_twin_matches_python_twin(hostlib):
+    """Row f-3 in C++ (compat/src/render.cpp): payload split (uint32 view), dequantisation, depth, convertScaleAbs(9),
+    JET table, BGR-as-RGB stacking — byte for byte the numpy twin (hobot_stereonet_amd/render.py), incl. raw = 0 -> inf
+    depth -> 255 and the table values remembered from OpenCV's colormap.cpp."""
+    from hobot_stereonet_amd import render
+    vp = C.c_void_p
+    hostlib.snhost_render.argtypes = [vp, C.c_long, C.c_int, C.c_int, vp, vp, vp, vp, vp]
+    hostlib.snhost_jet_lut.argtypes = [vp]
+    lut = np.empty((256, 3), np.uint8)
+    hostlib.snhost_jet_lut(lut.ctypes.data)
+    assert (lut == render.jet_lut()).all()
+    w, h = 40, 12
+    rng = np.random.default_rng(3)
+    raw = rng.integers(0, 400000, (h, w)).astype(np.int32)
+    raw[0, :5] = [0, 1, 200000, 2 ** 31 - 1, 10]
+    payload = np.frombuffer(raw.tobytes() + b"\xff\xd8JPEG", np.uint8).copy()
+    left = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    disp = np.empty((h, w), np.float64)
+    depth = np.empty((h, w), np.float64)
+    color = np.empty((h, w, 3), np.uint8)
+    joint = np.empty((2 * h, w, 3), np.uint8)
+    off = hostlib.snhost_render(payload.ctypes.data, payload.size, w, h, disp.ctypes.data, depth.ctypes.data,
+                                color.ctypes.data, left.ctypes.data, joint.ctypes.data)
+    assert off == w * h * 4 and bytes(payload[off:]) == b"\xff\xd8JPEG"
+    pr, _ = render.split_payload(payload.tobytes(), w, h)
+    pdisp, pdepth = render.disparity_and_depth(pr)
+    assert (disp == pdisp).all() and (depth == pdepth).all()
+    assert (color == render.colorize_depth(pdepth)).all()
+    assert (joint[:h] == left).all() and (joint[h:] == color).all()
+    assert hostlib.snhost_render(payload.ctypes.data, w * h * 4 - 1, w, h, None, None, None, None, None) == -1

@@ -95,3 +95,24 @@ def test_snw_roundtrip(tmp_path, weights_blob):
         f.write(b"XXXX")
     with pytest.raises(ValueError):
         weights.load_snw(p)
+
+
+def test_identical_eyes_reference_fixture_oracle(oracle, weights_blob):
+    """The reference's only image fixture (config/image_left.jpg == image_right.jpg, committed as a 160x96 crop): the
+    oracle's feature maps of the two eyes are equal, cost-volume plane 0 is exactly zero, the disparity is finite and
+    non-negative (uint32 and int32 views of the wire tensor agree)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "identical_eyes.npz"))
+    bgr = g["bgr"]
+    h, w = bgr.shape[:2]
+    nv12 = oracle.bgr_to_nv12(bgr)
+    x = oracle.preprocess_nv12(nv12, nv12, w, h)
+    assert (x[:3] == x[3:]).all()
+    planes = x[:3].astype(np.float32) / 128.0
+    f = oracle.features(weights_blob, planes)
+    cv = oracle.cost_volume(f, f, 6)
+    assert (cv[:, 0] == 0).all()
+    for dd in range(1, 6):
+        assert (cv[:, dd, :, :dd] == 0).all()        # x < d: defined as zero
+    disp, raw, low = oracle.forward(weights_blob, x, 96)
+    assert np.isfinite(disp).all() and raw.min() >= 0
