@@ -115,6 +115,8 @@ struct sn_handle {
   bool overlap = true;
   int tower_streams = kMaxTowerStreams;
   bool fuse_dil1 = false;    // SN_FUSE=3: dilation-1 residual blocks through the fused kernel (opt-in)
+  bool head_fuse = true;     // last tower conv + head in one kernel (fp16 mode; SN_HEAD_FUSE=0 separates them)
+  unsigned* dump = nullptr;  // 2 KB device scratch: where lanes without an output pixel store (fused head)
   bool use_graphs = true;    // hipGraph replay for the async single-pair path (SN_NO_GRAPH disables)
   ConvLayer down[kNDown], fres[kNFeatRes][2], fout, agg[kNAgg], rin, rres[kNRefRes][2];
   Down0F16 down0, refin;
@@ -587,6 +589,38 @@ hipError_t launch_head_final_f16(hipStream_t st, bool split, const uint4* x, siz
   return hipGetLastError();
 }
 
+// last tower layer + head in one launch (fp16 mode): overlapping 8 x 64 conv tiles, 6 x 62 head outputs each
+hipError_t launch_ref_conv_head_f16(hipStream_t st, const RefLayerF16& L, const RefGeom& g, int num_cu, const uint4* in,
+                                    const uint4* res, int nimg, unsigned* tile_ctr, const float* hw, float hbias,
+                                    const float* disp_low, int hl, int wl, int H, int W, float dmax, float inv_q,
+                                    float* out_disp, int32_t* out_raw, unsigned* dump) {
+  using T = RefTile2<1, 64, 8, 3>;
+  auto kern = k_ref_conv_head_f16;
+  if (tile_ctr == nullptr || dump == nullptr) return hipErrorInvalidValue;
+  constexpr int lds_bytes = 3 * T::BUF * 16 + HeadFuse::EXTRA_BYTES;
+  static_assert(2 * lds_bytes <= 160 * 1024, "two workgroups per CU");
+  {
+    hipError_t e = ensure_lds_attr(kern, lds_bytes);
+    if (e != hipSuccess) return e;
+  }
+  RefGeom gt = g;
+  gt.tiles_x = (W + HeadFuse::OW - 1) / HeadFuse::OW;
+  gt.tiles_y = (H + HeadFuse::OH - 1) / HeadFuse::OH;
+  const int total = gt.tiles_x * gt.tiles_y * nimg;
+  const int band = (total + 7) / 8;
+  int cap = num_cu * 2 / 8;
+  if (cap < 1) cap = 1;
+  const int nlb = cap < band ? cap : band;
+  hipLaunchKernelGGL(kern, dim3(nlb * 8), dim3(256), lds_bytes, st, in, res, L.wfrag, L.bias, gt, nimg, tile_ctr, hw,
+                     hbias, disp_low, hl, wl, H, W, dmax, inv_q, out_disp, out_raw, dump);
+  return hipGetLastError();
+}
+
+bool head_fuse_env() {   // SN_HEAD_FUSE=0: separate last conv + head launches (A/B switch)
+  static const bool on = !(getenv("SN_HEAD_FUSE") != nullptr && atoi(getenv("SN_HEAD_FUSE")) == 0);
+  return on;
+}
+
 bool fuse_env() {        // SN_FUSE=3: the dilation-1 blocks of the pipeline run through the fused kernel
   static const bool on = getenv("SN_FUSE") != nullptr && atoi(getenv("SN_FUSE")) == 3;
   return on;
@@ -830,18 +864,29 @@ int refine_chunk(sn_handle* h, Workspace& ws, hipStream_t st, int sidx, int ordi
                                 hl, wl, h->H, h->W, 1.0f / (float)h->D, g, c, rx, x3, lo_slots * 16, ncu));
     if (pe) HIP_TRY(h, hipEventRecord(h->ev[4], st));
     unsigned* const chunk_ctr = ws.tile_ctr + (size_t)ordinal * (kTileCtrBytes / sizeof(unsigned));
+    // fp16 mode: the last conv of the tower and the head run as one kernel (the tower's output tensor is never
+    // written); needs the last block to be an unfused dilation-1 block
+    const bool head_fused = !x3 && h->head_fuse && kRefDil[kNRefRes - 1] == 1 && !h->fuse_dil1;
     for (int i = 0; i < kNRefRes; ++i) {
       if (x3) {
         HIP_TRY(h, ref_conv_f16x3(st, h->rres16[i][0], g, ncu, kRefDil[i], rx, rt, nullptr, lo_slots, c, true));
         HIP_TRY(h, ref_conv_f16x3(st, h->rres16[i][1], g, ncu, kRefDil[i], rt, rx, rx, lo_slots, c, true));
+      } else if (head_fused && i == kNRefRes - 1) {
+        unsigned* ctr = chunk_ctr + 2 * i * kTileCtrStride;
+        HIP_TRY(h, ref_conv_f16(st, h->rres16[i][0], g, ncu, 1, rx, rt, nullptr, c, true, ctr));
+        if (pe) HIP_TRY(h, hipEventRecord(h->ev[5], st));          // the 11 plain tower launches end here
+        HIP_TRY(h, launch_ref_conv_head_f16(st, h->rres16[i][1], g, ncu, rt, rx, c, ctr + kTileCtrStride, h->rout.w,
+                                            h->rout.bias, dl, hl, wl, h->H, h->W, (float)h->D, inv_q, od, orw, h->dump));
       } else {
         HIP_TRY(h, ref_block_f16(st, h->rres16[i][0], h->rres16[i][1], g, ncu, kRefDil[i], &rx, &rt, c,
                                  chunk_ctr + 2 * i * kTileCtrStride, h->fuse_dil1));
       }
     }
-    if (pe) HIP_TRY(h, hipEventRecord(h->ev[5], st));
-    HIP_TRY(h, launch_head_final_f16(st, x3, rx, lo_slots, g, h->rout.w, h->rout.bias, dl, hl, wl, h->H, h->W, (float)h->D,
-                                     inv_q, od, orw, c));
+    if (!head_fused) {
+      if (pe) HIP_TRY(h, hipEventRecord(h->ev[5], st));
+      HIP_TRY(h, launch_head_final_f16(st, x3, rx, lo_slots, g, h->rout.w, h->rout.bias, dl, hl, wl, h->H, h->W, (float)h->D,
+                                       inv_q, od, orw, c));
+    }
   }
   HIP_TRY(h, hipGetLastError());
   return SN_OK;
@@ -1103,6 +1148,8 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
   h->overlap = getenv("SN_NO_OVERLAP") == nullptr;
   h->use_graphs = getenv("SN_NO_GRAPH") == nullptr;
   h->fuse_dil1 = fuse_env();
+  h->head_fuse = head_fuse_env();
+  if (hipMalloc(reinterpret_cast<void**>(&h->dump), 4096) != hipSuccess) return fail(SN_ERR_NOMEM);
 
   BlobWalker bw{blob.data()};
   const bool low_x3 = h->precision != SN_PREC_FP32;     // fp16 modes: low-resolution layers on split fp16 operands
@@ -1185,6 +1232,7 @@ int sn_destroy(sn_handle* h) {
       hipFree(l.wfrag);
       hipFree(l.bias);
     }
+  hipFree(h->dump);
   hipFree(h->aout.w);
   hipFree(h->rout.w);
   free_ws(&h->ws);
@@ -1578,11 +1626,14 @@ int sn_get_dominant_kernel(sn_handle* h, char* name, size_t cap, int* launches, 
              : h->precision == SN_PREC_F16X3 ? "k_ref_conv_f16x3<DIL> (refinement 3x3 C->C, 3x fp16 MFMA on hi/lo split operands)"
                                              : "k_conv_c32_mfma<3,1,*> (refinement 3x3 C->C, fp32 MFMA 32x32x2)");
   const double px = (double)h->Hp * h->Wp * h->ws.rb;
-  if (launches) *launches = 2 * kNRefRes;   // per refinement chunk
+  // fp16 mode with the fused last layer: the timed span holds the 11 plain tower launches (6 without, 5 with residual)
+  const bool hf = f16 && h->head_fuse && !h->fuse_dil1;
+  const int n_plain = kNRefRes, n_res = hf ? kNRefRes - 1 : kNRefRes;
+  if (launches) *launches = n_plain + n_res;   // per refinement chunk
   if (flops) *flops = 2.0 * px * kC * kC * 9;
   // algorithmic HBM bytes per launch: read the 32-channel input once + write the output once, plus the
-  // residual read on every second launch (averaged: 2.5 tensors); element = 2 B (fp16) or 4 B (fp32)
-  if (bytes) *bytes = px * kC * (f16 ? 2.0 : 4.0) * 2.5;
+  // residual read on the launches that have one, averaged; element = 2 B (fp16) or 4 B (fp32)
+  if (bytes) *bytes = px * kC * (f16 ? 2.0 : 4.0) * (2.0 * n_plain + 3.0 * n_res) / (double)(n_plain + n_res);
   return SN_OK;
 }
 
