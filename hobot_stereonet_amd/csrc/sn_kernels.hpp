@@ -1286,6 +1286,24 @@ __global__ __launch_bounds__(256, MINW) void k_ref_conv_f16_v2(const uint4* __re
     } else {
       issue(g0 + 1, img, y0, x0);                             // second channel half of THIS tile
     }
+    // residual: NSTORE 8-byte loads issued as inline asm right behind the DMA group of THIS phase, i.e. a whole tile
+    // (two compute phases) before the epilogue needs them — issued at the start of the second phase they had one
+    // phase (~1 us) to cover ~3 us of latency and every residual tile stalled ~2 us in front of its epilogue.  They
+    // sit between two DMA groups in the in-order VMEM queue, so the counted waits below name them explicitly.
+    // hipcc does not track asm loads: the "+v" statement behind the wait is what orders their use.
+    const unsigned tb = tile_base(img, y0, x0);
+    uint2 rres[RES ? T::NSTORE : 1];
+    if (RES) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const char* rq = reinterpret_cast<const char*>(res) + (tb + (unsigned)q * plane_b);    // uniform
+#pragma unroll
+        for (int s = 0; s < T::SPW; ++s) {
+          const char* rp = rq + io_voff[s];
+          asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rres[RES ? s * 4 + q : 0]) : "v"(rp) : "memory");
+        }
+      }
+    }
     // accumulators start at the bias: saves one add per output in the epilogue
 #pragma unroll
     for (int s = 0; s < T::SPW; ++s)
@@ -1294,8 +1312,10 @@ __global__ __launch_bounds__(256, MINW) void k_ref_conv_f16_v2(const uint4* __re
     ref2_compute<DIL, TW, 0, TH>(lds + (g0 % NB) * T::BUF + lane_off, wf, acc);
 
     // ---- phase g0+1 (channels 16..31) ----
-    if (NB == 3 && has_next) wait_vmcnt<T::KW>();             // younger than group g0+1: group g0+2
-    else wait_vmcnt<0>();                                     // last phase of this block / two-buffer ring
+    // younger than group g0+1: (NB = 3, another tile follows) group g0+2, and the residual loads behind it
+    constexpr int NRES = RES ? T::NSTORE : 0;
+    if (NB == 3 && has_next) wait_vmcnt<T::KW + NRES>();
+    else wait_vmcnt<NRES>();                                  // last tile of this block / two-buffer ring
     if (has_next && wave == 0) {                              // the atomic is older than group g0+2: it has returned
       asm volatile("" : "+v"(fetched));
       // belt and braces: should a returning atomic ever be retired out of order with the DMA groups, the sentinel
@@ -1313,22 +1333,6 @@ __global__ __launch_bounds__(256, MINW) void k_ref_conv_f16_v2(const uint4* __re
     if (has_next) t_next2 = t_begin + 2 * nlb + (int)__builtin_amdgcn_readfirstlane(tile_slot[ti & 1]);
     else t_next2 = t_end;
 
-    // residual: NSTORE 8-byte loads issued as inline asm BEFORE the next DMA group, so they are older
-    // than it and the counted wait below (all but the newest KW ops) retires them without draining
-    // the ring.  hipcc does not track asm loads: the "+v" wait statement is what orders their use.
-    const unsigned tb = tile_base(img, y0, x0);
-    uint2 rres[RES ? T::NSTORE : 1];
-    if (RES) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const char* rq = reinterpret_cast<const char*>(res) + (tb + (unsigned)q * plane_b);    // uniform
-#pragma unroll
-        for (int s = 0; s < T::SPW; ++s) {
-          const char* rp = rq + io_voff[s];
-          asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rres[RES ? s * 4 + q : 0]) : "v"(rp) : "memory");
-        }
-      }
-    }
     const bool more = has_next;
     if (more) issue(NB == 3 ? g0 + 3 : g0 + 2, nimg_, ny0, nx0);     // NB = 2: first half of the next tile
     ref2_compute<DIL, TW, 1, TH>(lds + ((g0 + 1) % NB) * T::BUF + lane_off, wf, acc);
@@ -1553,6 +1557,18 @@ __global__ __launch_bounds__(256, 2) void k_ref_conv_head_f16(const uint4* __res
           : "memory");
     }
     if (has_next) issue(g0 + 2, nimg_, ny0, nx0);
+    // residual loads right behind this phase's DMA group (see k_ref_conv_f16_v2): two compute phases of cover
+    const unsigned tb = tile_base(img, y0, x0);
+    uint2 rres[T::NSTORE];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const char* rq = reinterpret_cast<const char*>(res) + (tb + (unsigned)q * plane_b);
+#pragma unroll
+      for (int s = 0; s < T::SPW; ++s) {
+        const char* rp = rq + io_voff[s];
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rres[s * 4 + q]) : "v"(rp) : "memory");
+      }
+    }
     {
       const f32x4* bq = reinterpret_cast<const f32x4*>(s_bias + 16 * gh);
 #pragma unroll
@@ -1567,8 +1583,8 @@ __global__ __launch_bounds__(256, 2) void k_ref_conv_head_f16(const uint4* __res
     ref2_compute<DIL, TW, 0, TH>(lds + (g0 % NB) * T::BUF + lane_off, wf, acc);
 
     // ---- phase g0+1 ----
-    if (has_next) wait_vmcnt<T::KW>();
-    else wait_vmcnt<0>();
+    if (has_next) wait_vmcnt<T::KW + T::NSTORE>();            // younger than group g0+1: group g0+2 + the residual loads
+    else wait_vmcnt<T::NSTORE>();
     if (has_next && wave == 0) {
       asm volatile("" : "+v"(fetched));
       if (__builtin_amdgcn_readfirstlane(fetched) == 0xFFFFFFFFu) {
@@ -1582,18 +1598,7 @@ __global__ __launch_bounds__(256, 2) void k_ref_conv_head_f16(const uint4* __res
     if (has_next) t_next2 = t_begin + 2 * nlb + (int)__builtin_amdgcn_readfirstlane(tile_slot[ti & 1]);
     else t_next2 = t_end;
 
-    // residual loads and the bilinear taps of this thread's output pixels: inline asm, issued BEFORE the next DMA group
-    const unsigned tb = tile_base(img, y0, x0);
-    uint2 rres[T::NSTORE];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const char* rq = reinterpret_cast<const char*>(res) + (tb + (unsigned)q * plane_b);
-#pragma unroll
-      for (int s = 0; s < T::SPW; ++s) {
-        const char* rp = rq + io_voff[s];
-        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rres[s * 4 + q]) : "v"(rp) : "memory");
-      }
-    }
+    // the bilinear taps of this thread's output pixels: inline asm, issued BEFORE the next DMA group
     float uv[F::NUP];
     const float* dl = disp_low + (size_t)img * hl * wl;
 #pragma unroll
