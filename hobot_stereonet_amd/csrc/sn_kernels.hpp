@@ -1137,6 +1137,28 @@ __device__ __forceinline__ void ref2_compute(const uint4* lds_lane, const half8 
     }
   }
 }
+// First phase of a tile: the accumulators START at `init` (the bias) through the C operand of the first MFMA of each
+// segment — no 16 v_mov per segment to seed them.
+// `between(m)` runs after the m-th MFMA (m = 0 .. 9 * SPW - 1): the caller spreads its VMEM instructions (residual
+// loads) over the phase instead of issuing them as one burst in front of it — a burst of 16 loads behind a DMA group
+// stalled the wave's in-order issue for ~4 k cycles (VMEM queue full), i.e. kept 36 MFMAs waiting behind it.
+template <int DIL, int TW, int TH = 8, class Between>
+__device__ __forceinline__ void ref2_compute_init(const uint4* lds_lane, const half8 (&wf)[18], const f32x16& init,
+                                                  f32x16 (&acc)[RefTile2<DIL, TW, TH>::SPW], Between between) {
+  using T = RefTile2<DIL, TW, TH>;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+    for (int s = 0; s < T::SPW; ++s) {
+      const int off = ((s / T::CSEG) + ky * DIL) * T::COLS + (s % T::CSEG) * 32 + kx * DIL;
+      const half8 xb = *reinterpret_cast<const half8*>(lds_lane + off);
+      if (tap == 0) acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0], xb, init, 0, 0, 0);
+      else acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[tap * 2], xb, acc[s], 0, 0, 0);
+      between(tap * T::SPW + s);
+    }
+  }
+}
 
 // Tiles beyond the first two rounds are handed out by one device-scope counter per XCD band
 // (tile_ctr[16 * xcd], zeroed by the host before the launch) instead of a static stride.  When the
@@ -1160,6 +1182,11 @@ __global__ __launch_bounds__(256, MINW) void k_ref_conv_f16_v2(const uint4* __re
                                                             int lrelu, unsigned* tile_ctr) {
   using T = RefTile2<DIL, TW, TH, NB>;
   static_assert(NB == 2 || NB == 3, "ring depth");
+  // (Moving residual and output as whole 16-byte slots — lane (j, g) handling block 2i + g and the halves traded with
+  // v_permlane32_swap, 8 instead of 16 VMEM instructions per tile and direction — measured +-0 twice, this round with
+  // loads too; note for anyone retrying: an inline-asm global_store_dwordx4 needs the wait states of the VMEM-store-
+  // data hazard by hand, hipcc cannot see through the asm and dword 0 of lanes 12-15 of every row of 16 came out stale.)
+  constexpr int NIO = T::NSTORE;                             // VMEM instructions per tile: residual loads, stores
   extern __shared__ __attribute__((aligned(16))) uint4 lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1237,13 +1264,12 @@ __global__ __launch_bounds__(256, MINW) void k_ref_conv_f16_v2(const uint4* __re
     const uint4 v = wfrag[i * 64 + lane];
     wf[i] = *reinterpret_cast<const half8*>(&v);
   }
-  float bv[16];
+  f32x16 bv;
 #pragma unroll
   for (int r = 0; r < 16; ++r) bv[r] = bias[(r & 3) + 8 * (r >> 2) + 4 * gh];
 #pragma unroll
   for (int i = 0; i < 18; ++i) asm volatile("" : "+v"(wf[i]));
-#pragma unroll
-  for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(bv[r]));
+  asm volatile("" : "+v"(bv));
   wait_vmcnt<0>();
   int t_next = t0 + nlb;                                      // tile ti+1 (second round is static as well)
   int t_next2 = t0 + 2 * nlb;                                 // tile ti+2: handed out by the queue from here on
@@ -1258,10 +1284,10 @@ __global__ __launch_bounds__(256, MINW) void k_ref_conv_f16_v2(const uint4* __re
     // ---- phase g0 (channels 0..15) ----
     if (NB == 3) {
       if (ti == 0) wait_vmcnt<T::KW>();                       // younger than group 0: group 1
-      else wait_vmcnt<T::KW + T::NSTORE>();                   // ... plus the previous tile's stores
+      else wait_vmcnt<T::KW + NIO>();                         // ... plus the previous tile's stores
     } else {
       if (ti == 0) wait_vmcnt<0>();                           // two buffers: nothing else is in flight yet
-      else wait_vmcnt<T::NSTORE>();                           // only the previous tile's stores are younger
+      else wait_vmcnt<NIO>();                                 // only the previous tile's stores are younger
     }
     block_barrier();
     // `fetched` is written asynchronously by the returning atomic: it is defined opaquely up front and tied
@@ -1286,34 +1312,26 @@ __global__ __launch_bounds__(256, MINW) void k_ref_conv_f16_v2(const uint4* __re
     } else {
       issue(g0 + 1, img, y0, x0);                             // second channel half of THIS tile
     }
-    // residual: NSTORE 8-byte loads issued as inline asm right behind the DMA group of THIS phase, i.e. a whole tile
-    // (two compute phases) before the epilogue needs them — issued at the start of the second phase they had one
-    // phase (~1 us) to cover ~3 us of latency and every residual tile stalled ~2 us in front of its epilogue.  They
-    // sit between two DMA groups in the in-order VMEM queue, so the counted waits below name them explicitly.
-    // hipcc does not track asm loads: the "+v" statement behind the wait is what orders their use.
+    // residual: NSTORE 8-byte loads as inline asm, spread over THIS phase's MFMAs (one after every second MFMA), a
+    // whole tile before the epilogue needs them.  They sit between two DMA groups in the in-order VMEM queue, so the
+    // counted waits below name them explicitly.  hipcc does not track asm loads: the "+v" statement behind the wait
+    // is what orders their use.  SGPR base + 32-bit VGPR offset: no 64-bit VALU add per load.
     const unsigned tb = tile_base(img, y0, x0);
     uint2 rres[RES ? T::NSTORE : 1];
-    if (RES) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const char* rq = reinterpret_cast<const char*>(res) + (tb + (unsigned)q * plane_b);    // uniform
-#pragma unroll
-        for (int s = 0; s < T::SPW; ++s) {
-          const char* rp = rq + io_voff[s];
-          asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rres[RES ? s * 4 + q : 0]) : "v"(rp) : "memory");
-        }
+    const char* const rbase = reinterpret_cast<const char*>(res) + tb;                         // uniform
+    auto res_load = [&](int m) {
+      if (RES && (m & 1) && (m >> 1) < T::NSTORE) {
+        const int i = m >> 1, q = i / T::SPW, sg = i - q * T::SPW;
+        const char* rq = rbase + (unsigned)q * plane_b;
+        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(rres[RES ? sg * 4 + q : 0]) : "v"(io_voff[sg]), "s"(rq) : "memory");
       }
-    }
-    // accumulators start at the bias: saves one add per output in the epilogue
-#pragma unroll
-    for (int s = 0; s < T::SPW; ++s)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[s][r] = bv[r];
-    ref2_compute<DIL, TW, 0, TH>(lds + (g0 % NB) * T::BUF + lane_off, wf, acc);
+    };
+    // accumulators start at the bias (C operand of each segment's first MFMA): no add in the epilogue, no seeding moves
+    ref2_compute_init<DIL, TW, TH>(lds + (g0 % NB) * T::BUF + lane_off, wf, bv, acc, res_load);
 
     // ---- phase g0+1 (channels 16..31) ----
     // younger than group g0+1: (NB = 3, another tile follows) group g0+2, and the residual loads behind it
-    constexpr int NRES = RES ? T::NSTORE : 0;
+    constexpr int NRES = RES ? NIO : 0;
     if (NB == 3 && has_next) wait_vmcnt<T::KW + NRES>();
     else wait_vmcnt<NRES>();                                  // last tile of this block / two-buffer ring
     if (has_next && wave == 0) {                              // the atomic is older than group g0+2: it has returned
@@ -1345,33 +1363,42 @@ __global__ __launch_bounds__(256, MINW) void k_ref_conv_f16_v2(const uint4* __re
     // ---- epilogue: exactly NSTORE stores per wave; out-of-image pixels store zeros.  Tiles that lie
     // completely inside the image (all of them at 1280x720) skip the per-element masking. ----
     const bool interior = y0 + T::TH <= g.H && x0 + T::TW <= g.W;            // wave-uniform
+    const float slope = lrelu ? kSlope : 1.0f;         // max(v, v) = v: one code path with and without the activation
+    float one = 1.0f;
+    asm volatile("" : "+v"(one));                      // opaque: keeps the multiply so that hipcc selects v_fma_mix_f32
+    auto finish = [&](int s, int q) -> uint2 {          // bias is in the accumulator; + residual, activation, fp16
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = acc[s][4 * q + e];
+      if (RES) {
+        const uint2 rw = rres[RES ? s * 4 + q : 0];
+        const half4 rv = *reinterpret_cast<const half4*>(&rw);
+        // v += (float)residual as ONE v_fma_mix_f32 per value (fp16 source read in place) instead of cvt + add
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf((float)rv[e], one, v[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float t = v[e] * slope;
+        asm("v_max_f32 %0, %1, %2" : "=v"(v[e]) : "v"(v[e]), "v"(t));
+      }
+      half4 hv;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) hv[e] = (_Float16)v[e];
+      if (!interior) {
+        const int seg = seg0 + s;
+        const int y = y0 + seg / T::CSEG, x = x0 + (seg % T::CSEG) * 32 + j;
+        if (!(y < g.H && x < g.W)) hv = half4{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+      }
+      return *reinterpret_cast<const uint2*>(&hv);
+    };
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       char* oq = reinterpret_cast<char*>(out) + (tb + (unsigned)q * plane_b);                  // uniform
 #pragma unroll
       for (int s = 0; s < T::SPW; ++s) {
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[s][4 * q + e];
-        if (RES) {
-          const uint2 rw = rres[RES ? s * 4 + q : 0];
-          const half4 rv = *reinterpret_cast<const half4*>(&rw);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
-        }
-        if (lrelu) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = lrelu_fast(v[e]);
-        }
-        half4 hv;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) hv[e] = (_Float16)v[e];
-        if (!interior) {
-          const int seg = seg0 + s;
-          const int y = y0 + seg / T::CSEG, x = x0 + (seg % T::CSEG) * 32 + j;
-          if (!(y < g.H && x < g.W)) hv = half4{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
-        }
-        *reinterpret_cast<half4*>(oq + io_voff[s]) = hv;
+        const uint2 hv = finish(s, q);          // SGPR base + 32-bit VGPR offset: no 64-bit VALU add per store
+        asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(io_voff[s]), "v"(hv), "s"(oq) : "memory");
       }
     }
     if (!has_next) break;
@@ -1557,30 +1584,28 @@ __global__ __launch_bounds__(256, 2) void k_ref_conv_head_f16(const uint4* __res
           : "memory");
     }
     if (has_next) issue(g0 + 2, nimg_, ny0, nx0);
-    // residual loads right behind this phase's DMA group (see k_ref_conv_f16_v2): two compute phases of cover
+    // residual loads spread over this phase's MFMAs (see k_ref_conv_f16_v2): SGPR base + 32-bit VGPR offset
     const unsigned tb = tile_base(img, y0, x0);
     uint2 rres[T::NSTORE];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const char* rq = reinterpret_cast<const char*>(res) + (tb + (unsigned)q * plane_b);
-#pragma unroll
-      for (int s = 0; s < T::SPW; ++s) {
-        const char* rp = rq + io_voff[s];
-        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rres[s * 4 + q]) : "v"(rp) : "memory");
+    const char* const rbase = reinterpret_cast<const char*>(res) + tb;                         // uniform
+    auto res_load = [&](int m) {
+      if ((m & 1) && (m >> 1) < T::NSTORE) {
+        const int i = m >> 1, q = i / T::SPW, sg = i - q * T::SPW;
+        const char* rq = rbase + (unsigned)q * plane_b;
+        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(rres[sg * 4 + q]) : "v"(io_voff[sg]), "s"(rq) : "memory");
       }
-    }
+    };
     {
+      f32x16 binit;                        // conv bias of this lane's 16 rows, from LDS: C operand of the first MFMAs
       const f32x4* bq = reinterpret_cast<const f32x4*>(s_bias + 16 * gh);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const f32x4 b4 = bq[q];
 #pragma unroll
-        for (int s = 0; s < T::SPW; ++s)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc[s][4 * q + e] = b4[e];
+        for (int e = 0; e < 4; ++e) binit[4 * q + e] = b4[e];
       }
+      ref2_compute_init<DIL, TW, TH>(lds + (g0 % NB) * T::BUF + lane_off, wf, binit, acc, res_load);
     }
-    ref2_compute<DIL, TW, 0, TH>(lds + (g0 % NB) * T::BUF + lane_off, wf, acc);
 
     // ---- phase g0+1 ----
     if (has_next) wait_vmcnt<T::KW + T::NSTORE>();            // younger than group g0+1: group g0+2 + the residual loads
@@ -1630,6 +1655,8 @@ __global__ __launch_bounds__(256, 2) void k_ref_conv_head_f16(const uint4* __res
 #pragma unroll
     for (int i = 0; i < F::NUP; ++i) asm volatile("" : "+v"(uv[i]));
 
+    float one = 1.0f;
+    asm volatile("" : "+v"(one));          // opaque multiplier: hipcc then adds the fp16 residual with one v_fma_mix_f32
     // ---- y (fp16) -> P[tap][pixel] on the matrix core ----
     const bool interior = y0 >= 0 && y0 + TH <= g.H && x0 >= 0 && x0 + TW <= g.W;     // wave-uniform
     float* s_p = reinterpret_cast<float*>(lds + ((g0 + 1) % NB) * T::BUF);          // [9][TH][TW], free from here on
@@ -1656,7 +1683,7 @@ __global__ __launch_bounds__(256, 2) void k_ref_conv_head_f16(const uint4* __res
         const half4 rv = *reinterpret_cast<const half4*>(&rw);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float v = lrelu_fast(acc[s][4 * q + e] + (float)rv[e]);
+          const float v = lrelu_fast(__builtin_fmaf((float)rv[e], one, acc[s][4 * q + e]));      // v_fma_mix_f32
           yk[q >> 1][4 * (q & 1) + e] = inside ? (_Float16)v : (_Float16)0.f;
         }
       }

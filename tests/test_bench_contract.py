@@ -70,7 +70,7 @@ def test_bench_json_line_contract():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "verified", "end_to_end"):
         assert k in d, k
-    assert d["verified"] is True
+    assert d["verified"] is True and 0 <= d["epe_vs_oracle_px"] < 1e-3      # timed batch vs single pair AND vs the CPU oracle
     e2e = d["end_to_end"]
     assert e2e["unit"] == "pairs/s" and e2e["value"] > 0 and e2e["async_single_pair"]["value"] > 0
     assert e2e["h2d_bytes_per_pair"] == 3 * 1280 * 720 and e2e["d2h_bytes_per_pair"] == 4 * 1280 * 720
