@@ -4,7 +4,7 @@
 # -> gpurun_out/<tag>_*: bench line (default mode, with cpu_baseline + end_to_end), rocprofv3 kernel stats of the SAME
 #    command (rocprofv3 serialises the dispatches, so these are per-kernel times, not the overlapped pipeline), separate
 #    --pmc passes: FETCH_SIZE / WRITE_SIZE (scripts/pmc_traffic.py) and SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE
-#    (scripts/mfma_busy.py), bench lines of the other precision modes / configs / the stream mode, the MALL probe.
+#    (scripts/mfma_busy.py; PAIRS_PER_LAUNCH = the engine's automatic refine_chunk at this size, 2 at 1280x720), bench lines of the other precision modes / configs / the stream mode, the MALL probe.
 # Copy what should be judged into profiles/ afterwards (gpurun_out/ is scratch).
 set -u
 TAG=${1:-r02x}
@@ -22,7 +22,7 @@ done
 $T rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_pmc_mfma -- python $ROOT/bench.py --steps 2 --warmup 1 --batch 8 --no-cpu-baseline --no-end-to-end --no-verify > $OUT/${TAG}_pmc_mfma.log 2>&1
 cd $ROOT
 python scripts/pmc_traffic.py $(find $OUT/${TAG}_pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1) \
-    $(find $OUT/${TAG}_pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1) $OUT/${TAG}_pmc_traffic.json k_ref_conv_f16 1 > $OUT/${TAG}_pmc_summary.txt 2>&1
+    $(find $OUT/${TAG}_pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1) $OUT/${TAG}_pmc_traffic.json k_ref_conv_f16_v2 ${PAIRS_PER_LAUNCH:-2} > $OUT/${TAG}_pmc_summary.txt 2>&1
 python scripts/mfma_busy.py $(find $OUT/${TAG}_pmc_mfma -name "*counter_collection.csv" | head -1) $OUT/${TAG}_mfma_busy.json > $OUT/${TAG}_mfma_busy.txt 2>&1
 $T python bench.py --precision f16x3 --no-cpu-baseline --no-end-to-end --steps 20 > $OUT/${TAG}_f16x3_b64_bench.json 2>> $OUT/${TAG}_bench.err
 $T python bench.py --precision fp32 --no-cpu-baseline --no-end-to-end --steps 5 --batch 16 > $OUT/${TAG}_fp32_b16_bench.json 2>> $OUT/${TAG}_bench.err
@@ -32,6 +32,7 @@ $T python bench.py --stream 10 --batch 16 > $OUT/${TAG}_stream_c2_b16.json 2>> $
 $T python bench.py --config c5 --stream 10 --batch 16 > $OUT/${TAG}_stream_c5_b16.json 2>> $OUT/${TAG}_bench.err
 [ -x scripts/build/mall_probe ] && ./scripts/build/mall_probe > $OUT/${TAG}_mall_probe.txt 2>&1
 python scripts/kstats.py $OUT/${TAG}_f16_b64_kernel_stats.csv 30 > $OUT/${TAG}_kernel_summary.txt
+python scripts/tower_sequence.py $(find $OUT/${TAG}_prof -name "*kernel_trace.csv" | head -1) > $OUT/${TAG}_tower_sequence.txt 2>&1
 cat $OUT/${TAG}_mfma_busy.txt | head -12
 for f in f16_b64 f16x3_b64 fp32_b16 f16_b1 c5_f16_b64; do python - <<PY
 import json

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Per-position duration of the refinement tower's launches, from a rocprofv3 --kernel-trace CSV: the tower of one
+chunk is a fixed sequence of launches (6 residual blocks x 2 convs, the last one fused with the head); this prints,
+for each position of the sequence, the median / min / max duration over all chunks of the run.
+    python scripts/tower_sequence.py <kernel_trace.csv>"""
+import csv
+import re
+import sys
+from collections import defaultdict
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+ks = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows)
+seq = []
+for s, e, n in ks:
+    if "k_ref_conv_f16_v2" in n or "k_ref_conv_head_f16" in n or "k_refin_f16" in n:
+        m = re.search(r"k_ref_conv_f16_v2<(\d+), (\d+), (true|false)", n)
+        tag = "refin" if "k_refin" in n else ("head" if "head_f16" in n else f"dil{m.group(1)} tw{m.group(2)} res{int(m.group(3) == 'true')}")
+        seq.append((tag, (e - s) / 1e3))
+# split into chunks at every refin launch
+chunks, cur = [], []
+for tag, d in seq:
+    if tag == "refin":
+        if cur:
+            chunks.append(cur)
+        cur = []
+    cur.append((tag, d))
+if cur:
+    chunks.append(cur)
+full = max(len(c) for c in chunks)
+chunks = [c for c in chunks if len(c) == full][len(chunks) // 3:]
+print(f"{len(chunks)} chunks of {full} launches")
+tot = 0.0
+for i in range(full):
+    ds = sorted(c[i][1] for c in chunks)
+    tot += ds[len(ds) // 2]
+    print(f"  {i:2d} {chunks[0][i][0]:18s} med {ds[len(ds)//2]:7.1f} us   min {ds[0]:7.1f}   max {ds[-1]:7.1f}")
+print(f"  sum of medians {tot:.1f} us")
