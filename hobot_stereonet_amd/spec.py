@@ -21,6 +21,9 @@ REF_DILATIONS = (1, 2, 4, 8, 1, 1)
 LRELU_SLOPE = 0.2
 OUT_SCALE = 2.60443857769133e-6   # stereonet_node.cpp:282, publisher_member_function.py:29
 DEFAULT_W, DEFAULT_H, DEFAULT_D = 1280, 720, 192
+# Hierarchical ("multi") refinement, SURVEY.md appendix A: the same tower with SEPARATE weights applied at 1/8, 1/4, 1/2
+# and full resolution, x2 bilinear between the levels.  Level k works at 1/2^k resolution; level 0 is the `single` tower.
+MULTI_LEVELS = 4
 
 
 @dataclass(frozen=True)
@@ -45,8 +48,24 @@ class Layer:
         return self.w_numel // self.w_shape[0]
 
 
-def layers() -> List[Layer]:
-    """Canonical tensor order of the .snw weight file (weight, then bias, per layer)."""
+def ref_prefix(level: int) -> str:
+    """Name prefix of the refinement tower of `level` (0 = full resolution = the `single` tower)."""
+    return "ref" if level == 0 else f"ref{level}"
+
+
+def tower_layers(prefix: str) -> List[Layer]:
+    out: List[Layer] = [Layer(f"{prefix}.in", (C, 4, 3, 3), (C,))]
+    for i in range(N_REF_RES):
+        for j in (1, 2):
+            out.append(Layer(f"{prefix}.res{i}.{j}", (C, C, 3, 3), (C,)))
+    out.append(Layer(f"{prefix}.out", (1, C, 3, 3), (1,)))
+    return out
+
+
+def layers(levels: int = 1) -> List[Layer]:
+    """Canonical tensor order of the .snw weight file (weight, then bias, per layer).  `levels` > 1: the towers of
+    the coarser refinement levels 1 .. levels-1 follow the single-scale network, so a multi file starts with a
+    complete single file."""
     out: List[Layer] = []
     for i in range(N_DOWN):
         out.append(Layer(f"feat.down{i}", (C, 3 if i == 0 else C, 5, 5), (C,)))
@@ -57,19 +76,16 @@ def layers() -> List[Layer]:
     for i in range(N_AGG):
         out.append(Layer(f"agg.conv{i}", (C, C, 3, 3, 3), (C,)))
     out.append(Layer("agg.out", (1, C, 3, 3, 3), (1,)))
-    out.append(Layer("ref.in", (C, 4, 3, 3), (C,)))
-    for i in range(N_REF_RES):
-        for j in (1, 2):
-            out.append(Layer(f"ref.res{i}.{j}", (C, C, 3, 3), (C,)))
-    out.append(Layer("ref.out", (1, C, 3, 3), (1,)))
+    for level in range(levels):
+        out.extend(tower_layers(ref_prefix(level)))
     return out
 
 
-def offsets() -> dict:
+def offsets(levels: int = 1) -> dict:
     """name + '.w' / '.b' -> (offset, shape) into the flat fp32 blob."""
     off = 0
     table = {}
-    for l in layers():
+    for l in layers(levels):
         table[l.name + ".w"] = (off, l.w_shape)
         off += l.w_numel
         table[l.name + ".b"] = (off, l.b_shape)
@@ -78,15 +94,23 @@ def offsets() -> dict:
     return table
 
 
-def param_count() -> int:
-    return offsets()["__total__"][0]
+def param_count(levels: int = 1) -> int:
+    return offsets(levels)["__total__"][0]
+
+
+def levels_of(n_params: int) -> int:
+    """Refinement levels of a blob of n_params floats (1 or MULTI_LEVELS); ValueError otherwise."""
+    for lv in (1, MULTI_LEVELS):
+        if n_params == param_count(lv):
+            return lv
+    raise ValueError(f"{n_params} parameters match neither the single nor the multi SN-K4 network")
 
 
 def ceil16(v: int) -> int:
     return (v + 15) // 16 * 16
 
 
-def flops_per_pair(w: int, h: int, d: int, refine: bool = True) -> float:
+def flops_per_pair(w: int, h: int, d: int, refine: bool = True, levels: int = 1) -> float:
     """Algorithmic FLOPs (2*MAC, convs only) for one stereo pair — SURVEY.md appendix A."""
     wp, hp = ceil16(w), ceil16(h)
     wl, hl, dl = wp // 16, hp // 16, d // 16
@@ -97,5 +121,6 @@ def flops_per_pair(w: int, h: int, d: int, refine: bool = True) -> float:
     mac += 2 * (2 * N_FEAT_RES + 1) * wl * hl * C * C * 9
     mac += N_AGG * dl * hl * wl * C * C * 27 + dl * hl * wl * C * 27
     if refine:
-        mac += wp * hp * (4 * C * 9 + 2 * N_REF_RES * C * C * 9 + C * 9)
+        for k in range(levels):
+            mac += (wp * hp // 4 ** k) * (4 * C * 9 + 2 * N_REF_RES * C * C * 9 + C * 9)
     return 2.0 * mac

@@ -36,6 +36,9 @@ def lib():
         _lib.so_quantize.restype = C.c_int8
         _lib.so_quantize.argtypes = [C.c_float] * 5
         _lib.so_forward.restype = C.c_int
+        _lib.so_forward_levels.restype = C.c_int
+        _lib.so_weight_count_levels.restype = C.c_long
+        _lib.so_weight_count_levels.argtypes = [C.c_int]
     return _lib
 
 
@@ -53,6 +56,20 @@ def num_threads() -> int:
 
 def weight_count() -> int:
     return lib().so_weight_count()
+
+
+MULTI_LEVELS = 4
+
+
+def weight_count_levels(levels: int) -> int:
+    return lib().so_weight_count_levels(levels)
+
+
+def levels_of(weights: np.ndarray) -> int:
+    for lv in (1, MULTI_LEVELS):
+        if weights.size == weight_count_levels(lv):
+            return lv
+    raise ValueError(f"{weights.size} parameters: neither a single nor a multi blob")
 
 
 def weight_offset(name: str) -> int:
@@ -176,16 +193,44 @@ def refine(weights, disp_up, img, dmax):
     return out
 
 
-def forward(weights, in6, dmax):
-    """in6: int8 (6,h,w) -> (disp f32 (h,w), raw int32 (h,w), disp_low f32)"""
+def avgpool2(x):
+    x = _f32(x)
+    c, h, w = x.shape
+    out = np.empty((c, h // 2, w // 2), np.float32)
+    lib().so_avgpool2(_p(x), C.c_int(c), C.c_int(h), C.c_int(w), _p(out))
+    return out
+
+
+def refine_level(weights, level, disp_up, img, dnorm):
+    weights, disp_up, img = _f32(weights), _f32(disp_up), _f32(img)
+    hp, wp = disp_up.shape
+    out = np.empty((hp, wp), np.float32)
+    lib().so_refine_level(_p(weights), C.c_int(level), _p(disp_up), _p(img), C.c_int(hp), C.c_int(wp),
+                          C.c_float(dnorm), _p(out))
+    return out
+
+
+def forward_levels(weights, in6, dmax):
+    """in6: int8 (6,h,w) -> (disp f32 (h,w), raw int32 (h,w), disp_low f32, [level-1 map, level-2 map, ...]).
+    The number of refinement levels follows from the size of the weight blob (single: no level maps)."""
     weights = _f32(weights)
+    levels = levels_of(weights)
     in6 = np.ascontiguousarray(in6, dtype=np.int8)
     _, h, w = in6.shape
-    hl, wl = (h + 15) // 16, (w + 15) // 16
+    hp, wp = (h + 15) // 16 * 16, (w + 15) // 16 * 16
     disp = np.empty((h, w), np.float32)
     raw = np.empty((h, w), np.int32)
-    low = np.empty((hl, wl), np.float32)
-    rc = lib().so_forward(_p(weights), _p(in6), C.c_int(w), C.c_int(h), C.c_int(dmax), _p(disp), _p(raw), _p(low))
+    low = np.empty((hp // 16, wp // 16), np.float32)
+    maps = [np.empty((hp >> k, wp >> k), np.float32) for k in range(1, levels)]
+    ptrs = (C.c_void_p * max(1, len(maps)))(*[m.ctypes.data for m in maps]) if maps else None
+    rc = lib().so_forward_levels(_p(weights), C.c_int(levels), _p(in6), C.c_int(w), C.c_int(h), C.c_int(dmax),
+                                 _p(disp), _p(raw), _p(low), ptrs)
     if rc != 0:
-        raise ValueError("so_forward rejected its arguments")
+        raise ValueError("so_forward_levels rejected its arguments")
+    return disp, raw, low, maps
+
+
+def forward(weights, in6, dmax):
+    """in6: int8 (6,h,w) -> (disp f32 (h,w), raw int32 (h,w), disp_low f32); single or multi by the blob's size"""
+    disp, raw, low, _ = forward_levels(weights, in6, dmax)
     return disp, raw, low

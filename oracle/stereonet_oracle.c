@@ -152,7 +152,7 @@ typedef struct {
 
 static const int k_ref_dil[SO_NRRES] = {1, 2, 4, 8, 1, 1};
 
-#define SO_MAX_LAYERS 64
+#define SO_MAX_LAYERS 96
 typedef struct {
   char name[24];
   long w_off, w_n, b_off, b_n;
@@ -161,6 +161,7 @@ typedef struct {
 static layer_t g_layers[SO_MAX_LAYERS];
 static int g_nlayers = 0;
 static long g_total = 0;
+static long g_total_single = 0;   /* parameters of the single-scale network = offset of the first coarse tower */
 
 static void add_layer(const char *name, long nw, long nb) {
   layer_t *l = &g_layers[g_nlayers++];
@@ -192,18 +193,34 @@ static void build_table(void) {
     add_layer(nm, C * C * 27, C);
   }
   add_layer("agg.out", C * 27, 1);
-  add_layer("ref.in", C * 4 * 9, C);
-  for (int i = 0; i < SO_NRRES; ++i)
-    for (int j = 1; j <= 2; ++j) {
-      snprintf(nm, sizeof nm, "ref.res%d.%d", i, j);
-      add_layer(nm, C * C * 9, C);
-    }
-  add_layer("ref.out", C * 9, 1);
+  /* refinement towers: level 0 ("ref", full resolution = the `single` tower), then — only present in a `multi`
+   * blob — the towers of the coarser levels 1 .. SO_MULTI_LEVELS-1 ("ref1" = 1/2, "ref2" = 1/4, "ref3" = 1/8) */
+  for (int lv = 0; lv < SO_MULTI_LEVELS; ++lv) {
+    char pre[8];
+    if (lv == 0) snprintf(pre, sizeof pre, "ref");
+    else snprintf(pre, sizeof pre, "ref%d", lv);
+    snprintf(nm, sizeof nm, "%s.in", pre);
+    add_layer(nm, C * 4 * 9, C);
+    for (int i = 0; i < SO_NRRES; ++i)
+      for (int j = 1; j <= 2; ++j) {
+        snprintf(nm, sizeof nm, "%s.res%d.%d", pre, i, j);
+        add_layer(nm, C * C * 9, C);
+      }
+    snprintf(nm, sizeof nm, "%s.out", pre);
+    add_layer(nm, C * 9, 1);
+    if (lv == 0) g_total_single = g_total;
+  }
 }
 
 long so_weight_count(void) {
   build_table();
-  return g_total;
+  return g_total_single;
+}
+
+long so_weight_count_levels(int levels) {
+  build_table();
+  if (levels <= 1) return g_total_single;
+  return levels == SO_MULTI_LEVELS ? g_total : -1;
 }
 
 /* name is "<layer>.w" or "<layer>.b", e.g. "feat.res3.2.w" */
@@ -255,6 +272,22 @@ static void bind_net(const float *base, net_t *net) {
       net->rres[i][j] = get_conv(base, nm);
     }
   net->rout = get_conv(base, "ref.out");
+}
+
+/* the tower of refinement level `level` (0 = "ref") bound into the rin / rres / rout members */
+static void bind_tower(const float *base, int level, net_t *net) {
+  char pre[8], nm[24];
+  if (level == 0) snprintf(pre, sizeof pre, "ref");
+  else snprintf(pre, sizeof pre, "ref%d", level);
+  snprintf(nm, sizeof nm, "%s.in", pre);
+  net->rin = get_conv(base, nm);
+  for (int i = 0; i < SO_NRRES; ++i)
+    for (int j = 0; j < 2; ++j) {
+      snprintf(nm, sizeof nm, "%s.res%d.%d", pre, i, j + 1);
+      net->rres[i][j] = get_conv(base, nm);
+    }
+  snprintf(nm, sizeof nm, "%s.out", pre);
+  net->rout = get_conv(base, nm);
 }
 
 /* ======================================================================== */
@@ -456,12 +489,29 @@ void so_aggregate(const float *weights, const float *fl, const float *fr,
 
 void so_refine(const float *weights, const float *disp_up, const float *img,
                int hp, int wp, int dmax, float *disp) {
+  so_refine_level(weights, 0, disp_up, img, hp, wp, (float)dmax, disp);
+}
+
+/* 2x2 average pooling of c planes (h, w even): the image pyramid of the hierarchical refinement */
+void so_avgpool2(const float *in, int c, int h, int w, float *out) {
+  const int ho = h / 2, wo = w / 2;
+#pragma omp parallel for schedule(static)
+  for (int p = 0; p < c * ho; ++p) {
+    const int ch = p / ho, y = p - ch * ho;
+    const float *r0 = in + ((size_t)ch * h + 2 * y) * w, *r1 = r0 + w;
+    float *o = out + ((size_t)ch * ho + y) * wo;
+    for (int x = 0; x < wo; ++x) o[x] = ((r0[2 * x] + r0[2 * x + 1]) + (r1[2 * x] + r1[2 * x + 1])) * 0.25f;
+  }
+}
+
+void so_refine_level(const float *weights, int level, const float *disp_up, const float *img,
+                     int hp, int wp, float dnorm, float *disp) {
   net_t net;
-  bind_net(weights, &net);
+  bind_tower(weights, level, &net);
   const size_t plane = (size_t)hp * wp;
   const size_t n = (size_t)SO_C * plane;
   float *in4 = falloc(4 * plane);
-  const float inv_d = 1.0f / (float)dmax;
+  const float inv_d = 1.0f / dnorm;
 #pragma omp parallel for schedule(static)
   for (long i = 0; i < (long)plane; ++i) in4[i] = disp_up[i] * inv_d;
   memcpy(in4 + plane, img, 3 * plane * sizeof(float));
@@ -470,7 +520,7 @@ void so_refine(const float *weights, const float *disp_up, const float *img,
   so_lrelu(x, (long)n, SO_LRELU);
   for (int i = 0; i < SO_NRRES; ++i) res_block(net.rres[i], x, t1, t2, hp, wp, k_ref_dil[i]);
   so_conv2d(x, SO_C, hp, wp, net.rout.w, net.rout.b, 1, 3, 1, 1, 1, t1);
-  const float fd = (float)dmax;
+  const float fd = dnorm;
 #pragma omp parallel for schedule(static)
   for (long i = 0; i < (long)plane; ++i) {
     const float v = disp_up[i] + fd * t1[i];
@@ -484,6 +534,17 @@ void so_refine(const float *weights, const float *disp_up, const float *img,
  * (output 1x1xHxW int32, value*scale*16*12 = disparity in px). */
 int so_forward(const float *weights, const int8_t *in6, int w, int h, int dmax,
                float *disp, int32_t *raw, float *disp_low) {
+  return so_forward_levels(weights, 1, in6, w, h, dmax, disp, raw, disp_low, NULL);
+}
+
+/* levels = 1: single-scale refinement (x16 upsample, one tower).  levels = SO_MULTI_LEVELS: hierarchical refinement
+ * (SURVEY.md appendix A `multi`): for k = levels-1 .. 0, at 1/2^k resolution,
+ *     up_k = bilinear_x2(d_{k+1}) * 2,   img_k = avgpool_{2^k}(left planes),   D_k = D / 2^k,
+ *     d_k  = relu(up_k + D_k * tower_k(cat[up_k / D_k, img_k])),               d_levels = soft-argmin map.
+ * level_maps (nullable): levels-1 pointers, level_maps[k-1] receives d_k (hp/2^k x wp/2^k) for k >= 1. */
+int so_forward_levels(const float *weights, int levels, const int8_t *in6, int w, int h, int dmax,
+                      float *disp, int32_t *raw, float *disp_low, float *const *level_maps) {
+  if (levels != 1 && levels != SO_MULTI_LEVELS) return -1;
   if (!weights || !in6 || w <= 0 || h <= 0 || dmax < 16 || dmax % 16) return -1;
   const int wp = (w + 15) / 16 * 16, hp = (h + 15) / 16 * 16;
   const int wl = wp / 16, hl = hp / 16, dl = dmax / 16;
@@ -503,8 +564,30 @@ int so_forward(const float *weights, const int8_t *in6, int w, int h, int dmax,
   so_soft_argmin(cost, dl, hl, wl, dlow);
   if (disp_low) memcpy(disp_low, dlow, (size_t)hl * wl * sizeof(float));
   float *dup = falloc(pp), *dfull = falloc(pp);
-  so_upsample_bilinear(dlow, hl, wl, 16, 16.0f, dup);
-  so_refine(weights, dup, planes, hp, wp, dmax, dfull);
+  if (levels == 1) {
+    so_upsample_bilinear(dlow, hl, wl, 16, 16.0f, dup);
+    so_refine(weights, dup, planes, hp, wp, dmax, dfull);
+  } else {
+    /* image pyramid of the left eye: pyr[k] = 3 x hp/2^k x wp/2^k */
+    float *pyr[SO_MULTI_LEVELS];
+    pyr[0] = planes;
+    for (int k = 1; k < levels; ++k) {
+      pyr[k] = falloc((size_t)3 * (hp >> k) * (wp >> k));
+      so_avgpool2(pyr[k - 1], 3, hp >> (k - 1), wp >> (k - 1), pyr[k]);
+    }
+    float *prev = falloc(pp), *cur = falloc(pp);
+    memcpy(prev, dlow, (size_t)hl * wl * sizeof(float));
+    for (int k = levels - 1; k >= 0; --k) {
+      const int hk = hp >> k, wk = wp >> k;
+      so_upsample_bilinear(prev, hk / 2, wk / 2, 2, 2.0f, dup);
+      so_refine_level(weights, k, dup, pyr[k], hk, wk, (float)dmax / (float)(1 << k), cur);
+      if (k >= 1 && level_maps && level_maps[k - 1]) memcpy(level_maps[k - 1], cur, (size_t)hk * wk * sizeof(float));
+      float *t = prev; prev = cur; cur = t;
+    }
+    memcpy(dfull, prev, pp * sizeof(float));
+    for (int k = 1; k < levels; ++k) free(pyr[k]);
+    free(prev); free(cur);
+  }
   /* wire format: raw = lrintf(disp * inv_q), inv_q = float(1 / (16 * 12 * scale)) for EVERY dmax: every consumer of
    * the tensor multiplies by the literal 16 * 12 (parser.cpp:86, stereonet_node.cpp:288, publisher_member_function.py:75) */
   const float inv_q = (float)(1.0 / (16.0 * 12.0 * (double)SO_OUT_SCALE));

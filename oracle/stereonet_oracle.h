@@ -34,6 +34,7 @@ extern "C" {
 #define SO_NFRES 6         /* feature-tower residual blocks                 */
 #define SO_NAGG 4          /* 3-D aggregation convs (C→C)                   */
 #define SO_NRRES 6         /* refinement residual blocks                    */
+#define SO_MULTI_LEVELS 4  /* hierarchical refinement: towers at 1/8, 1/4, 1/2, 1  */
 #define SO_LRELU 0.2f
 #define SO_OUT_SCALE 2.60443857769133e-6f   /* stereonet_node.cpp:282, render.py:29 */
 
@@ -71,8 +72,11 @@ void so_dequant_depth(const int32_t *raw, int n, float scale, float dmax,
  * order (each layer = weight then bias):
  *   feat.down0..3  feat.res0..5.{1,2}  feat.out
  *   agg.conv0..3   agg.out
- *   ref.in         ref.res0..5.{1,2}   ref.out                                  */
-long so_weight_count(void);          /* = 423586 */
+ *   ref.in         ref.res0..5.{1,2}   ref.out
+ * a hierarchical ("multi") blob continues with the towers of the coarser levels, same layer list each:
+ *   ref1.* (1/2 resolution)   ref2.* (1/4)   ref3.* (1/8)                       */
+long so_weight_count(void);          /* = 423586 (single-scale network) */
+long so_weight_count_levels(int levels);   /* 1 -> 423586, SO_MULTI_LEVELS -> 760933, else -1 */
 long so_weight_offset(const char *name);   /* "<layer>.w|b", e.g. "feat.res3.2.w", "agg.out.b"; -1 if unknown */
 
 /* ---- network: primitive ops (NCHW fp32, zero padding) ------------------ */
@@ -101,6 +105,16 @@ void so_refine(const float *weights, const float *disp_up, const float *img,
  * soft-argmin output (units of low-res px). Returns 0, or -1 on bad args. */
 int so_forward(const float *weights, const int8_t *in6, int w, int h, int dmax,
                float *disp, int32_t *raw, float *disp_low);
+
+/* Hierarchical refinement pieces: 2x2 average pooling (image pyramid), one refinement level with the tower named
+ * ref<level> (0 = "ref") normalised by dnorm = D / 2^level, and the whole path with `levels` refinement levels
+ * (1 = so_forward; SO_MULTI_LEVELS = `multi`, weights = the longer blob).  level_maps: NULL, or levels-1 pointers;
+ * level_maps[k-1] receives the level-k map (hp/2^k x wp/2^k, level-k pixel units), k = 1 .. levels-1. */
+void so_avgpool2(const float *in, int c, int h, int w, float *out);
+void so_refine_level(const float *weights, int level, const float *disp_up, const float *img,
+                     int hp, int wp, float dnorm, float *disp);
+int so_forward_levels(const float *weights, int levels, const int8_t *in6, int w, int h, int dmax,
+                      float *disp, int32_t *raw, float *disp_low, float *const *level_maps);
 
 int so_num_threads(void);
 

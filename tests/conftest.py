@@ -28,6 +28,19 @@ def weights_blob():
 
 
 @pytest.fixture(scope="session")
+def weights_multi():
+    """Seed-0 blob of the hierarchical-refinement (`multi`) network: starts with weights_blob."""
+    from hobot_stereonet_amd import spec, weights
+    return weights.synthetic(0, spec.MULTI_LEVELS)
+
+
+@pytest.fixture(scope="session")
+def golden_multi():
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "network_multi_golden.npz"))
+
+
+@pytest.fixture(scope="session")
 def golden_net():
     import numpy as np
     return np.load(os.path.join(ROOT, "tests", "golden", "network_golden.npz"))
@@ -41,15 +54,15 @@ def golden_pre():
 
 @pytest.fixture(scope="session")
 def model_factory(tmp_path_factory, weights_blob):
-    """-> f(w, h, d) -> path of an SNW1 model file with seed-0 synthetic weights."""
-    from hobot_stereonet_amd import weights
+    """-> f(w, h, d, multi=False) -> path of an SNW1 model file with seed-0 synthetic weights."""
+    from hobot_stereonet_amd import spec, weights
     made = {}
 
-    def make(w, h, d):
-        key = (w, h, d)
+    def make(w, h, d, multi=False):
+        key = (w, h, d, multi)
         if key not in made:
-            p = str(tmp_path_factory.mktemp("models") / f"sn_{w}x{h}_d{d}.snw")
-            weights.save_snw(p, weights_blob, w, h, d)
+            p = str(tmp_path_factory.mktemp("models") / f"sn_{w}x{h}_d{d}{'_multi' if multi else ''}.snw")
+            weights.save_snw(p, weights.synthetic(0, spec.MULTI_LEVELS) if multi else weights_blob, w, h, d)
             made[key] = p
         return made[key]
 

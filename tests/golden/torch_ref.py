@@ -58,13 +58,27 @@ def soft_argmin(cost):                   # (1,dl,h,w) -> (1,h,w)
     return (p * d).sum(1)
 
 
-def refine(blob, disp_up, img, dmax):    # (1,1,hp,wp), (1,3,hp,wp)
+def refine(blob, disp_up, img, dmax, prefix="ref"):    # (1,1,hp,wp), (1,3,hp,wp)
     x = torch.cat([disp_up / dmax, img], 1)
-    x = lrelu(F.conv2d(x, _t(blob, "ref.in.w"), _t(blob, "ref.in.b"), padding=1))
+    x = lrelu(F.conv2d(x, _t(blob, prefix + ".in.w"), _t(blob, prefix + ".in.b"), padding=1))
     for i, dil in enumerate(spec.REF_DILATIONS):
-        x = res_block(blob, f"ref.res{i}", x, dil)
-    r = F.conv2d(x, _t(blob, "ref.out.w"), _t(blob, "ref.out.b"), padding=1)
+        x = res_block(blob, f"{prefix}.res{i}", x, dil)
+    r = F.conv2d(x, _t(blob, prefix + ".out.w"), _t(blob, prefix + ".out.b"), padding=1)
     return F.relu(disp_up + dmax * r)
+
+
+def refine_multi(blob, low, img, dmax, levels):
+    """Hierarchical refinement (`multi`): level k = levels-1 .. 0 works at 1/2^k resolution on
+    the x2 bilinear upsample (values x2) of the level below (the soft-argmin map for the coarsest level), the left image
+    average-pooled by 2^k, its own tower weights and D / 2^k as the disparity normalisation."""
+    d = low[:, None] * (16.0 / 2 ** levels)          # soft-argmin map in 1/2^levels-resolution pixel units
+    per_level = []
+    for k in range(levels - 1, -1, -1):
+        up = F.interpolate(d, scale_factor=2, mode="bilinear", align_corners=False) * 2.0
+        img_k = F.avg_pool2d(img, 2 ** k) if k else img
+        d = refine(blob, up, img_k, dmax / 2 ** k, spec.ref_prefix(k))
+        per_level.append(d[0, 0].numpy().copy())
+    return d, per_level
 
 
 def forward(blob, in6: np.ndarray, dmax: int):
@@ -78,7 +92,12 @@ def forward(blob, in6: np.ndarray, dmax: int):
         fr = features(blob, x[:, 3:])
         cost = aggregate(blob, fl, fr, dmax // 16)
         low = soft_argmin(cost)
-        up = F.interpolate(low[:, None], scale_factor=16, mode="bilinear", align_corners=False) * 16.0
-        disp = refine(blob, up, x[:, :3], dmax)
-    return {"disp": disp[0, 0, :h, :w].numpy().copy(), "disp_low": low[0].numpy().copy(),
+        levels = spec.levels_of(blob.size)
+        per_level = []
+        if levels == 1:
+            up = F.interpolate(low[:, None], scale_factor=16, mode="bilinear", align_corners=False) * 16.0
+            disp = refine(blob, up, x[:, :3], dmax)
+        else:
+            disp, per_level = refine_multi(blob, low, x[:, :3], dmax, levels)
+    return {"levels": per_level, "disp": disp[0, 0, :h, :w].numpy().copy(), "disp_low": low[0].numpy().copy(),
             "cost": cost[0].numpy().copy(), "fl": fl[0].numpy().copy(), "fr": fr[0].numpy().copy()}

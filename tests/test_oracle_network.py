@@ -45,6 +45,52 @@ def test_forward_matches_golden(oracle, golden_net, weights_blob, name, w, h, d,
     assert raw.min() >= 0     # uint32 and int32 views agree (appendix B-5)
 
 
+def test_multi_weight_table_and_file_format(oracle, weights_blob, weights_multi, tmp_path):
+    """A hierarchical (`multi`) blob = the single blob + the towers of levels 1..3."""
+    assert oracle.weight_count_levels(1) == spec.param_count(1)
+    assert oracle.weight_count_levels(spec.MULTI_LEVELS) == spec.param_count(spec.MULTI_LEVELS) == 760933
+    assert oracle.weight_count_levels(2) == -1
+    for name, (off, _) in spec.offsets(spec.MULTI_LEVELS).items():
+        if name != "__total__":
+            assert oracle.weight_offset(name) == off, name
+    assert np.array_equal(weights_multi[:weights_blob.size], weights_blob)
+    p = str(tmp_path / "m.snw")
+    weights.save_snw(p, weights_multi, 96, 64, 48)
+    blob, meta = weights.load_snw(p)
+    assert meta == {"width": 96, "height": 64, "dmax": 48, "levels": spec.MULTI_LEVELS} and np.array_equal(blob, weights_multi)
+    with pytest.raises(ValueError):
+        weights.save_snw(p, weights_multi[:-1], 96, 64, 48)
+    assert abs(spec.flops_per_pair(1280, 720, 192, levels=4) / 1e9 - 295.56) < 0.01      # SURVEY.md appendix A table
+    assert abs(spec.flops_per_pair(1242, 375, 256, levels=4) / 1e9 - 155.36) < 0.01
+
+
+@pytest.mark.parametrize("name,w,h,d,seed", CASES)
+def test_multi_forward_matches_golden(oracle, golden_multi, weights_multi, name, w, h, d, seed):
+    assert sha(weights_multi) == str(golden_multi["weights_sha256"])
+    x = synth.model_input_i8(w, h, d, seed)
+    assert sha(x) == str(golden_multi[name + ".input_sha256"])
+    disp, raw, low, maps = oracle.forward_levels(weights_multi, x, d)
+    assert len(maps) == spec.MULTI_LEVELS - 1
+    assert np.abs(low - golden_multi[name + ".disp_low"]).max() < 2e-5
+    for k, m in enumerate(maps, start=1):                     # level k works at 1/2^k resolution
+        gk = golden_multi[f"{name}.level{k}"]
+        assert m.shape == gk.shape == (spec.ceil16(h) >> k, spec.ceil16(w) >> k)
+        assert np.abs(m - gk).mean() < TOL and np.abs(m - gk).max() < 20 * TOL
+    assert np.abs(disp - golden_multi[name + ".disp"]).mean() < TOL
+    assert np.abs(disp - golden_multi[name + ".disp"]).max() < 20 * TOL
+    q = 192 * spec.OUT_SCALE
+    assert np.abs(raw.astype(np.float64) * q - disp).max() <= 0.52 * q + 2e-6 and raw.min() >= 0
+    # the hierarchy is not a no-op: it differs from the single-scale result of the same leading weights
+    single, _, _ = oracle.forward(weights_multi[:spec.param_count()], x, d)
+    assert np.abs(single - disp).mean() > 0.05
+
+
+def test_multi_ops_match_golden(oracle, golden_multi):
+    g = golden_multi
+    np.testing.assert_allclose(oracle.upsample_bilinear(g["op.up2.x"], 2, 2.0), g["op.up2.y"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(oracle.avgpool2(g["op.pool.x"]), g["op.pool.y"], rtol=1e-6, atol=1e-6)
+
+
 def test_ops_match_golden(oracle, golden_net):
     g = golden_net
     x = g["op.conv2d.x"]
@@ -90,7 +136,7 @@ def test_snw_roundtrip(tmp_path, weights_blob):
     p = str(tmp_path / "m.snw")
     weights.save_snw(p, weights_blob, 1280, 720, 192)
     blob, meta = weights.load_snw(p)
-    assert (blob == weights_blob).all() and meta == {"width": 1280, "height": 720, "dmax": 192}
+    assert (blob == weights_blob).all() and meta == {"width": 1280, "height": 720, "dmax": 192, "levels": 1}
     with open(p, "r+b") as f:
         f.write(b"XXXX")
     with pytest.raises(ValueError):
