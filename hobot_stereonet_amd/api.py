@@ -33,7 +33,7 @@ class SnIoInfo(C.Structure):
                 ("max_batch", C.c_int), ("precision", C.c_int), ("task_num", C.c_int), ("device", C.c_int),
                 ("out_scale", C.c_float), ("in_bytes", C.c_size_t), ("out_bytes", C.c_size_t),
                 ("flops_per_pair", C.c_double), ("refine_chunk", C.c_int), ("piece", C.c_int),
-                ("tower_streams", C.c_int), ("reserved", C.c_int)]
+                ("tower_streams", C.c_int), ("refine_levels", C.c_int)]
 
 
 class StereoNetError(RuntimeError):
@@ -137,6 +137,7 @@ class StereoNetHIP:
         self.width, self.height, self.dmax = info.width, info.height, info.dmax
         self.max_batch = info.max_batch
         self.refine_chunk, self.piece, self.tower_streams = info.refine_chunk, info.piece, info.tower_streams
+        self.refine_levels = info.refine_levels
         self.out_scale = float(info.out_scale)
         self.flops_per_pair = float(info.flops_per_pair)
 

@@ -202,10 +202,16 @@ __global__ __launch_bounds__(256) void k_cost_slots(const float* __restrict__ fe
   o[plane] = *reinterpret_cast<const uint4*>(&lo);
 }
 
-// bilinear x16, align_corners=False, values x16 (disparity in full-res px)
-__device__ __forceinline__ float upsample16(const float* low, int hl, int wl, int y, int x) {
-  float sy = ((float)y + 0.5f) * (1.0f / 16.0f) - 0.5f;
-  float sx = ((float)x + 0.5f) * (1.0f / 16.0f) - 0.5f;
+// Scale of the bilinear upsample that feeds a refinement level: single-scale refinement reads the soft-argmin map
+// x16 ({1/16, 16}); every level of the hierarchical refinement reads the map of the level below x2 ({1/2, 2}).
+struct UpScale {
+  float rs, mul;            // 1 / factor, factor (the values are disparities in pixels of the finer grid)
+};
+
+// bilinear upsample, align_corners=False (half-pixel centres, edge clamp), values x factor
+__device__ __forceinline__ float upsample_map(const float* low, int hl, int wl, int y, int x, UpScale u) {
+  float sy = ((float)y + 0.5f) * u.rs - 0.5f;
+  float sx = ((float)x + 0.5f) * u.rs - 0.5f;
   sy = sy < 0.f ? 0.f : sy;
   sx = sx < 0.f ? 0.f : sx;
   const int y0 = (int)sy, x0 = (int)sx;
@@ -214,22 +220,58 @@ __device__ __forceinline__ float upsample16(const float* low, int hl, int wl, in
   const float hy = 1.0f - ly, hx = 1.0f - lx;
   const float v = hy * (hx * low[y0 * wl + x0] + lx * low[y0 * wl + x1]) +
                   ly * (hx * low[y1 * wl + x0] + lx * low[y1 * wl + x1]);
-  return v * 16.0f;
+  return v * u.mul;
 }
 
-// Refinement input: channel 0 = upsampled disparity / D, channels 1..3 = left image planes.
+// Refinement input: channel 0 = upsampled disparity / D, channels 1..3 = left image planes — the int8 model input
+// (full resolution) or, for the coarser levels of the hierarchical refinement, the float image pyramid.
 struct LoadRefineIn {
   const float* disp_low;    // [n][hl][wl]
   const int8_t* in6;        // [n][6][H][W]
   int hl, wl, H, W, Hp, Wp;
   float inv_d;
+  UpScale up;
+  const float* pyr;         // nullptr, or [n][3][Hp][Wp] average-pooled left planes of this level
   __device__ __forceinline__ float operator()(int img, int c, int y, int x) const {
     if ((unsigned)y >= (unsigned)Hp || (unsigned)x >= (unsigned)Wp || c >= 4) return 0.f;
-    if (c == 0) return upsample16(disp_low + (size_t)img * hl * wl, hl, wl, y, x) * inv_d;
+    if (c == 0) return upsample_map(disp_low + (size_t)img * hl * wl, hl, wl, y, x, up) * inv_d;
+    if (pyr) return pyr[(((size_t)img * 3 + (c - 1)) * Hp + y) * Wp + x];
     if (y >= H || x >= W) return 0.f;
     return (float)in6[(((size_t)img * 6 + (c - 1)) * H + y) * W + x] * (1.0f / 128.0f);
   }
 };
+
+// Image pyramid of the hierarchical refinement: 2x2 average pooling of the LEFT eye's three planes.
+// FIRST = true: source = int8 model input [n][6][H][W] (v / 128, zero outside H x W), output [n][3][Ho][Wo] with
+// Ho = Hp / 2; otherwise source = the float level above, [n][3][2 Ho][2 Wo].  All values are small integers over a
+// power of two, so the sums are exact in fp32 and the order of the additions does not matter.
+template <bool FIRST>
+__global__ __launch_bounds__(256) void k_img_pool2(const void* __restrict__ src, int H, int W, int Ho, int Wo,
+                                                   float* __restrict__ out, long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int x = (int)(i % Wo);
+  long t = i / Wo;
+  const int y = (int)(t % Ho);
+  t /= Ho;
+  const int c = (int)(t % 3), n = (int)(t / 3);
+  float s = 0.f;
+  if (FIRST) {
+    const int8_t* p = reinterpret_cast<const int8_t*>(src) + ((size_t)n * 6 + c) * H * (size_t)W;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const int yy = 2 * y + dy, xx = 2 * x + dx;
+        if (yy < H && xx < W) s += (float)p[(size_t)yy * W + xx];
+      }
+    s *= 1.0f / 512.0f;
+  } else {
+    const float* p = reinterpret_cast<const float*>(src) + (((size_t)n * 3 + c) * (2 * Ho) + 2 * y) * (size_t)(2 * Wo) + 2 * x;
+    s = ((p[0] + p[1]) + (p[2 * Wo] + p[2 * Wo + 1])) * 0.25f;
+  }
+  out[i] = s;
+}
 
 // ------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution, C_out = 32, on the exact-fp32 matrix core.
@@ -1015,7 +1057,8 @@ __global__ __launch_bounds__(256) void k_head_final(const float* __restrict__ xi
                                                     int hl, int wl, int Hp, int Wp, int H, int W,
                                                     float dmax, float inv_q,
                                                     float* __restrict__ out_disp,       // nullable [n][H][W]
-                                                    int32_t* __restrict__ out_raw) {    // nullable [n][H][W]
+                                                    int32_t* __restrict__ out_raw,      // nullable [n][H][W]
+                                                    UpScale ups) {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
   const int n = blockIdx.z;
@@ -1038,7 +1081,7 @@ __global__ __launch_bounds__(256) void k_head_final(const float* __restrict__ xi
       }
     }
   }
-  const float up = upsample16(disp_low + (size_t)n * hl * wl, hl, wl, y, x);
+  const float up = upsample_map(disp_low + (size_t)n * hl * wl, hl, wl, y, x, ups);
   float d = up + dmax * acc;
   d = d > 0.f ? d : 0.f;
   const size_t o = ((size_t)n * H + y) * W + x;
@@ -1446,7 +1489,7 @@ __global__ __launch_bounds__(256, 2) void k_ref_conv_head_f16(const uint4* __res
                                                               RefGeom g, int nimg, unsigned* tile_ctr,
                                                               const float* __restrict__ hw,      // head weights [32][9]
                                                               float hbias, const float* __restrict__ disp_low, int hl,
-                                                              int wl, int H, int W, float dmax, float inv_q,
+                                                              int wl, int H, int W, float dmax, float inv_q, UpScale ups,
                                                               float* out_disp, int32_t* out_raw, unsigned* dump) {
   constexpr int DIL = 1, TW = 64, TH = 8, NB = 3;
   using T = RefTile2<DIL, TW, TH, NB>;
@@ -1631,8 +1674,8 @@ __global__ __launch_bounds__(256, 2) void k_ref_conv_head_f16(const uint4* __res
       int Y = y0 + 1 + (opy[k] < 0 ? 0 : opy[k]), X = x0 + 1 + opx[k];
       Y = Y < H ? Y : H - 1;
       X = X < W ? X : W - 1;
-      float sy = ((float)Y + 0.5f) * (1.0f / 16.0f) - 0.5f;
-      float sx = ((float)X + 0.5f) * (1.0f / 16.0f) - 0.5f;
+      float sy = ((float)Y + 0.5f) * ups.rs - 0.5f;
+      float sx = ((float)X + 0.5f) * ups.rs - 0.5f;
       sy = sy < 0.f ? 0.f : sy;
       sx = sx < 0.f ? 0.f : sx;
       const int yy0 = (int)sy, xx0 = (int)sx;
@@ -1717,13 +1760,13 @@ __global__ __launch_bounds__(256, 2) void k_ref_conv_head_f16(const uint4* __res
       const int Y = y0 + 1 + oy, X = x0 + 1 + ox;
       const bool ok = opy[k] >= 0 && Y < H && X < W;
       // bilinear weights of (Y, X) (the same arithmetic as at the loads above; out-of-image lanes are discarded)
-      float sy = ((float)(Y < H ? Y : H - 1) + 0.5f) * (1.0f / 16.0f) - 0.5f;
-      float sx = ((float)(X < W ? X : W - 1) + 0.5f) * (1.0f / 16.0f) - 0.5f;
+      float sy = ((float)(Y < H ? Y : H - 1) + 0.5f) * ups.rs - 0.5f;
+      float sx = ((float)(X < W ? X : W - 1) + 0.5f) * ups.rs - 0.5f;
       sy = sy < 0.f ? 0.f : sy;
       sx = sx < 0.f ? 0.f : sx;
       const float ly = sy - (float)(int)sy, lx = sx - (float)(int)sx;
       const float hy = 1.0f - ly, hx = 1.0f - lx;
-      const float up = (hy * (hx * uv[4 * k] + lx * uv[4 * k + 1]) + ly * (hx * uv[4 * k + 2] + lx * uv[4 * k + 3])) * 16.0f;
+      const float up = (hy * (hx * uv[4 * k] + lx * uv[4 * k + 1]) + ly * (hx * uv[4 * k + 2] + lx * uv[4 * k + 3])) * ups.mul;
       float d = up + dmax * r;
       d = d > 0.f ? d : 0.f;
       const size_t o = (size_t)img * HWo + (size_t)Y * W + X;
@@ -2247,6 +2290,11 @@ __global__ __launch_bounds__(256, 1) void k_ref_conv_f16x3(const uint4* __restri
 // Staging: one thread builds 4 consecutive pixels (three aligned dword loads of int8 + four upsample evaluations)
 // for the next tile while the MFMAs of the current one run; persistent workgroups, LDS double buffered.
 // SPLIT = true writes the hi/lo pair of tensors of SN_PREC_F16X3.
+// PYR = true (coarser levels of the hierarchical refinement): the image planes come from the float pyramid
+// [n][3][g.H][g.W]; their values are not exact in fp16, so the slot carries them as hi/lo pairs too,
+//     [d_hi, Y_hi, U_hi, V_hi, d_lo, Y_lo, U_lo, V_lo]
+// and fragment b of the weights holds the hi weights at entries 4..7 (for the int8 source entries 5..7 are zero).
+// The disparity comes from `disp_low` upsampled by `ups` (x16 from the soft-argmin map, x2 from the level below).
 // ------------------------------------------------------------------------------------------
 struct RefInTile {
   static constexpr int TH = 8, TW = 64;
@@ -2257,10 +2305,10 @@ struct RefInTile {
   static constexpr int SPW = TH * (TW / 32) / 4;
 };
 
-template <bool SPLIT>
+template <bool SPLIT, bool PYR>
 __global__ __launch_bounds__(256) void k_refin_f16(const float* __restrict__ disp_low,   // [n][hl][wl]
-                                                   const int8_t* __restrict__ in6,       // [n][6][H][W]
-                                                   int hl, int wl, int H, int W, float inv_d,
+                                                   const void* __restrict__ img_src,     // int8 [n][6][H][W] / PYR: float [n][3][g.H][g.W]
+                                                   int hl, int wl, int H, int W, float inv_d, UpScale ups,
                                                    const uint4* __restrict__ wfrag,      // [5][a|b][64]
                                                    const float* __restrict__ bias, uint4* __restrict__ out,
                                                    size_t lo_off_bytes, RefGeom g, int nimg, int al4) {
@@ -2294,7 +2342,10 @@ __global__ __launch_bounds__(256) void k_refin_f16(const float* __restrict__ dis
   // staging unit of this thread: row ur of the window, pixels 4*uq .. 4*uq+3
   const int ur = tid / (T::COLS / 4), uq = tid - ur * (T::COLS / 4);
   const bool unit = tid < T::NUNIT;
+  const int8_t* const in6 = reinterpret_cast<const int8_t*>(img_src);
+  const float* const pyr = reinterpret_cast<const float*>(img_src);
   uint32_t pimg[3];
+  float pf[PYR ? 3 : 1][4];
   float pd[4];
   bool pval[4];
   auto fetch = [&](int tile) {
@@ -2312,9 +2363,16 @@ __global__ __launch_bounds__(256) void k_refin_f16(const float* __restrict__ dis
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       pval[k] = (unsigned)(x + k) < (unsigned)g.W;
-      if (pval[k]) pd[k] = upsample16(dl, hl, wl, y, x + k) * inv_d;
+      if (pval[k]) pd[k] = upsample_map(dl, hl, wl, y, x + k, ups) * inv_d;
     }
-    if (y < H) {
+    if (PYR) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float* row = pyr + (((size_t)img * 3 + c) * g.H + y) * (size_t)g.W;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pf[PYR ? c : 0][k] = pval[k] ? row[x + k] : 0.f;
+      }
+    } else if (y < H) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const int8_t* row = in6 + (((size_t)img * 6 + c) * H + y) * (size_t)W;
@@ -2341,8 +2399,18 @@ __global__ __launch_bounds__(256) void k_refin_f16(const float* __restrict__ dis
         const _Float16 dh = (_Float16)pd[k];
         sl[0] = dh;
         sl[4] = (_Float16)((pd[k] - (float)dh) * kSplitScale);
+        if (PYR) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) sl[1 + c] = (_Float16)((float)(int8_t)(pimg[c] >> (8 * k)) * (1.0f / 128.0f));
+          for (int c = 0; c < 3; ++c) {
+            const float v = pf[PYR ? c : 0][k];
+            const _Float16 vh = (_Float16)v;
+            sl[1 + c] = vh;
+            sl[5 + c] = (_Float16)((v - (float)vh) * kSplitScale);
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) sl[1 + c] = (_Float16)((float)(int8_t)(pimg[c] >> (8 * k)) * (1.0f / 128.0f));
+        }
       }
       buf[ur * T::COLS + 4 * uq + k] = *reinterpret_cast<const uint4*>(&sl);
     }
@@ -2441,7 +2509,7 @@ __global__ __launch_bounds__(256) void k_head_final_f16(const uint4* __restrict_
                                                         float bias, const float* __restrict__ disp_low, int hl,
                                                         int wl, int H, int W, float dmax, float inv_q,
                                                         float* __restrict__ out_disp, int32_t* __restrict__ out_raw,
-                                                        int tiles_x, int tiles_y) {
+                                                        int tiles_x, int tiles_y, UpScale ups) {
   using T = HeadTile<TH>;
   extern __shared__ __attribute__((aligned(16))) float s_p[];           // [9][RP][CP]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -2517,7 +2585,7 @@ __global__ __launch_bounds__(256) void k_head_final_f16(const uint4* __restrict_
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) acc += s_p[(ky * 3 + kx) * T::PLANE + (oy + ky) * T::CP + ox + kx];
-    const float up = upsample16(dl, hl, wl, y, x);
+    const float up = upsample_map(dl, hl, wl, y, x, ups);
     float d = up + dmax * acc;
     d = d > 0.f ? d : 0.f;
     const size_t o = ((size_t)n * H + y) * W + x;

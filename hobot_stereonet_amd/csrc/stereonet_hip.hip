@@ -61,6 +61,7 @@ struct HeadLayer {          // C -> 1 layers (VALU kernels)
   float bias = 0.f;
 };
 
+constexpr int kMaxLevels = 4, kMultiLevels = 4;              // hierarchical refinement: 1/8, 1/4, 1/2, 1
 constexpr int kTileCtrStride = 8 * 16;                       // uints per tower launch (one 64-B line per XCD)
 constexpr size_t kTileCtrBytes = (size_t)2 * 6 * kTileCtrStride * sizeof(unsigned);   // 2 * kNRefRes launches
 
@@ -76,11 +77,26 @@ struct Workspace {          // activations for up to `nb` pairs
   int ns = 1;                 // tower streams this workspace serves: one (x, t) activation pair per stream
   float* ref[2 * kMaxTowerStreams] = {};
   uint4* ref16[2 * kMaxTowerStreams] = {};   // fp16 NCHW8c padded (fp16 modes): [2 * stream + {x, t}]
+  // hierarchical refinement, levels 1..: activation pairs (their own zero borders), image pyramid [rb][3][Hk][Wk]
+  // and level disparity maps [rb][Hk][Wk], one set per tower stream
+  float* ref_lv[kMaxLevels][2 * kMaxTowerStreams] = {};
+  uint4* ref16_lv[kMaxLevels][2 * kMaxTowerStreams] = {};
+  float* pyr[kMaxLevels][kMaxTowerStreams] = {};
+  float* lvl_disp[kMaxLevels][kMaxTowerStreams] = {};
   int n_chunks = 0;
   unsigned* tile_ctr = nullptr;           // dynamic tile queues of the fp16 tower: [12 launches][8 XCDs][16] uints
   float* out_disp = nullptr;
   int32_t* out_raw = nullptr;
   uint8_t* nv12 = nullptr;   // staging for NV12 inputs (2 eyes or one side-by-side frame)
+};
+
+struct Tower {               // one refinement level: weights (in the forms the precision mode needs) + geometry
+  ConvLayer rin, rres[kNRefRes][2];
+  Down0F16 refin;
+  RefLayerF16 rres16[kNRefRes][2];
+  HeadLayer rout;
+  RefGeom rg{};
+  int Hk = 0, Wk = 0;        // padded size of this level: Hp >> k, Wp >> k
 };
 
 struct Slot {                // async request slot (sn_submit / sn_wait)
@@ -118,11 +134,13 @@ struct sn_handle {
   bool head_fuse = true;     // last tower conv + head in one kernel (fp16 mode; SN_HEAD_FUSE=0 separates them)
   unsigned* dump = nullptr;  // 2 KB device scratch: where lanes without an output pixel store (fused head)
   bool use_graphs = true;    // hipGraph replay for the async single-pair path (SN_NO_GRAPH disables)
-  ConvLayer down[kNDown], fres[kNFeatRes][2], fout, agg[kNAgg], rin, rres[kNRefRes][2];
-  Down0F16 down0, refin;
-  HeadLayer aout, rout;
-  RefLayerF16 rres16[kNRefRes][2];
-  RefGeom rg{};
+  ConvLayer down[kNDown], fres[kNFeatRes][2], fout, agg[kNAgg];
+  Down0F16 down0;
+  HeadLayer aout;
+  // refinement towers: tw[0] = full resolution (the only one of a single-scale model); a hierarchical ("multi") model
+  // has levels = kMultiLevels towers, tw[k] working at 1/2^k resolution
+  int levels = 1;
+  Tower tw[kMaxLevels];
   int num_cu = 256;
   Workspace ws;
   std::vector<Slot> slots;
@@ -176,8 +194,12 @@ struct BlobWalker {
   }
 };
 
-size_t param_count() {
-  size_t n = 0;
+size_t tower_param_count() {
+  return (size_t)kC * 4 * 9 + kC + (size_t)2 * kNRefRes * (kC * kC * 9 + kC) + kC * 9 + 1;
+}
+
+size_t param_count(int levels = 1) {
+  size_t n = (size_t)(levels - 1) * tower_param_count();
   for (int i = 0; i < kNDown; ++i) n += (size_t)kC * (i == 0 ? 3 : kC) * 25 + kC;
   n += (size_t)(2 * kNFeatRes + 1) * (kC * kC * 9 + kC);
   n += (size_t)kNAgg * (kC * kC * 27 + kC) + kC * 27 + 1;
@@ -260,8 +282,9 @@ int upload_down0_f16(sn_handle* h, const HostLayer& l, Down0F16* out) {
   return SN_OK;
 }
 
-// A-fragments of k_refin_f16: K = 8 * tap + e over the pixel slot [d_hi, Y, U, V, d_lo, 0, 0, 0];
-// fragment a = hi weights on (d_hi, Y, U, V); fragment b = lo weights on the same entries + hi(w_d) on d_lo
+// A-fragments of k_refin_f16: K = 8 * tap + e over the pixel slot [d_hi, Y_hi, U_hi, V_hi, d_lo, Y_lo, U_lo, V_lo]
+// (the image lo parts are zero when the source is the int8 model input, whose values are exact in fp16);
+// fragment a = hi weights on entries 0..3; fragment b = lo weights on entries 0..3 + hi weights on entries 4..7
 int upload_refin_f16(sn_handle* h, const HostLayer& l, Down0F16* out) {
   std::vector<_Float16> pk((size_t)5 * 2 * 64 * 8, (_Float16)0.f);
   for (int t = 0; t < 5; ++t)
@@ -275,7 +298,7 @@ int upload_refin_f16(sn_handle* h, const HostLayer& l, Down0F16* out) {
         const _Float16 hi = (_Float16)w;
         a[c] = hi;
         b[c] = (_Float16)((w - (float)hi) * kSplitScale);
-        if (c == 0) b[4] = hi;
+        b[4 + c] = hi;
       }
     }
   HIP_TRY(h, dalloc(&out->wfrag, pk.size() / 8));
@@ -283,19 +306,22 @@ int upload_refin_f16(sn_handle* h, const HostLayer& l, Down0F16* out) {
   return SN_OK;
 }
 
+// img_src: the int8 model input [n][6][H][W] (pyr = false) or the float image pyramid level [n][3][g.H][g.W]
 hipError_t launch_refin_f16(hipStream_t st, const Down0F16& L, const float* bias, const float* disp_low,
-                            const int8_t* in6, int hl, int wl, int H, int W, float inv_d, const RefGeom& g, int nimg,
-                            uint4* out, bool split, size_t lo_off_bytes, int num_cu) {
+                            const void* img_src, bool pyr, int hl, int wl, int H, int W, float inv_d, UpScale ups,
+                            const RefGeom& g, int nimg, uint4* out, bool split, size_t lo_off_bytes, int num_cu) {
   const int total = g.tiles_x * g.tiles_y * nimg;
   int blocks = 2 * num_cu;
   if (blocks > total) blocks = total;
-  const int al4 = (W % 4 == 0) && (reinterpret_cast<uintptr_t>(in6) % 4 == 0);
-  if (split)
-    hipLaunchKernelGGL(k_refin_f16<true>, dim3(blocks), dim3(256), RefInTile::LDS_BYTES, st, disp_low, in6, hl, wl, H, W,
-                       inv_d, L.wfrag, bias, out, lo_off_bytes, g, nimg, al4);
-  else
-    hipLaunchKernelGGL(k_refin_f16<false>, dim3(blocks), dim3(256), RefInTile::LDS_BYTES, st, disp_low, in6, hl, wl, H, W,
-                       inv_d, L.wfrag, bias, out, lo_off_bytes, g, nimg, al4);
+  const int al4 = !pyr && (W % 4 == 0) && (reinterpret_cast<uintptr_t>(img_src) % 4 == 0);
+#define SN_REFIN(S, P)                                                                                              \
+  hipLaunchKernelGGL((k_refin_f16<S, P>), dim3(blocks), dim3(256), RefInTile::LDS_BYTES, st, disp_low, img_src, hl, wl, \
+                     H, W, inv_d, ups, L.wfrag, bias, out, lo_off_bytes, g, nimg, al4)
+  if (split && pyr) SN_REFIN(true, true);
+  else if (split) SN_REFIN(true, false);
+  else if (pyr) SN_REFIN(false, true);
+  else SN_REFIN(false, false);
+#undef SN_REFIN
   return hipGetLastError();
 }
 
@@ -575,17 +601,17 @@ hipError_t launch_ref_block_f16_h(hipStream_t st, const RefLayerF16& L1, const R
 
 hipError_t launch_head_final_f16(hipStream_t st, bool split, const uint4* x, size_t lo_slots, const RefGeom& g,
                                  const float* w, float bias, const float* disp_low, int hl, int wl, int H, int W, float dmax,
-                                 float inv_q, float* out_disp, int32_t* out_raw, int nimg) {
+                                 float inv_q, UpScale ups, float* out_disp, int32_t* out_raw, int nimg) {
   constexpr int TH = 16;
   using T = HeadTile<TH>;
   const int tiles_x = (W + T::TWO - 1) / T::TWO, tiles_y = (H + TH - 1) / TH;
   const dim3 grid((unsigned)(tiles_x * tiles_y * nimg));
   if (split)
     hipLaunchKernelGGL((k_head_final_f16<true, TH>), grid, dim3(256), T::LDS_BYTES, st, x, lo_slots, g, w, bias, disp_low, hl,
-                       wl, H, W, dmax, inv_q, out_disp, out_raw, tiles_x, tiles_y);
+                       wl, H, W, dmax, inv_q, out_disp, out_raw, tiles_x, tiles_y, ups);
   else
     hipLaunchKernelGGL((k_head_final_f16<false, TH>), grid, dim3(256), T::LDS_BYTES, st, x, (size_t)0, g, w, bias, disp_low,
-                       hl, wl, H, W, dmax, inv_q, out_disp, out_raw, tiles_x, tiles_y);
+                       hl, wl, H, W, dmax, inv_q, out_disp, out_raw, tiles_x, tiles_y, ups);
   return hipGetLastError();
 }
 
@@ -593,7 +619,7 @@ hipError_t launch_head_final_f16(hipStream_t st, bool split, const uint4* x, siz
 hipError_t launch_ref_conv_head_f16(hipStream_t st, const RefLayerF16& L, const RefGeom& g, int num_cu, const uint4* in,
                                     const uint4* res, int nimg, unsigned* tile_ctr, const float* hw, float hbias,
                                     const float* disp_low, int hl, int wl, int H, int W, float dmax, float inv_q,
-                                    float* out_disp, int32_t* out_raw, unsigned* dump) {
+                                    UpScale ups, float* out_disp, int32_t* out_raw, unsigned* dump) {
   using T = RefTile2<1, 64, 8, 3>;
   auto kern = k_ref_conv_head_f16;
   if (tile_ctr == nullptr || dump == nullptr) return hipErrorInvalidValue;
@@ -612,7 +638,7 @@ hipError_t launch_ref_conv_head_f16(hipStream_t st, const RefLayerF16& L, const 
   if (cap < 1) cap = 1;
   const int nlb = cap < band ? cap : band;
   hipLaunchKernelGGL(kern, dim3(nlb * 8), dim3(256), lds_bytes, st, in, res, L.wfrag, L.bias, gt, nimg, tile_ctr, hw,
-                     hbias, disp_low, hl, wl, H, W, dmax, inv_q, out_disp, out_raw, dump);
+                     hbias, disp_low, hl, wl, H, W, dmax, inv_q, ups, out_disp, out_raw, dump);
   return hipGetLastError();
 }
 
@@ -675,15 +701,33 @@ int alloc_ws(sn_handle* h, Workspace* ws, int nb, int rb, int ns) {
     for (int k = 0; k < 2 * ws->ns; ++k) HIP_TRY(h, dalloc(&ws->ref[k], (size_t)rb * kC * HWp));
   } else {
     for (int k = 0; k < 2 * ws->ns; ++k) {
-      const size_t slots = (ref16_slots(h->rg, rb) + kRefSlack) * (h->precision == SN_PREC_F16X3 ? 2 : 1);
+      const size_t slots = (ref16_slots(h->tw[0].rg, rb) + kRefSlack) * (h->precision == SN_PREC_F16X3 ? 2 : 1);
       HIP_TRY(h, dalloc(&ws->ref16[k], slots));
       HIP_TRY(h, hipMemset(ws->ref16[k], 0, slots * sizeof(uint4)));   // the zero border is never written again
     }
     // fine-grained: the queue words must be coherent across the 8 XCD L2s at device scope and with the memset
     // one counter block per tower chunk of a forward(): chunks never straddle a low-resolution piece, so every
     // piece may end with one short chunk (forward() numbers the chunks with a running ordinal)
-    ws->n_chunks = (nb + rb - 1) / rb + (nb + pb - 1) / pb + 2;
+    // (a hierarchical model runs `levels` towers per chunk: one counter block per chunk and level)
+    ws->n_chunks = ((nb + rb - 1) / rb + (nb + pb - 1) / pb + 2) * h->levels;
     HIP_TRY(h, hipExtMallocWithFlags(reinterpret_cast<void**>(&ws->tile_ctr), kTileCtrBytes * ws->n_chunks, hipDeviceMallocFinegrained));
+  }
+  for (int lv = 1; lv < h->levels; ++lv) {
+    const Tower& T = h->tw[lv];
+    const size_t HWk = (size_t)T.Hk * T.Wk;
+    for (int k = 0; k < 2 * ws->ns; ++k) {
+      if (h->precision == SN_PREC_FP32) {
+        HIP_TRY(h, dalloc(&ws->ref_lv[lv][k], (size_t)rb * kC * HWk));
+      } else {
+        const size_t slots = (ref16_slots(T.rg, rb) + kRefSlack) * (h->precision == SN_PREC_F16X3 ? 2 : 1);
+        HIP_TRY(h, dalloc(&ws->ref16_lv[lv][k], slots));
+        HIP_TRY(h, hipMemset(ws->ref16_lv[lv][k], 0, slots * sizeof(uint4)));
+      }
+    }
+    for (int k = 0; k < ws->ns; ++k) {
+      HIP_TRY(h, dalloc(&ws->pyr[lv][k], (size_t)rb * 3 * HWk));
+      HIP_TRY(h, dalloc(&ws->lvl_disp[lv][k], (size_t)rb * HWk));
+    }
   }
   HIP_TRY(h, dalloc(&ws->out_disp, (size_t)nb * HW));
   HIP_TRY(h, dalloc(&ws->out_raw, (size_t)nb * HW));
@@ -702,6 +746,14 @@ void free_ws(Workspace* ws) {
   hipFree(ws->disp_low);
   for (auto p : ws->ref) hipFree(p);
   for (auto p : ws->ref16) hipFree(p);
+  for (auto& lv : ws->ref_lv)
+    for (auto p : lv) hipFree(p);
+  for (auto& lv : ws->ref16_lv)
+    for (auto p : lv) hipFree(p);
+  for (auto& lv : ws->pyr)
+    for (auto p : lv) hipFree(p);
+  for (auto& lv : ws->lvl_disp)
+    for (auto p : lv) hipFree(p);
   hipFree(ws->out_disp);
   hipFree(ws->out_raw);
   hipFree(ws->nv12);
@@ -821,74 +873,129 @@ inline int first_piece(const Workspace& ws, int n) {
   return m < n ? m : n;
 }
 
-// Refinement of ONE tower chunk: pairs [q0, q0+c), c <= ws.rb, on stream `st` with the activation pair of tower
-// stream `sidx`; `ordinal` selects the chunk's tile-queue counters.
-int refine_chunk(sn_handle* h, Workspace& ws, hipStream_t st, int sidx, int ordinal, int q0, int c, const int8_t* in6,
-                 float* out_disp, int32_t* out_raw, bool pe) {
+// One refinement level of one tower chunk (c pairs) on stream `st`.
+//   T          the level's tower (weights + geometry); rx / rt (fp32) or rx16 / rt16 (fp16 modes) its activation pair
+//   src        [c][sh][sw] map the level starts from, upsampled by `ups` (x16: soft-argmin map, single-scale; x2: the
+//              level below, hierarchical)
+//   img_src    int8 model input of the chunk (pyr = false) or the level's float image pyramid [c][3][Hk][Wk]
+//   H, W       size of the level's output map (the image for level 0, the whole padded level otherwise)
+//   dnorm      D / 2^level: disparity normalisation at the tower input and residual scale at its output
+//   od / orw   float map and (level 0 only) wire map, both nullable
+int refine_level(sn_handle* h, Workspace& ws, hipStream_t st, const Tower& T, float* rx, float* rt, uint4* rx16,
+                 uint4* rt16, const float* src, int sh, int sw, UpScale ups, const void* img_src, bool pyr, int H, int W,
+                 float dnorm, float* od, int32_t* orw, unsigned* chunk_ctr, int c, bool pe) {
   const int ncu = h->num_cu;
-  const int Hp = h->Hp, Wp = h->Wp, hl = h->hl, wl = h->wl;
-  const size_t HW = (size_t)h->H * h->W;
+  const int Hk = T.Hk, Wk = T.Wk;
   // The wire factor is the reference's literal 16 * 12 for EVERY dmax (parser.cpp:86, stereonet_node.cpp:288,
   // publisher_member_function.py:75): the unmodified consumers recover pixels whatever D the model was built for.
   const float inv_q = (float)(1.0 / (kWireFactor * (double)kOutScale));
-  LoadRefineIn ld{ws.disp_low + (size_t)q0 * hl * wl, in6 + (size_t)q0 * 6 * HW, hl, wl, h->H, h->W, Hp, Wp,
-                  1.0f / (float)h->D};
-  float* od = out_disp ? out_disp + (size_t)q0 * HW : nullptr;
-  int32_t* orw = out_raw ? out_raw + (size_t)q0 * HW : nullptr;
-  const float* dl = ws.disp_low + (size_t)q0 * hl * wl;
-  dim3 grid((h->W + 63) / 64, (h->H + 3) / 4, c);
   if (h->precision == SN_PREC_FP32) {
-    float* rx = ws.ref[2 * sidx];
-    float* rt = ws.ref[2 * sidx + 1];
-    if (Hp * Wp <= 64 * 128)
-      HIP_TRY(h, (launch_conv<3, 1, 1, 4, 4, 32>(st, h->rin, ld, c, Hp, Wp, rx, nullptr, true)));
+    LoadRefineIn ld{src, reinterpret_cast<const int8_t*>(img_src), sh, sw, H, W, Hk, Wk, 1.0f / dnorm, ups,
+                    pyr ? reinterpret_cast<const float*>(img_src) : nullptr};
+    if (Hk * Wk <= 64 * 128)
+      HIP_TRY(h, (launch_conv<3, 1, 1, 4, 4, 32>(st, T.rin, ld, c, Hk, Wk, rx, nullptr, true)));
     else
-      HIP_TRY(h, (launch_conv<3, 1, 1, 4, 8, 64>(st, h->rin, ld, c, Hp, Wp, rx, nullptr, true)));
+      HIP_TRY(h, (launch_conv<3, 1, 1, 4, 8, 64>(st, T.rin, ld, c, Hk, Wk, rx, nullptr, true)));
     if (pe) HIP_TRY(h, hipEventRecord(h->ev[4], st));
     for (int i = 0; i < kNRefRes; ++i) {
-      HIP_TRY(h, conv3x3(st, h->rres[i][0], rx, c, Hp, Wp, kRefDil[i], rt, nullptr, true));
-      HIP_TRY(h, conv3x3(st, h->rres[i][1], rt, c, Hp, Wp, kRefDil[i], rx, rx, true));
+      HIP_TRY(h, conv3x3(st, T.rres[i][0], rx, c, Hk, Wk, kRefDil[i], rt, nullptr, true));
+      HIP_TRY(h, conv3x3(st, T.rres[i][1], rt, c, Hk, Wk, kRefDil[i], rx, rx, true));
     }
     if (pe) HIP_TRY(h, hipEventRecord(h->ev[5], st));
-    hipLaunchKernelGGL(k_head_final, grid, dim3(256), 0, st, rx, h->rout.w, h->rout.bias, dl, hl, wl, Hp, Wp, h->H,
-                       h->W, (float)h->D, inv_q, od, orw);
+    dim3 grid((W + 63) / 64, (H + 3) / 4, c);
+    hipLaunchKernelGGL(k_head_final, grid, dim3(256), 0, st, rx, T.rout.w, T.rout.bias, src, sh, sw, Hk, Wk, H, W, dnorm,
+                       inv_q, od, orw, ups);
   } else {
     // fp16 tower: ref.in writes the NCHW8c fp16 tensor, the 12 C->C convs run on v_mfma_f32_32x32x16_f16, the head
     // reads fp16 and finishes in fp32
-    uint4* rx = ws.ref16[2 * sidx];
-    uint4* rt = ws.ref16[2 * sidx + 1];
-    const RefGeom& g = h->rg;
+    uint4* x16 = rx16;
+    uint4* t16 = rt16;
+    const RefGeom& g = T.rg;
     const bool x3 = h->precision == SN_PREC_F16X3;
     const size_t lo_slots = ref16_slots(g, ws.rb) + kRefSlack;       // hi tensor -> lo tensor (F16X3)
-    HIP_TRY(h, launch_refin_f16(st, h->refin, h->rin.bias, ws.disp_low + (size_t)q0 * hl * wl, in6 + (size_t)q0 * 6 * HW,
-                                hl, wl, h->H, h->W, 1.0f / (float)h->D, g, c, rx, x3, lo_slots * 16, ncu));
+    HIP_TRY(h, launch_refin_f16(st, T.refin, T.rin.bias, src, img_src, pyr, sh, sw, H, W, 1.0f / dnorm, ups, g, c, x16, x3,
+                                lo_slots * 16, ncu));
     if (pe) HIP_TRY(h, hipEventRecord(h->ev[4], st));
-    unsigned* const chunk_ctr = ws.tile_ctr + (size_t)ordinal * (kTileCtrBytes / sizeof(unsigned));
     // fp16 mode: the last conv of the tower and the head run as one kernel (the tower's output tensor is never
     // written); needs the last block to be an unfused dilation-1 block
     const bool head_fused = !x3 && h->head_fuse && kRefDil[kNRefRes - 1] == 1 && !h->fuse_dil1;
     for (int i = 0; i < kNRefRes; ++i) {
       if (x3) {
-        HIP_TRY(h, ref_conv_f16x3(st, h->rres16[i][0], g, ncu, kRefDil[i], rx, rt, nullptr, lo_slots, c, true));
-        HIP_TRY(h, ref_conv_f16x3(st, h->rres16[i][1], g, ncu, kRefDil[i], rt, rx, rx, lo_slots, c, true));
+        HIP_TRY(h, ref_conv_f16x3(st, T.rres16[i][0], g, ncu, kRefDil[i], x16, t16, nullptr, lo_slots, c, true));
+        HIP_TRY(h, ref_conv_f16x3(st, T.rres16[i][1], g, ncu, kRefDil[i], t16, x16, x16, lo_slots, c, true));
       } else if (head_fused && i == kNRefRes - 1) {
         unsigned* ctr = chunk_ctr + 2 * i * kTileCtrStride;
-        HIP_TRY(h, ref_conv_f16(st, h->rres16[i][0], g, ncu, 1, rx, rt, nullptr, c, true, ctr));
+        HIP_TRY(h, ref_conv_f16(st, T.rres16[i][0], g, ncu, 1, x16, t16, nullptr, c, true, ctr));
         if (pe) HIP_TRY(h, hipEventRecord(h->ev[5], st));          // the 11 plain tower launches end here
-        HIP_TRY(h, launch_ref_conv_head_f16(st, h->rres16[i][1], g, ncu, rt, rx, c, ctr + kTileCtrStride, h->rout.w,
-                                            h->rout.bias, dl, hl, wl, h->H, h->W, (float)h->D, inv_q, od, orw, h->dump));
+        HIP_TRY(h, launch_ref_conv_head_f16(st, T.rres16[i][1], g, ncu, t16, x16, c, ctr + kTileCtrStride, T.rout.w,
+                                            T.rout.bias, src, sh, sw, H, W, dnorm, inv_q, ups, od, orw, h->dump));
       } else {
-        HIP_TRY(h, ref_block_f16(st, h->rres16[i][0], h->rres16[i][1], g, ncu, kRefDil[i], &rx, &rt, c,
+        HIP_TRY(h, ref_block_f16(st, T.rres16[i][0], T.rres16[i][1], g, ncu, kRefDil[i], &x16, &t16, c,
                                  chunk_ctr + 2 * i * kTileCtrStride, h->fuse_dil1));
       }
     }
     if (!head_fused) {
       if (pe) HIP_TRY(h, hipEventRecord(h->ev[5], st));
-      HIP_TRY(h, launch_head_final_f16(st, x3, rx, lo_slots, g, h->rout.w, h->rout.bias, dl, hl, wl, h->H, h->W, (float)h->D,
-                                       inv_q, od, orw, c));
+      HIP_TRY(h, launch_head_final_f16(st, x3, x16, lo_slots, g, T.rout.w, T.rout.bias, src, sh, sw, H, W, dnorm, inv_q, ups,
+                                       od, orw, c));
     }
   }
   HIP_TRY(h, hipGetLastError());
+  return SN_OK;
+}
+
+// Refinement of ONE tower chunk: pairs [q0, q0+c), c <= ws.rb, on stream `st` with the activation buffers of tower
+// stream `sidx`; `ordinal` selects the chunk's tile-queue counters.
+//   single-scale model: x16 upsample of the soft-argmin map, one tower at full resolution;
+//   hierarchical model (SURVEY.md appendix A `multi`): image pyramid of the left eye, then the towers of levels
+//   levels-1 .. 0, each starting from the x2 upsample of the map below it (values x2), normalised by D / 2^level.
+int refine_chunk(sn_handle* h, Workspace& ws, hipStream_t st, int sidx, int ordinal, int q0, int c, const int8_t* in6,
+                 float* out_disp, int32_t* out_raw, bool pe) {
+  const int hl = h->hl, wl = h->wl;
+  const size_t HW = (size_t)h->H * h->W;
+  float* od = out_disp ? out_disp + (size_t)q0 * HW : nullptr;
+  int32_t* orw = out_raw ? out_raw + (size_t)q0 * HW : nullptr;
+  const float* dlow = ws.disp_low + (size_t)q0 * hl * wl;
+  const int8_t* in_chunk = in6 + (size_t)q0 * 6 * HW;
+  const size_t ctr_words = kTileCtrBytes / sizeof(unsigned);
+  unsigned* const ctr0 = ws.tile_ctr ? ws.tile_ctr + (size_t)ordinal * h->levels * ctr_words : nullptr;
+  if (h->levels == 1)
+    return refine_level(h, ws, st, h->tw[0], ws.ref[2 * sidx], ws.ref[2 * sidx + 1], ws.ref16[2 * sidx],
+                        ws.ref16[2 * sidx + 1], dlow, hl, wl, UpScale{1.0f / 16.0f, 16.0f}, in_chunk, false, h->H, h->W,
+                        (float)h->D, od, orw, ctr0, c, pe);
+  // image pyramid: level 1 from the int8 input, the others from the level above
+  for (int lv = 1; lv < h->levels; ++lv) {
+    const Tower& T = h->tw[lv];
+    const long total = (long)c * 3 * T.Hk * T.Wk;
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (lv == 1)
+      hipLaunchKernelGGL(k_img_pool2<true>, grid, dim3(256), 0, st, (const void*)in_chunk, h->H, h->W, T.Hk, T.Wk,
+                         ws.pyr[lv][sidx], total);
+    else
+      hipLaunchKernelGGL(k_img_pool2<false>, grid, dim3(256), 0, st, (const void*)ws.pyr[lv - 1][sidx], 0, 0, T.Hk, T.Wk,
+                         ws.pyr[lv][sidx], total);
+  }
+  HIP_TRY(h, hipGetLastError());
+  const float* src = dlow;
+  int sh = hl, sw = wl;
+  const UpScale x2{0.5f, 2.0f};
+  for (int lv = h->levels - 1; lv >= 0; --lv) {
+    const Tower& T = h->tw[lv];
+    const float dnorm = (float)h->D / (float)(1 << lv);
+    unsigned* ctr = ctr0 ? ctr0 + (size_t)lv * ctr_words : nullptr;
+    int rc;
+    if (lv > 0)
+      rc = refine_level(h, ws, st, T, ws.ref_lv[lv][2 * sidx], ws.ref_lv[lv][2 * sidx + 1], ws.ref16_lv[lv][2 * sidx],
+                        ws.ref16_lv[lv][2 * sidx + 1], src, sh, sw, x2, ws.pyr[lv][sidx], true, T.Hk, T.Wk, dnorm,
+                        ws.lvl_disp[lv][sidx], nullptr, ctr, c, false);
+    else
+      rc = refine_level(h, ws, st, T, ws.ref[2 * sidx], ws.ref[2 * sidx + 1], ws.ref16[2 * sidx], ws.ref16[2 * sidx + 1],
+                        src, sh, sw, x2, in_chunk, false, h->H, h->W, dnorm, od, orw, ctr, c, pe);
+    if (rc) return rc;
+    src = ws.lvl_disp[lv][sidx];
+    sh = T.Hk;
+    sw = T.Wk;
+  }
   return SN_OK;
 }
 
@@ -1046,7 +1153,13 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
   const uint32_t dil_ok[6] = {1, 2, 4, 8, 1, 1};
   if (hd.version != 1 || hd.channels != kC || hd.n_down != kNDown || hd.n_fres != kNFeatRes ||
       hd.n_agg != kNAgg || hd.n_rres != kNRefRes || memcmp(hd.dil, dil_ok, sizeof dil_ok) != 0 ||
-      hd.n_params != param_count()) {
+      (hd.reserved != 0 && hd.reserved != 1 && hd.reserved != (uint64_t)kMultiLevels)) {
+    fclose(f);
+    return SN_ERR_FORMAT;
+  }
+  // header word 72: refinement levels (0 / 1 = single-scale tower, 4 = hierarchical; weights.py documents the layout)
+  const int levels = hd.reserved > 1 ? (int)hd.reserved : 1;
+  if (hd.n_params != param_count(levels)) {
     fclose(f);
     return SN_ERR_FORMAT;
   }
@@ -1093,7 +1206,12 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
   h->task_num = c.task_num > 0 ? c.task_num : 4;
   h->refine_chunk = c.refine_chunk;                            // <= 0: chosen below from the tensor size
   h->piece = c.piece > 0 ? c.piece : 16;
-  h->rg = make_ref_geom(h->Hp, h->Wp);
+  h->levels = levels;
+  for (int k = 0; k < levels; ++k) {
+    h->tw[k].Hk = h->Hp >> k;
+    h->tw[k].Wk = h->Wp >> k;
+    h->tw[k].rg = make_ref_geom(h->tw[k].Hk, h->tw[k].Wk);
+  }
   {
     const char* e = getenv("SN_TOWER_STREAMS");        // 2 = consecutive tower chunks alternate between two streams
     h->tower_streams = e ? atoi(e) : 1;
@@ -1106,7 +1224,7 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
     // not depend on its size, and ~5 TB/s per byte once they spill (scripts/mall_probe.hip): 1280x720
     // -> 2 pairs (4 x 61 MB), 1248x384 -> 4 pairs (8 x 32 MB); measured equal to one-pair chunks alternating on two
     // streams (SN_TOWER_STREAMS=2), with fewer and fuller launches.
-    const double tensor_mb = 4.0 * h->rg.Hs * h->rg.Ws * 16.0 / 1048576.0 * (c.precision == SN_PREC_F16X3 ? 2.0 : c.precision == SN_PREC_FP32 ? 2.0 : 1.0);
+    const double tensor_mb = 4.0 * h->tw[0].rg.Hs * h->tw[0].rg.Ws * 16.0 / 1048576.0 * (c.precision == SN_PREC_F16X3 ? 2.0 : c.precision == SN_PREC_FP32 ? 2.0 : 1.0);
     int rc_auto = (int)(256.0 / (2.0 * tensor_mb * h->tower_streams) + 0.5);
     h->refine_chunk = rc_auto < 1 ? 1 : (rc_auto > 8 ? 8 : rc_auto);
   }
@@ -1116,7 +1234,7 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
   // the kernels use 32-bit element / byte offsets inside one tensor: keep every tensor below 2^32
   {
     const double low_elems = 2.0 * (h->piece < h->max_batch ? h->piece : h->max_batch) * kC * (h->Hp / 2.0) * (h->Wp / 2.0);
-    const double ref_bytes = (double)h->refine_chunk * 4.0 * h->rg.Hs * h->rg.Ws * 16.0;
+    const double ref_bytes = (double)h->refine_chunk * 4.0 * h->tw[0].rg.Hs * h->tw[0].rg.Ws * 16.0;
     const double vol_elems = (double)(h->piece < h->max_batch ? h->piece : h->max_batch) * h->Dl * kC * h->hl * h->wl;
     if (low_elems >= 4.0e9 || ref_bytes >= 4.0e9 || vol_elems >= 4.0e9) {
       delete h;
@@ -1183,24 +1301,26 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
       return fail(rc);
   }
   if ((rc = upload_head(h, bw.next(1, kC, 27), &h->aout))) return fail(rc);
-  {
-    const HostLayer hl_ = bw.next(kC, 4, 9);
-    if ((rc = upload_conv2d(h, hl_, 4, &h->rin))) return fail(rc);
-    if (h->precision != SN_PREC_FP32 && (rc = upload_refin_f16(h, hl_, &h->refin)))
-      return fail(rc);
-  }
-  for (int i = 0; i < kNRefRes; ++i)
-    for (int j = 0; j < 2; ++j) {
-      const HostLayer hl_ = bw.next(kC, kC, 9);
-      if (h->precision == SN_PREC_FP32) {
-        if ((rc = upload_conv2d(h, hl_, 8, &h->rres[i][j]))) return fail(rc);
-      } else if (h->precision == SN_PREC_F16X3) {
-        if ((rc = upload_ref_f16x3(h, hl_, &h->rres16[i][j]))) return fail(rc);
-      } else {
-        if ((rc = upload_ref_f16(h, hl_, &h->rres16[i][j]))) return fail(rc);
-      }
+  for (int lv = 0; lv < h->levels; ++lv) {          // blob order: tower of level 0, then (multi) levels 1, 2, 3
+    Tower& T = h->tw[lv];
+    {
+      const HostLayer hl_ = bw.next(kC, 4, 9);
+      if ((rc = upload_conv2d(h, hl_, 4, &T.rin))) return fail(rc);
+      if (h->precision != SN_PREC_FP32 && (rc = upload_refin_f16(h, hl_, &T.refin))) return fail(rc);
     }
-  if ((rc = upload_head(h, bw.next(1, kC, 9), &h->rout))) return fail(rc);
+    for (int i = 0; i < kNRefRes; ++i)
+      for (int j = 0; j < 2; ++j) {
+        const HostLayer hl_ = bw.next(kC, kC, 9);
+        if (h->precision == SN_PREC_FP32) {
+          if ((rc = upload_conv2d(h, hl_, 8, &T.rres[i][j]))) return fail(rc);
+        } else if (h->precision == SN_PREC_F16X3) {
+          if ((rc = upload_ref_f16x3(h, hl_, &T.rres16[i][j]))) return fail(rc);
+        } else {
+          if ((rc = upload_ref_f16(h, hl_, &T.rres16[i][j]))) return fail(rc);
+        }
+      }
+    if ((rc = upload_head(h, bw.next(1, kC, 9), &T.rout))) return fail(rc);
+  }
   if (bw.off != blob.size()) return fail(SN_ERR_FORMAT);
 
   if ((rc = alloc_ws(h, &h->ws, h->max_batch, h->refine_chunk, h->tower_streams))) return fail(rc == SN_ERR_DEVICE ? SN_ERR_NOMEM : rc);
@@ -1219,22 +1339,24 @@ int sn_destroy(sn_handle* h) {
   };
   for (auto& l : h->down) free_conv(l);
   hipFree(h->down0.wfrag);
-  hipFree(h->refin.wfrag);
   for (auto& b : h->fres)
     for (auto& l : b) free_conv(l);
   free_conv(h->fout);
   for (auto& l : h->agg) free_conv(l);
-  free_conv(h->rin);
-  for (auto& b : h->rres)
-    for (auto& l : b) free_conv(l);
-  for (auto& b : h->rres16)
-    for (auto& l : b) {
-      hipFree(l.wfrag);
-      hipFree(l.bias);
-    }
+  for (auto& T : h->tw) {
+    hipFree(T.refin.wfrag);
+    free_conv(T.rin);
+    for (auto& b : T.rres)
+      for (auto& l : b) free_conv(l);
+    for (auto& b : T.rres16)
+      for (auto& l : b) {
+        hipFree(l.wfrag);
+        hipFree(l.bias);
+      }
+    hipFree(T.rout.w);
+  }
   hipFree(h->dump);
   hipFree(h->aout.w);
-  hipFree(h->rout.w);
   free_ws(&h->ws);
   for (auto& s : h->slots) {
     free_ws(&s.ws);
@@ -1283,8 +1405,10 @@ int sn_get_io_info(const sn_handle* h, sn_io_info* info) {
   for (int k = 1; k <= kNDown; ++k) mac += 2.0 * (wp * hp / (double)(1 << (2 * k))) * kC * (k == 1 ? 3 : kC) * 25;
   mac += 2.0 * (2 * kNFeatRes + 1) * wl * hl * kC * kC * 9;
   mac += kNAgg * dl * hl * wl * kC * kC * 27 + dl * hl * wl * kC * 27;
-  mac += wp * hp * (4.0 * kC * 9 + 2.0 * kNRefRes * kC * kC * 9 + kC * 9);
+  for (int k = 0; k < h->levels; ++k)
+    mac += (wp * hp / (double)(1 << (2 * k))) * (4.0 * kC * 9 + 2.0 * kNRefRes * kC * kC * 9 + kC * 9);
   info->flops_per_pair = 2.0 * mac;
+  info->refine_levels = h->levels;
   info->refine_chunk = h->ws.rb;
   info->piece = h->ws.pb;
   info->tower_streams = h->ws.ns;
@@ -1770,8 +1894,8 @@ int sn_dbg_refin(sn_handle* h, const float* disp_low, const int8_t* in6, int h_p
   HIP_TRY(h, hipMemcpy(dbias, bias, kC * 4, hipMemcpyHostToDevice));
   HIP_TRY(h, hipMemcpy(din, in6, (size_t)6 * h_px * w, hipMemcpyHostToDevice));
   HIP_TRY(h, hipMemset(dout, 0, 2 * slots * 16));
-  HIP_TRY(h, launch_refin_f16(h->stream, L, dbias, ddl, din, hl, wl, h_px, w, 1.0f / (float)dmax, g, 1, dout, split != 0,
-                              slots * 16, h->num_cu));
+  HIP_TRY(h, launch_refin_f16(h->stream, L, dbias, ddl, din, false, hl, wl, h_px, w, 1.0f / (float)dmax,
+                              UpScale{1.0f / 16.0f, 16.0f}, g, 1, dout, split != 0, slots * 16, h->num_cu));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   std::vector<_Float16> hout(2 * slots * 8);
   HIP_TRY(h, hipMemcpy(hout.data(), dout, 2 * slots * 16, hipMemcpyDeviceToHost));
@@ -2052,6 +2176,12 @@ int sn_dbg_read(sn_handle* h, const char* what, float* dst, size_t cap, size_t* 
   else if (!strcmp(what, "disp_low")) { src = h->ws.disp_low; cnt = hw; }
   else if (!strcmp(what, "tile_ctr") && h->ws.tile_ctr) { src = reinterpret_cast<const float*>(h->ws.tile_ctr); cnt = kTileCtrBytes / 4 * h->ws.n_chunks; }
   else if (!strcmp(what, "refine_x") && h->precision == SN_PREC_FP32) { src = h->ws.ref[0]; cnt = (size_t)kC * h->Hp * h->Wp; }
+  else if (!strncmp(what, "level", 5) && what[5] >= '1' && what[5] < '0' + h->levels && what[6] == 0) {
+    // hierarchical refinement: the map of level k (first pair of the last chunk refined on tower stream 0)
+    const int k = what[5] - '0';
+    src = h->ws.lvl_disp[k][0];
+    cnt = (size_t)h->tw[k].Hk * h->tw[k].Wk;
+  }
   else return SN_ERR_ARG;
   *n = cnt;
   if (!dst) return SN_OK;

@@ -94,7 +94,8 @@ typedef struct sn_io_info {
   int refine_chunk;       /* pairs per refinement-tower launch actually in use */
   int piece;              /* pairs per low-resolution piece actually in use    */
   int tower_streams;      /* tower chunks in flight (1 or 2)                   */
-  int reserved;
+  int refine_levels;      /* 1 = single-scale refinement; 4 = hierarchical (towers at 1/8, 1/4, 1/2, 1), as the
+                           * model file says (weights.py: header word 72) */
 } sn_io_info;
 
 /* DnnNode::Init + Model introspection ------------------------------------------------------- */
@@ -212,7 +213,8 @@ int sn_dbg_ref_conv_f16x3(sn_handle *h, const float *in, int h_px, int w, const 
 int sn_dbg_ref_block_f16(sn_handle *h, const float *in, int h_px, int w, const float *w1, const float *b1,
                          const float *w2, const float *b2, int dil, float *out);
 /* intermediates of the most recent batch-1 inference: "feat_l" / "feat_r" [32][hl][wl],
- * "cost"... see DESIGN.md §6; returns the element count in *n (dst may be NULL to query). */
+ * "cost" [Dl][hl][wl], "disp_low" [hl][wl], and for a hierarchical model "level1" .. "level3" (the map of that
+ * refinement level, [Hp/2^k][Wp/2^k]); returns the element count in *n (dst may be NULL to query). */
 int sn_dbg_read(sn_handle *h, const char *what, float *dst, size_t cap, size_t *n);
 
 #ifdef __cplusplus

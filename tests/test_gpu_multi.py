@@ -1,0 +1,102 @@
+"""Hierarchical ("multi") refinement — SURVEY.md appendix A: the refinement tower with separate weights at 1/8, 1/4, 1/2
+and full resolution, x2 bilinear between the levels — HIP path vs the CPU oracle through the C ABI.  The model file
+says which refinement it holds (weights.py, header word 72); nothing else changes for the caller.  Needs an MI355X."""
+import numpy as np
+import pytest
+
+from hobot_stereonet_amd import api, spec, synth
+
+pytestmark = pytest.mark.gpu
+EPE_TOL = 1e-3      # px, BASELINE.json north_star
+CASES = [("c96x64_d48", 96, 64, 48, 3), ("c160x96_d96", 160, 96, 96, 4), ("c100x52_d32", 100, 52, 32, 5)]
+# (mean, max) bounds in level pixels for the maps of the coarse levels and the final map
+TOLS = {api.PREC_FP32: (1e-4, 2e-3), api.PREC_F16X3: (1e-4, 2e-3), api.PREC_F16: (EPE_TOL, 20 * EPE_TOL)}
+
+
+@pytest.mark.parametrize("prec", [api.PREC_FP32, api.PREC_F16X3, api.PREC_F16])
+@pytest.mark.parametrize("name,w,h,d,seed", CASES)
+def test_multi_small_vs_oracle_and_golden(model_factory, oracle, golden_multi, weights_multi, name, w, h, d, seed, prec):
+    x = synth.model_input_i8(w, h, d, seed)
+    hp, wp = spec.ceil16(h), spec.ceil16(w)
+    with api.StereoNetHIP(model_factory(w, h, d, multi=True), precision=prec) as eng:
+        assert eng.refine_levels == spec.MULTI_LEVELS
+        assert abs(eng.info.flops_per_pair - spec.flops_per_pair(w, h, d, levels=spec.MULTI_LEVELS)) < 1.0
+        disp, raw = eng.infer(x)
+        maps = [eng.dbg_read(f"level{k}").reshape(hp >> k, wp >> k) for k in range(1, spec.MULTI_LEVELS)]
+    odisp, oraw, olow, omaps = oracle.forward_levels(weights_multi, x, d)
+    mean_tol, max_tol = TOLS[prec]
+    for k, (m, om) in enumerate(zip(maps, omaps), start=1):
+        err = np.abs(m - om)
+        print(f"{name} prec={prec} level {k}: mean {err.mean():.2e} max {err.max():.2e}")
+        assert err.mean() < mean_tol and err.max() < max_tol, (k, err.mean(), err.max())
+    err = np.abs(disp - odisp)
+    print(f"{name} prec={prec} final: EPE {err.mean():.2e} max {err.max():.2e}")
+    assert err.mean() < mean_tol and err.max() < max_tol
+    assert np.abs(disp - golden_multi[name + ".disp"]).mean() < EPE_TOL
+    inv_q = np.float32(1.0 / (192.0 * float(np.float32(spec.OUT_SCALE))))
+    assert (raw == np.rint(disp * inv_q).astype(np.int32)).all() and raw.min() >= 0
+    assert np.abs(raw.astype(np.int64) - oraw).max() <= max(1, int(np.ceil(err.max() * float(inv_q))) + 1)
+
+
+def test_multi_differs_from_single_and_shares_the_lowres_branch(model_factory, oracle, weights_multi):
+    """A multi file starts with a complete single file: same low-resolution branch, different refinement."""
+    w, h, d = 160, 96, 96
+    x = synth.model_input_i8(w, h, d, 4)
+    with api.StereoNetHIP(model_factory(w, h, d, multi=True), precision=api.PREC_FP32) as em, \
+            api.StereoNetHIP(model_factory(w, h, d), precision=api.PREC_FP32) as es:
+        dm, _ = em.infer(x)
+        lm = em.dbg_read("disp_low")
+        ds, _ = es.infer(x)
+        ls = es.dbg_read("disp_low")
+        assert es.refine_levels == 1
+        with pytest.raises(Exception):
+            es.dbg_read("level1")
+    assert np.array_equal(lm, ls)
+    assert np.abs(dm - ds).mean() > 0.05
+
+
+@pytest.mark.parametrize("prec", [api.PREC_FP32, api.PREC_F16])
+def test_multi_kitti_c5_1242x375_d256(model_factory, oracle, weights_multi, prec):
+    """BASELINE.json configs[4] / SURVEY.md §8(d) C5: KITTI 1242x375, D=256, hierarchical refinement."""
+    w, h, d = 1242, 375, 256
+    x = synth.model_input_i8(w, h, d, 22)
+    with api.StereoNetHIP(model_factory(w, h, d, multi=True), precision=prec) as eng:
+        disp, raw = eng.infer(x)
+    odisp, oraw, _ = oracle.forward(weights_multi, x, d)
+    epe = float(np.abs(disp - odisp).mean())
+    print(f"C5 multi 1242x375 D=256 prec={prec}: EPE {epe:.3e} px, max {np.abs(disp - odisp).max():.3e}")
+    assert disp.shape == (h, w) and epe < EPE_TOL
+    inv_q = np.float32(1.0 / (192.0 * float(np.float32(spec.OUT_SCALE))))
+    assert (raw == np.rint(disp * inv_q).astype(np.int32)).all()
+
+
+def test_multi_batch_chunks_pieces_and_async_equal_single(model_factory):
+    """Ragged tower chunks / low-resolution pieces and the async slots run the same arithmetic per pair."""
+    w, h, d = 200, 120, 64
+    xs = np.stack([synth.model_input_i8(w, h, d, 40 + i) for i in range(7)])
+    with api.StereoNetHIP(model_factory(w, h, d, multi=True), max_batch=7, precision=api.PREC_F16, refine_chunk=2,
+                          piece=3) as eng:
+        disp, raw = eng.infer(xs)
+        singles = [eng.infer(xs[i]) for i in range(7)]
+        araw = [np.empty((h, w), np.int32) for _ in range(4)]
+        adisp = [np.empty((h, w), np.float32) for _ in range(4)]
+        for rep in range(3):             # the third request per slot replays a captured hipGraph
+            tickets = [eng.submit(xs[i], araw[i], adisp[i]) for i in range(4)]
+            for t in tickets:
+                eng.wait(t)
+            for i in range(4):
+                assert np.array_equal(araw[i], singles[i][1]) and np.array_equal(adisp[i], singles[i][0]), (rep, i)
+    for i in range(7):
+        assert np.array_equal(disp[i], singles[i][0]) and np.array_equal(raw[i], singles[i][1]), i
+
+
+def test_multi_full_size_1280x720(model_factory, oracle, weights_multi):
+    w, h, d = 1280, 720, 192
+    x = synth.model_input_i8(w, h, d, 9)
+    with api.StereoNetHIP(model_factory(w, h, d, multi=True), precision=api.PREC_F16) as eng:
+        disp, raw = eng.infer(x)
+        assert abs(eng.info.flops_per_pair / 1e9 - 295.56) < 0.01
+    odisp, _, _ = oracle.forward(weights_multi, x, d)
+    epe = float(np.abs(disp - odisp).mean())
+    print(f"multi 1280x720 D=192 f16: EPE {epe:.3e} px")
+    assert epe < EPE_TOL
