@@ -77,12 +77,14 @@ struct Workspace {          // activations for up to `nb` pairs
   int ns = 1;                 // tower streams this workspace serves: one (x, t) activation pair per stream
   float* ref[2 * kMaxTowerStreams] = {};
   uint4* ref16[2 * kMaxTowerStreams] = {};   // fp16 NCHW8c padded (fp16 modes): [2 * stream + {x, t}]
-  // hierarchical refinement, levels 1..: activation pairs (their own zero borders), image pyramid [rb][3][Hk][Wk]
-  // and level disparity maps [rb][Hk][Wk], one set per tower stream
-  float* ref_lv[kMaxLevels][2 * kMaxTowerStreams] = {};
-  uint4* ref16_lv[kMaxLevels][2 * kMaxTowerStreams] = {};
-  float* pyr[kMaxLevels][kMaxTowerStreams] = {};
-  float* lvl_disp[kMaxLevels][kMaxTowerStreams] = {};
+  // hierarchical refinement, levels 1..: the coarse levels run once per low-resolution PIECE (pb pairs), in chunks
+  // of rbk[level] = min(pb, rb * 4^level) pairs (the same activation footprint per launch as level 0).  Activation
+  // pairs (their own zero borders) for rbk pairs; image pyramid [pb][3][Hk][Wk] and level maps [pb][Hk][Wk].
+  int rbk[kMaxLevels] = {};
+  float* ref_lv[kMaxLevels][2] = {};
+  uint4* ref16_lv[kMaxLevels][2] = {};
+  float* pyr[kMaxLevels] = {};
+  float* lvl_disp[kMaxLevels] = {};
   int n_chunks = 0;
   unsigned* tile_ctr = nullptr;           // dynamic tile queues of the fp16 tower: [12 launches][8 XCDs][16] uints
   float* out_disp = nullptr;
@@ -684,6 +686,7 @@ int alloc_ws(sn_handle* h, Workspace* ws, int nb, int rb, int ns) {
   ws->nb = nb;
   ws->rb = rb;
   ws->ns = (ns > 1 && nb > rb) ? (ns < kMaxTowerStreams ? ns : kMaxTowerStreams) : 1;
+  if (h->levels > 1) ws->ns = 1;      // the level maps of a piece live in one buffer set: one tower stream
   ws->pb = h->piece > 0 ? h->piece : 16;
   if (ws->pb > nb) ws->pb = nb;
   if (ws->pb < rb) ws->pb = rb;
@@ -708,26 +711,32 @@ int alloc_ws(sn_handle* h, Workspace* ws, int nb, int rb, int ns) {
     // fine-grained: the queue words must be coherent across the 8 XCD L2s at device scope and with the memset
     // one counter block per tower chunk of a forward(): chunks never straddle a low-resolution piece, so every
     // piece may end with one short chunk (forward() numbers the chunks with a running ordinal)
-    // (a hierarchical model runs `levels` towers per chunk: one counter block per chunk and level)
-    ws->n_chunks = ((nb + rb - 1) / rb + (nb + pb - 1) / pb + 2) * h->levels;
+    // a hierarchical model adds the coarse-level launches of every piece: one block per (piece, level, coarse chunk)
+    ws->n_chunks = (nb + rb - 1) / rb + (nb + pb - 1) / pb + 2;
+    for (int lv = 1; lv < h->levels; ++lv) {
+      long r = (long)rb << (2 * lv);
+      const int rbk = r < pb ? (int)r : pb;
+      ws->n_chunks += ((nb + pb - 1) / pb + 2) * ((pb + rbk - 1) / rbk + 1);
+    }
     HIP_TRY(h, hipExtMallocWithFlags(reinterpret_cast<void**>(&ws->tile_ctr), kTileCtrBytes * ws->n_chunks, hipDeviceMallocFinegrained));
   }
+  ws->rbk[0] = rb;
   for (int lv = 1; lv < h->levels; ++lv) {
     const Tower& T = h->tw[lv];
     const size_t HWk = (size_t)T.Hk * T.Wk;
-    for (int k = 0; k < 2 * ws->ns; ++k) {
+    long r = (long)rb << (2 * lv);
+    ws->rbk[lv] = r < pb ? (int)r : pb;
+    for (int k = 0; k < 2; ++k) {
       if (h->precision == SN_PREC_FP32) {
-        HIP_TRY(h, dalloc(&ws->ref_lv[lv][k], (size_t)rb * kC * HWk));
+        HIP_TRY(h, dalloc(&ws->ref_lv[lv][k], (size_t)ws->rbk[lv] * kC * HWk));
       } else {
-        const size_t slots = (ref16_slots(T.rg, rb) + kRefSlack) * (h->precision == SN_PREC_F16X3 ? 2 : 1);
+        const size_t slots = (ref16_slots(T.rg, ws->rbk[lv]) + kRefSlack) * (h->precision == SN_PREC_F16X3 ? 2 : 1);
         HIP_TRY(h, dalloc(&ws->ref16_lv[lv][k], slots));
         HIP_TRY(h, hipMemset(ws->ref16_lv[lv][k], 0, slots * sizeof(uint4)));
       }
     }
-    for (int k = 0; k < ws->ns; ++k) {
-      HIP_TRY(h, dalloc(&ws->pyr[lv][k], (size_t)rb * 3 * HWk));
-      HIP_TRY(h, dalloc(&ws->lvl_disp[lv][k], (size_t)rb * HWk));
-    }
+    HIP_TRY(h, dalloc(&ws->pyr[lv], (size_t)pb * 3 * HWk));
+    HIP_TRY(h, dalloc(&ws->lvl_disp[lv], (size_t)pb * HWk));
   }
   HIP_TRY(h, dalloc(&ws->out_disp, (size_t)nb * HW));
   HIP_TRY(h, dalloc(&ws->out_raw, (size_t)nb * HW));
@@ -750,10 +759,8 @@ void free_ws(Workspace* ws) {
     for (auto p : lv) hipFree(p);
   for (auto& lv : ws->ref16_lv)
     for (auto p : lv) hipFree(p);
-  for (auto& lv : ws->pyr)
-    for (auto p : lv) hipFree(p);
-  for (auto& lv : ws->lvl_disp)
-    for (auto p : lv) hipFree(p);
+  for (auto p : ws->pyr) hipFree(p);
+  for (auto p : ws->lvl_disp) hipFree(p);
   hipFree(ws->out_disp);
   hipFree(ws->out_raw);
   hipFree(ws->nv12);
@@ -881,9 +888,10 @@ inline int first_piece(const Workspace& ws, int n) {
 //   H, W       size of the level's output map (the image for level 0, the whole padded level otherwise)
 //   dnorm      D / 2^level: disparity normalisation at the tower input and residual scale at its output
 //   od / orw   float map and (level 0 only) wire map, both nullable
+//   cap        pairs the activation buffers were allocated for (c <= cap)
 int refine_level(sn_handle* h, Workspace& ws, hipStream_t st, const Tower& T, float* rx, float* rt, uint4* rx16,
                  uint4* rt16, const float* src, int sh, int sw, UpScale ups, const void* img_src, bool pyr, int H, int W,
-                 float dnorm, float* od, int32_t* orw, unsigned* chunk_ctr, int c, bool pe) {
+                 float dnorm, float* od, int32_t* orw, unsigned* chunk_ctr, int c, int cap, bool pe) {
   const int ncu = h->num_cu;
   const int Hk = T.Hk, Wk = T.Wk;
   // The wire factor is the reference's literal 16 * 12 for EVERY dmax (parser.cpp:86, stereonet_node.cpp:288,
@@ -912,7 +920,7 @@ int refine_level(sn_handle* h, Workspace& ws, hipStream_t st, const Tower& T, fl
     uint4* t16 = rt16;
     const RefGeom& g = T.rg;
     const bool x3 = h->precision == SN_PREC_F16X3;
-    const size_t lo_slots = ref16_slots(g, ws.rb) + kRefSlack;       // hi tensor -> lo tensor (F16X3)
+    const size_t lo_slots = ref16_slots(g, cap) + kRefSlack;         // hi tensor -> lo tensor (F16X3); cap = pairs the buffers hold
     HIP_TRY(h, launch_refin_f16(st, T.refin, T.rin.bias, src, img_src, pyr, sh, sw, H, W, 1.0f / dnorm, ups, g, c, x16, x3,
                                 lo_slots * 16, ncu));
     if (pe) HIP_TRY(h, hipEventRecord(h->ev[4], st));
@@ -944,59 +952,86 @@ int refine_level(sn_handle* h, Workspace& ws, hipStream_t st, const Tower& T, fl
   return SN_OK;
 }
 
-// Refinement of ONE tower chunk: pairs [q0, q0+c), c <= ws.rb, on stream `st` with the activation buffers of tower
-// stream `sidx`; `ordinal` selects the chunk's tile-queue counters.
-//   single-scale model: x16 upsample of the soft-argmin map, one tower at full resolution;
-//   hierarchical model (SURVEY.md appendix A `multi`): image pyramid of the left eye, then the towers of levels
-//   levels-1 .. 0, each starting from the x2 upsample of the map below it (values x2), normalised by D / 2^level.
-int refine_chunk(sn_handle* h, Workspace& ws, hipStream_t st, int sidx, int ordinal, int q0, int c, const int8_t* in6,
-                 float* out_disp, int32_t* out_raw, bool pe) {
-  const int hl = h->hl, wl = h->wl;
+// Next tile-queue block of this forward() (nullptr for the fp32 path, which has no queues); the pool is sized by
+// alloc_ws for the worst case, running past it would alias another launch's counters -> refuse loudly.
+inline int take_ctr_block(sn_handle* h, Workspace& ws, int* ctr_block, unsigned** out) {
+  *out = nullptr;
+  if (!ws.tile_ctr) return SN_OK;
+  if (*ctr_block >= ws.n_chunks) {
+    set_err(h, "internal: tile-queue pool exhausted");
+    return SN_ERR_DEVICE;
+  }
+  *out = ws.tile_ctr + (size_t)(*ctr_block)++ * (kTileCtrBytes / sizeof(unsigned));
+  return SN_OK;
+}
+
+// Hierarchical model (SURVEY.md appendix A `multi`), coarse part, once per low-resolution piece [p0, p0+m): the image
+// pyramid of the left eye, then the towers of levels levels-1 .. 1, each starting from the x2 upsample of the map below
+// it (the soft-argmin map for the coarsest), values x2, normalised by D / 2^level.  Level k runs in chunks of
+// ws.rbk[k] pairs.  Leaves the level-1 maps of the piece in ws.lvl_disp[1].  *ctr_block: next free tile-queue block.
+int refine_coarse(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, const int8_t* in6, int* ctr_block) {
   const size_t HW = (size_t)h->H * h->W;
-  float* od = out_disp ? out_disp + (size_t)q0 * HW : nullptr;
-  int32_t* orw = out_raw ? out_raw + (size_t)q0 * HW : nullptr;
-  const float* dlow = ws.disp_low + (size_t)q0 * hl * wl;
-  const int8_t* in_chunk = in6 + (size_t)q0 * 6 * HW;
-  const size_t ctr_words = kTileCtrBytes / sizeof(unsigned);
-  unsigned* const ctr0 = ws.tile_ctr ? ws.tile_ctr + (size_t)ordinal * h->levels * ctr_words : nullptr;
-  if (h->levels == 1)
-    return refine_level(h, ws, st, h->tw[0], ws.ref[2 * sidx], ws.ref[2 * sidx + 1], ws.ref16[2 * sidx],
-                        ws.ref16[2 * sidx + 1], dlow, hl, wl, UpScale{1.0f / 16.0f, 16.0f}, in_chunk, false, h->H, h->W,
-                        (float)h->D, od, orw, ctr0, c, pe);
-  // image pyramid: level 1 from the int8 input, the others from the level above
-  for (int lv = 1; lv < h->levels; ++lv) {
+  const int8_t* in_piece = in6 + (size_t)p0 * 6 * HW;
+  for (int lv = 1; lv < h->levels; ++lv) {       // level 1 from the int8 input, the others from the level above
     const Tower& T = h->tw[lv];
-    const long total = (long)c * 3 * T.Hk * T.Wk;
+    const long total = (long)m * 3 * T.Hk * T.Wk;
     const dim3 grid((unsigned)((total + 255) / 256));
     if (lv == 1)
-      hipLaunchKernelGGL(k_img_pool2<true>, grid, dim3(256), 0, st, (const void*)in_chunk, h->H, h->W, T.Hk, T.Wk,
-                         ws.pyr[lv][sidx], total);
+      hipLaunchKernelGGL(k_img_pool2<true>, grid, dim3(256), 0, st, (const void*)in_piece, h->H, h->W, T.Hk, T.Wk,
+                         ws.pyr[lv], total);
     else
-      hipLaunchKernelGGL(k_img_pool2<false>, grid, dim3(256), 0, st, (const void*)ws.pyr[lv - 1][sidx], 0, 0, T.Hk, T.Wk,
-                         ws.pyr[lv][sidx], total);
+      hipLaunchKernelGGL(k_img_pool2<false>, grid, dim3(256), 0, st, (const void*)ws.pyr[lv - 1], 0, 0, T.Hk, T.Wk,
+                         ws.pyr[lv], total);
   }
   HIP_TRY(h, hipGetLastError());
-  const float* src = dlow;
-  int sh = hl, sw = wl;
-  const UpScale x2{0.5f, 2.0f};
-  for (int lv = h->levels - 1; lv >= 0; --lv) {
+  const float* src = ws.disp_low + (size_t)p0 * h->hl * h->wl;
+  int sh = h->hl, sw = h->wl;
+  for (int lv = h->levels - 1; lv >= 1; --lv) {
     const Tower& T = h->tw[lv];
+    const size_t HWk = (size_t)T.Hk * T.Wk;
     const float dnorm = (float)h->D / (float)(1 << lv);
-    unsigned* ctr = ctr0 ? ctr0 + (size_t)lv * ctr_words : nullptr;
-    int rc;
-    if (lv > 0)
-      rc = refine_level(h, ws, st, T, ws.ref_lv[lv][2 * sidx], ws.ref_lv[lv][2 * sidx + 1], ws.ref16_lv[lv][2 * sidx],
-                        ws.ref16_lv[lv][2 * sidx + 1], src, sh, sw, x2, ws.pyr[lv][sidx], true, T.Hk, T.Wk, dnorm,
-                        ws.lvl_disp[lv][sidx], nullptr, ctr, c, false);
-    else
-      rc = refine_level(h, ws, st, T, ws.ref[2 * sidx], ws.ref[2 * sidx + 1], ws.ref16[2 * sidx], ws.ref16[2 * sidx + 1],
-                        src, sh, sw, x2, in_chunk, false, h->H, h->W, dnorm, od, orw, ctr, c, pe);
-    if (rc) return rc;
-    src = ws.lvl_disp[lv][sidx];
+    for (int q = 0; q < m; q += ws.rbk[lv]) {
+      const int c = (m - q) < ws.rbk[lv] ? (m - q) : ws.rbk[lv];
+      unsigned* ctr = nullptr;
+      int rc = take_ctr_block(h, ws, ctr_block, &ctr);
+      if (rc) return rc;
+      rc = refine_level(h, ws, st, T, ws.ref_lv[lv][0], ws.ref_lv[lv][1], ws.ref16_lv[lv][0], ws.ref16_lv[lv][1],
+                                  src + (size_t)q * sh * sw, sh, sw, UpScale{0.5f, 2.0f}, ws.pyr[lv] + (size_t)q * 3 * HWk, true,
+                                  T.Hk, T.Wk, dnorm, ws.lvl_disp[lv] + (size_t)q * HWk, nullptr, ctr, c, ws.rbk[lv], false);
+      if (rc) return rc;
+    }
+    src = ws.lvl_disp[lv];
     sh = T.Hk;
     sw = T.Wk;
   }
   return SN_OK;
+}
+
+// Full-resolution refinement of ONE tower chunk: pairs [q0, q0+c), c <= ws.rb, of the piece that starts at p0, on
+// stream `st` with the activation pair of tower stream `sidx`; *ctr_block: next free tile-queue block.
+//   single-scale model: x16 upsample of the soft-argmin map;
+//   hierarchical model: x2 upsample of the piece's level-1 maps (refine_coarse ran before on the same stream).
+int refine_chunk(sn_handle* h, Workspace& ws, hipStream_t st, int sidx, int* ctr_block, int p0, int q0, int c,
+                 const int8_t* in6, float* out_disp, int32_t* out_raw, bool pe) {
+  const int hl = h->hl, wl = h->wl;
+  const size_t HW = (size_t)h->H * h->W;
+  float* od = out_disp ? out_disp + (size_t)q0 * HW : nullptr;
+  int32_t* orw = out_raw ? out_raw + (size_t)q0 * HW : nullptr;
+  const int8_t* in_chunk = in6 + (size_t)q0 * 6 * HW;
+  unsigned* ctr = nullptr;
+  const int rc0 = take_ctr_block(h, ws, ctr_block, &ctr);
+  if (rc0) return rc0;
+  const float* src = ws.disp_low + (size_t)q0 * hl * wl;
+  int sh = hl, sw = wl;
+  UpScale ups{1.0f / 16.0f, 16.0f};
+  if (h->levels > 1) {
+    sh = h->tw[1].Hk;
+    sw = h->tw[1].Wk;
+    src = ws.lvl_disp[1] + (size_t)(q0 - p0) * sh * sw;
+    ups = UpScale{0.5f, 2.0f};
+  }
+  return refine_level(h, ws, st, h->tw[0], ws.ref[2 * sidx], ws.ref[2 * sidx + 1], ws.ref16[2 * sidx], ws.ref16[2 * sidx + 1],
+                      src, sh, sw, ups, in_chunk, false, h->H, h->W, (float)h->D, od, orw, ctr, c, ws.rb, pe);
 }
 
 // in6: device int8 [n][6][H][W]; out_disp / out_raw: device, nullable.
@@ -1013,19 +1048,20 @@ int refine_chunk(sn_handle* h, Workspace& ws, hipStream_t st, int sidx, int ordi
 int forward(sn_handle* h, Workspace& ws, hipStream_t st, int n, const int8_t* in6, float* out_disp,
             int32_t* out_raw, bool want_cost) {
   const bool prof = h->profiling && (&ws == &h->ws);
-  const bool multi = !prof && (&ws == &h->ws) && h->overlap && n > ws.rb;
+  const bool piped = !prof && (&ws == &h->ws) && h->overlap && n > ws.rb;
   int rc;
+  int ctr_block = 0;          // tile-queue blocks are handed out in launch order (alloc_ws sized the pool)
   if (ws.tile_ctr) HIP_TRY(h, hipMemsetAsync(ws.tile_ctr, 0, kTileCtrBytes * ws.n_chunks, st));
-  if (!multi) {
+  if (!piped) {
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[0], st));
-    int chunk = 0;
     for (int p0 = 0, m = 0; p0 < n; p0 += m) {
       m = (n - p0) < ws.pb ? (n - p0) : ws.pb;
       if ((rc = lowres(h, ws, st, p0, m, in6, want_cost, prof && p0 == 0))) return rc;
       if (prof && p0 == 0) HIP_TRY(h, hipEventRecord(h->ev[2], st));
-      for (int q0 = p0; q0 < p0 + m; q0 += ws.rb, ++chunk) {
+      if (h->levels > 1 && (rc = refine_coarse(h, ws, st, p0, m, in6, &ctr_block))) return rc;
+      for (int q0 = p0; q0 < p0 + m; q0 += ws.rb) {
         const int c = (p0 + m - q0) < ws.rb ? (p0 + m - q0) : ws.rb;
-        if ((rc = refine_chunk(h, ws, st, 0, chunk, q0, c, in6, out_disp, out_raw, prof && q0 == 0))) return rc;
+        if ((rc = refine_chunk(h, ws, st, 0, &ctr_block, p0, q0, c, in6, out_disp, out_raw, prof && q0 == 0))) return rc;
       }
     }
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[3], st));
@@ -1043,6 +1079,11 @@ int forward(sn_handle* h, Workspace& ws, hipStream_t st, int n, const int8_t* in
     hipEvent_t e = h->ev_piece[k % kMaxPieceEvents];
     HIP_TRY(h, hipEventRecord(e, h->s_low));
     bool waited[kMaxTowerStreams] = {};
+    if (h->levels > 1) {                   // coarse levels of the whole piece first (one tower stream: alloc_ws)
+      HIP_TRY(h, hipStreamWaitEvent(h->s_tow[0], e, 0));
+      waited[0] = true;
+      if ((rc = refine_coarse(h, ws, h->s_tow[0], p0, m, in6, &ctr_block))) return rc;
+    }
     for (int q0 = p0; q0 < p0 + m; q0 += ws.rb, ++chunk) {
       const int c = (p0 + m - q0) < ws.rb ? (p0 + m - q0) : ws.rb;
       const int s = chunk % ns;
@@ -1050,7 +1091,7 @@ int forward(sn_handle* h, Workspace& ws, hipStream_t st, int n, const int8_t* in
         HIP_TRY(h, hipStreamWaitEvent(h->s_tow[s], e, 0));
         waited[s] = true;
       }
-      if ((rc = refine_chunk(h, ws, h->s_tow[s], s, chunk, q0, c, in6, out_disp, out_raw, false))) return rc;
+      if ((rc = refine_chunk(h, ws, h->s_tow[s], s, &ctr_block, p0, q0, c, in6, out_disp, out_raw, false))) return rc;
     }
   }
   HIP_TRY(h, hipEventRecord(h->ev_join, h->s_low));
@@ -2177,9 +2218,9 @@ int sn_dbg_read(sn_handle* h, const char* what, float* dst, size_t cap, size_t* 
   else if (!strcmp(what, "tile_ctr") && h->ws.tile_ctr) { src = reinterpret_cast<const float*>(h->ws.tile_ctr); cnt = kTileCtrBytes / 4 * h->ws.n_chunks; }
   else if (!strcmp(what, "refine_x") && h->precision == SN_PREC_FP32) { src = h->ws.ref[0]; cnt = (size_t)kC * h->Hp * h->Wp; }
   else if (!strncmp(what, "level", 5) && what[5] >= '1' && what[5] < '0' + h->levels && what[6] == 0) {
-    // hierarchical refinement: the map of level k (first pair of the last chunk refined on tower stream 0)
+    // hierarchical refinement: the map of level k (first pair of the last piece)
     const int k = what[5] - '0';
-    src = h->ws.lvl_disp[k][0];
+    src = h->ws.lvl_disp[k];
     cnt = (size_t)h->tw[k].Hk * h->tw[k].Wk;
   }
   else return SN_ERR_ARG;

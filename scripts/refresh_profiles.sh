@@ -27,14 +27,16 @@ python scripts/mfma_busy.py $(find $OUT/${TAG}_pmc_mfma -name "*counter_collecti
 $T python bench.py --precision f16x3 --no-cpu-baseline --no-end-to-end --steps 20 > $OUT/${TAG}_f16x3_b64_bench.json 2>> $OUT/${TAG}_bench.err
 $T python bench.py --precision fp32 --no-cpu-baseline --no-end-to-end --steps 5 --batch 16 > $OUT/${TAG}_fp32_b16_bench.json 2>> $OUT/${TAG}_bench.err
 $T python bench.py --no-cpu-baseline --no-end-to-end --batch 1 --steps 400 --warmup 20 > $OUT/${TAG}_f16_b1_bench.json 2>> $OUT/${TAG}_bench.err
-$T python bench.py --config c5 --steps 50 > $OUT/${TAG}_c5_f16_b64_bench.json 2>> $OUT/${TAG}_bench.err
+$T python bench.py --config c5 --steps 50 > $OUT/${TAG}_c5_f16_b64_bench.json 2>> $OUT/${TAG}_bench.err          # hierarchical refinement (c5 default)
+$T python bench.py --config c5 --refine single --steps 50 --no-cpu-baseline --no-end-to-end > $OUT/${TAG}_c5_single_f16_b64_bench.json 2>> $OUT/${TAG}_bench.err
+$T python bench.py --refine multi --steps 40 --no-cpu-baseline --no-end-to-end > $OUT/${TAG}_c2_multi_f16_b64_bench.json 2>> $OUT/${TAG}_bench.err
 $T python bench.py --stream 10 --batch 16 > $OUT/${TAG}_stream_c2_b16.json 2>> $OUT/${TAG}_bench.err
 $T python bench.py --config c5 --stream 10 --batch 16 > $OUT/${TAG}_stream_c5_b16.json 2>> $OUT/${TAG}_bench.err
 [ -x scripts/build/mall_probe ] && ./scripts/build/mall_probe > $OUT/${TAG}_mall_probe.txt 2>&1
 python scripts/kstats.py $OUT/${TAG}_f16_b64_kernel_stats.csv 30 > $OUT/${TAG}_kernel_summary.txt
 python scripts/tower_sequence.py $(find $OUT/${TAG}_prof -name "*kernel_trace.csv" | head -1) > $OUT/${TAG}_tower_sequence.txt 2>&1
 cat $OUT/${TAG}_mfma_busy.txt | head -12
-for f in f16_b64 f16x3_b64 fp32_b16 f16_b1 c5_f16_b64; do python - <<PY
+for f in f16_b64 f16x3_b64 fp32_b16 f16_b1 c5_f16_b64 c5_single_f16_b64 c2_multi_f16_b64; do python - <<PY
 import json
 try:
     d=json.loads(open("$OUT/${TAG}_${f}_bench.json").read().strip().splitlines()[-1])

@@ -2,7 +2,9 @@
 """Per-position duration of the refinement tower's launches, from a rocprofv3 --kernel-trace CSV: the tower of one
 chunk is a fixed sequence of launches (6 residual blocks x 2 convs, the last one fused with the head); this prints,
 for each position of the sequence, the median / min / max duration over all chunks of the run.
-    python scripts/tower_sequence.py <kernel_trace.csv>"""
+    python scripts/tower_sequence.py <kernel_trace.csv> [levels]
+levels = 4 for a hierarchical model: the towers of levels 3, 2, 1, 0 follow each other per chunk; the summary is then
+printed per level (sequence index modulo levels)."""
 import csv
 import re
 import sys
@@ -27,11 +29,16 @@ for tag, d in seq:
 if cur:
     chunks.append(cur)
 full = max(len(c) for c in chunks)
-chunks = [c for c in chunks if len(c) == full][len(chunks) // 3:]
-print(f"{len(chunks)} chunks of {full} launches")
-tot = 0.0
-for i in range(full):
-    ds = sorted(c[i][1] for c in chunks)
-    tot += ds[len(ds) // 2]
-    print(f"  {i:2d} {chunks[0][i][0]:18s} med {ds[len(ds)//2]:7.1f} us   min {ds[0]:7.1f}   max {ds[-1]:7.1f}")
-print(f"  sum of medians {tot:.1f} us")
+levels = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+chunks = chunks[len(chunks) // 3 // levels * levels:]
+for lv in range(levels):
+    sel = [c for i, c in enumerate(chunks) if i % levels == lv and len(c) == full]
+    if not sel:
+        continue
+    print(f"{len(sel)} towers of {full} launches" + (f" — level {levels - 1 - lv}" if levels > 1 else ""))
+    tot = 0.0
+    for i in range(full):
+        ds = sorted(c[i][1] for c in sel)
+        tot += ds[len(ds) // 2]
+        print(f"  {i:2d} {sel[0][i][0]:18s} med {ds[len(ds)//2]:7.1f} us   min {ds[0]:7.1f}   max {ds[-1]:7.1f}")
+    print(f"  sum of medians {tot:.1f} us")
