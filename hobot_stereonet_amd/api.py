@@ -316,15 +316,17 @@ class StereoNetHIP:
                     "sn_dbg_conv3d")
         return out
 
-    def dbg_ref_conv_f16(self, x, wt, bias, dil=1, lrelu=False, residual=None):
+    def dbg_ref_conv_f16(self, x, wt, bias, dil=1, lrelu=False, residual=None, tile_w=0):
+        """tile_w: 0 = the width the engine would choose for this launch, 64 / 32 = force that variant (dilation 1, 2)"""
         x = np.ascontiguousarray(x, np.float32)
         wt = np.ascontiguousarray(wt, np.float32)
         bias = np.ascontiguousarray(bias, np.float32)
         _, h, w = x.shape
         out = np.empty((32, h, w), np.float32)
         res = np.ascontiguousarray(residual, np.float32) if residual is not None else None
+        flags = int(bool(lrelu)) | (2 if tile_w == 64 else 4 if tile_w == 32 else 0)
         self._check(self._lib.sn_dbg_ref_conv_f16(self._h, x.ctypes.data, h, w, wt.ctypes.data, bias.ctypes.data, dil,
-                                                  int(lrelu), _np_ptr(res), out.ctypes.data), "sn_dbg_ref_conv_f16")
+                                                  flags, _np_ptr(res), out.ctypes.data), "sn_dbg_ref_conv_f16")
         return out
 
     def dbg_ref_conv_f16x3(self, x, wt, bias, dil=1, lrelu=False, residual=None):

@@ -654,8 +654,27 @@ bool fuse_env() {        // SN_FUSE=3: the dilation-1 blocks of the pipeline run
   return on;
 }
 
+// Tile width of a dilation-1 / -2 launch.  The persistent grid (two workgroups per CU) works through the tiles in
+// rounds and the launch lasts ceil(tiles / workgroups) rounds: 1280x720, two pairs = 3600 8x64 tiles on 512
+// workgroups = 7.03 -> 8 rounds, 12 % of the launch spent on 16 leftover tiles.  8x32 tiles cost ~3 % more per pixel
+// (per-tile waits and barriers, 34/32 instead of 66/64 halo columns) but quantise twice as finely (14.06 -> 15
+// half-rounds = 7.5): measured +1.7 % end to end at 1280x720, +0.7 % at 1248x384.  Chosen per launch from the
+// tile count; force_tw (parity hooks): 64 or 32.
+inline int tower_tile_width(const RefGeom& g, int nimg, int num_cu, int force_tw) {
+  if (force_tw == 32 || force_tw == 64) return force_tw;
+  const long wgs = 2L * num_cu;
+  const long rows = (g.H + 7) / 8;
+  const long r64 = ((long)((g.W + 63) / 64) * rows * nimg + wgs - 1) / wgs;
+  const long r32 = ((long)((g.W + 31) / 32) * rows * nimg + wgs - 1) / wgs;
+  return (double)r32 * 0.5 * 1.03 < (double)r64 ? 32 : 64;
+}
+
 hipError_t ref_conv_f16(hipStream_t st, const RefLayerF16& L, const RefGeom& g, int num_cu, int dil, const uint4* in,
-                        uint4* out, const uint4* res, int nimg, bool lrelu, unsigned* tile_ctr) {
+                        uint4* out, const uint4* res, int nimg, bool lrelu, unsigned* tile_ctr, int force_tw = 0) {
+  if (dil <= 2 && tower_tile_width(g, nimg, num_cu, force_tw) == 32) {
+    if (dil == 1) return launch_ref_f16_v2<1, 32>(st, L, g, num_cu, in, out, res, nimg, lrelu, tile_ctr);
+    if (dil == 2) return launch_ref_f16_v2<2, 32>(st, L, g, num_cu, in, out, res, nimg, lrelu, tile_ctr);
+  }
   switch (dil) {
     case 1: return launch_ref_f16_v2<1, 64>(st, L, g, num_cu, in, out, res, nimg, lrelu, tile_ctr);
     case 2: return launch_ref_f16_v2<2, 64>(st, L, g, num_cu, in, out, res, nimg, lrelu, tile_ctr);
@@ -2056,7 +2075,9 @@ int sn_dbg_ref_conv_f16(sn_handle* h, const float* in, int h_px, int w, const fl
     return SN_ERR_ARG;
   }
   HIP_TRY(h, hipMemsetAsync(ctr, 0, kTileCtrBytes, h->stream));
-  HIP_TRY(h, ref_conv_f16(h->stream, L, g, h->num_cu, dil, din, dout, dres, 1, lrelu != 0, ctr));
+  // lrelu bits 1 / 2: force the 8x64 / 8x32 tile variant of the dilation-1 / -2 kernels (default: chosen per launch)
+  HIP_TRY(h, ref_conv_f16(h->stream, L, g, h->num_cu, dil, din, dout, dres, 1, (lrelu & 1) != 0, ctr,
+                          (lrelu & 2) ? 64 : (lrelu & 4) ? 32 : 0));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   std::vector<_Float16> hout(slots * 8);
   HIP_TRY(h, hipMemcpy(hout.data(), dout, slots * 16, hipMemcpyDeviceToHost));

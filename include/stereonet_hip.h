@@ -202,7 +202,9 @@ int sn_dbg_refin(sn_handle *h, const float *disp_low, const int8_t *in6, int h_p
 int sn_dbg_conv3d(sn_handle *h, const float *in, int d, int h_px, int w, const float *wt,
                   const float *bias, int lrelu, float *out);
 /* one 32->32 3x3 conv (dilation 1/2/4/8) through the fp16 refinement-tower kernel: in / residual / out are
- * fp32 [32][h][w] on the host; the hook converts to the kernel's fp16 NCHW8c layout and back. */
+ * fp32 [32][h][w] on the host; the hook converts to the kernel's fp16 NCHW8c layout and back.
+ * lrelu bit 0 = LeakyReLU; bit 1 / bit 2 force the 8x64 / 8x32 tile variant of the dilation-1 / -2 kernel (default: the
+ * width the engine picks for the launch from its tile count). */
 int sn_dbg_ref_conv_f16(sn_handle *h, const float *in, int h_px, int w, const float *wt, const float *bias,
                         int dil, int lrelu, const float *residual, float *out);
 /* the same layer through the split-operand (SN_PREC_F16X3) kernel */

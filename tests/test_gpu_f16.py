@@ -21,23 +21,28 @@ def eng16(model_factory):
     eng.close()
 
 
-@pytest.mark.parametrize("h,w,dil", [(16, 64, 1), (64, 96, 1), (45, 80, 2), (72, 200, 4), (130, 300, 8),
-                                     (8, 64, 8), (100, 129, 1), (24, 70, 4), (720, 1280, 1)])
-def test_ref_conv_f16_layer(eng16, oracle, h, w, dil):
+@pytest.mark.parametrize("h,w,dil,tw", [(16, 64, 1, 64), (64, 96, 1, 32), (45, 80, 2, 64), (45, 80, 2, 32), (72, 200, 4, 0),
+                                        (130, 300, 8, 0), (8, 64, 8, 0), (100, 129, 1, 64), (100, 129, 1, 32), (24, 70, 4, 0),
+                                        (720, 1280, 1, 64), (720, 1280, 1, 32), (720, 1280, 2, 0)])
+def test_ref_conv_f16_layer(eng16, oracle, h, w, dil, tw):
+    """tw: tile width of the dilation-1 / -2 kernel (8x64 or 8x32; 0 = what the engine picks for this launch)"""
     rng = np.random.default_rng(h * 31 + w + dil)
     x = q16(rng.standard_normal((32, h, w)))
     wt = q16(rng.standard_normal((32, 32, 3, 3)) / 17.0)
     b = rng.standard_normal(32).astype(np.float32)
     ref = oracle.conv2d(x, wt, b, 1, dil, dil)
-    got = eng16.dbg_ref_conv_f16(x, wt, b, dil)
+    got = eng16.dbg_ref_conv_f16(x, wt, b, dil, tile_w=tw)
     scale = np.abs(ref).max()
     assert np.abs(got - q16(ref)).max() <= 2e-3 * scale / 2 + 1e-6      # <= 1 fp16 ulp of the largest value
     assert np.abs(got - ref).mean() < 3e-4 * scale
     res = q16(rng.standard_normal((32, h, w)))
     v = ref + res
     ref2 = np.where(v > 0, v, v * np.float32(0.2))
-    got2 = eng16.dbg_ref_conv_f16(x, wt, b, dil, lrelu=True, residual=res)
+    got2 = eng16.dbg_ref_conv_f16(x, wt, b, dil, lrelu=True, residual=res, tile_w=tw)
     assert np.abs(got2 - ref2).max() <= 1.2e-3 * np.abs(ref2).max() + 1e-6
+    if tw:             # both tile shapes compute the same sums in the same order: bit-identical
+        other = eng16.dbg_ref_conv_f16(x, wt, b, dil, lrelu=True, residual=res, tile_w=96 - tw)
+        assert np.array_equal(got2, other)
 
 
 CASES = [("c96x64_d48", 96, 64, 48, 3), ("c160x96_d96", 160, 96, 96, 4), ("c100x52_d32", 100, 52, 32, 5)]
