@@ -101,14 +101,17 @@ def test_node_init_fails_loudly_without_gpu(hostlib, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ingest", ["nv12", "tensor"])
-def test_stereonet_node_end_to_end(hostlib, oracle, weights_blob, tmp_path, ingest):
+@pytest.mark.parametrize("ingest,multi", [("nv12", False), ("tensor", False), ("nv12", True)])
+def test_stereonet_node_end_to_end(hostlib, oracle, weights_blob, weights_multi, tmp_path, ingest, multi):
     """hbmem NV12 frame in -> /stereonet_node_output message out, payload = int32 tensor || JPEG(left).
     ingest = nv12: the node hands the raw message payload to the backend (split + CvtNV12Data2Tensors on the GPU, the
-    default); tensor: the reference's host steps and Run() on the int8 tensor.  Both must publish the same bytes."""
+    default); tensor: the reference's host steps and Run() on the int8 tensor.  Both must publish the same bytes.
+    multi: model_file holds the hierarchical-refinement network — nothing else changes for the node."""
     from PIL import Image
     w, h, d = 96, 64, 48
     m = str(tmp_path / "m.snw")
+    if multi:
+        weights_blob = weights_multi
     weights.save_snw(m, weights_blob, w, h, d)
     # band-limited luma (white noise is pathological for JPEG), random chroma bytes
     lt, rt = synth.stereo_pair_u8(w, h, d, 8)
