@@ -2296,23 +2296,30 @@ __global__ __launch_bounds__(256, 1) void k_ref_conv_f16x3(const uint4* __restri
 // and fragment b of the weights holds the hi weights at entries 4..7 (for the int8 source entries 5..7 are zero).
 // The disparity comes from `disp_low` upsampled by `ups` (x16 from the soft-argmin map, x2 from the level below).
 // ------------------------------------------------------------------------------------------
+// VMEM instructions are what a tile's time is made of (as in the tower, §5 of DESIGN.md): the four pixels of a staging
+// unit share their four bilinear taps when the upsample is x16 (an aligned group of four never straddles a cell
+// boundary, which lies between columns 16n+7 and 16n+8): 4 instead of 16 tap loads per thread; outputs go out with
+// SGPR-base stores on precomputed per-lane offsets; the accumulators start at the bias / at an inline zero through the
+// first MFMA's C operand (50.5 -> 41.5 us per two pairs at 1280x720; __launch_bounds__(256, 2): left alone hipcc spent
+// 335 registers on it and halved the occupancy).
+template <int TW_>
 struct RefInTile {
-  static constexpr int TH = 8, TW = 64;
+  static constexpr int TH = 8, TW = TW_, CSEG = TW / 32;
   static constexpr int ROWS = TH + 2, COLS = TW + 8;        // staged window starts 4 px left of the tile (dword aligned)
   static constexpr int BUF = ROWS * COLS;                   // slots per buffer
   static constexpr int LDS_BYTES = 2 * BUF * 16;
-  static constexpr int NUNIT = ROWS * (COLS / 4);           // 4-pixel staging units per tile (180 <= 256 threads)
-  static constexpr int SPW = TH * (TW / 32) / 4;
+  static constexpr int NUNIT = ROWS * (COLS / 4);           // 4-pixel staging units per tile (180 / 100 <= 256 threads)
+  static constexpr int SPW = TH * CSEG / 4;
 };
 
-template <bool SPLIT, bool PYR>
-__global__ __launch_bounds__(256) void k_refin_f16(const float* __restrict__ disp_low,   // [n][hl][wl]
+template <bool SPLIT, bool PYR, int TW>
+__global__ __launch_bounds__(256, 2) void k_refin_f16(const float* __restrict__ disp_low,   // [n][hl][wl]
                                                    const void* __restrict__ img_src,     // int8 [n][6][H][W] / PYR: float [n][3][g.H][g.W]
                                                    int hl, int wl, int H, int W, float inv_d, UpScale ups,
                                                    const uint4* __restrict__ wfrag,      // [5][a|b][64]
                                                    const float* __restrict__ bias, uint4* __restrict__ out,
                                                    size_t lo_off_bytes, RefGeom g, int nimg, int al4) {
-  using T = RefInTile;
+  using T = RefInTile<TW>;
   static_assert(T::NUNIT <= 256, "one staging unit per thread");
   extern __shared__ __attribute__((aligned(16))) uint4 s_px[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -2326,7 +2333,7 @@ __global__ __launch_bounds__(256) void k_refin_f16(const float* __restrict__ dis
     wa[t] = *reinterpret_cast<const half8*>(&a);
     wb[t] = *reinterpret_cast<const half8*>(&b);
   }
-  float bv[16];
+  f32x16 bv;
 #pragma unroll
   for (int r = 0; r < 16; ++r) bv[r] = bias[(r & 3) + 8 * (r >> 2) + 4 * gk];
   int koff[5];                               // slot offset of tap 2t + g inside the staged window
@@ -2344,6 +2351,7 @@ __global__ __launch_bounds__(256) void k_refin_f16(const float* __restrict__ dis
   const bool unit = tid < T::NUNIT;
   const int8_t* const in6 = reinterpret_cast<const int8_t*>(img_src);
   const float* const pyr = reinterpret_cast<const float*>(img_src);
+  const bool x16 = ups.rs == 1.0f / 16.0f;                  // uniform
   uint32_t pimg[3];
   float pf[PYR ? 3 : 1][4];
   float pd[4];
@@ -2361,9 +2369,29 @@ __global__ __launch_bounds__(256) void k_refin_f16(const float* __restrict__ dis
     if (!unit || (unsigned)y >= (unsigned)g.H) return;
     const float* dl = disp_low + (size_t)img * hl * wl;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      pval[k] = (unsigned)(x + k) < (unsigned)g.W;
-      if (pval[k]) pd[k] = upsample_map(dl, hl, wl, y, x + k, ups) * inv_d;
+    for (int k = 0; k < 4; ++k) pval[k] = (unsigned)(x + k) < (unsigned)g.W;
+    if (x16 && x >= 0) {
+      // the four pixels of an aligned group lie in one cell of the x16 grid: one set of taps (upsample_map's arithmetic)
+      float sy = ((float)y + 0.5f) * ups.rs - 0.5f;
+      sy = sy < 0.f ? 0.f : sy;
+      float sx0 = ((float)x + 0.5f) * ups.rs - 0.5f;
+      sx0 = sx0 < 0.f ? 0.f : sx0;
+      const int y0 = (int)sy, x0 = (int)sx0;
+      const int y1 = y0 < hl - 1 ? y0 + 1 : y0, x1 = x0 < wl - 1 ? x0 + 1 : x0;
+      const float ly = sy - (float)y0, hy = 1.0f - ly;
+      const float a00 = dl[y0 * wl + x0], a01 = dl[y0 * wl + x1], a10 = dl[y1 * wl + x0], a11 = dl[y1 * wl + x1];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float sx = ((float)(x + k) + 0.5f) * ups.rs - 0.5f;
+        sx = sx < 0.f ? 0.f : sx;
+        const float lx = sx - (float)x0, hx = 1.0f - lx;
+        const float v = hy * (hx * a00 + lx * a01) + ly * (hx * a10 + lx * a11);
+        pd[k] = pval[k] ? v * ups.mul * inv_d : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (pval[k]) pd[k] = upsample_map(dl, hl, wl, y, x + k, ups) * inv_d;
     }
     if (PYR) {
 #pragma unroll
@@ -2423,53 +2451,64 @@ __global__ __launch_bounds__(256) void k_refin_f16(const float* __restrict__ dis
   __syncthreads();
   int cur = 0;
   const unsigned plane_b = (unsigned)g.Hs * (unsigned)g.Ws * 16u;
+  unsigned io_voff[T::SPW];                  // per-lane byte offset of this lane's 8 output bytes inside the tile
+#pragma unroll
+  for (int s = 0; s < T::SPW; ++s) {
+    const int seg = wave * T::SPW + s;
+    io_voff[s] = ((unsigned)(seg / T::CSEG) * (unsigned)g.Ws + (unsigned)((seg % T::CSEG) * 32 + j)) * 16u + gk * 8u;
+  }
   for (; tile < total; tile += gridDim.x) {
     const int nxt = tile + gridDim.x;
     if (nxt < total) fetch(nxt);
     const uint4* buf = s_px + cur * T::BUF;
     f32x16 acc0[T::SPW], acc1[T::SPW];
+    f32x16 zero;
 #pragma unroll
-    for (int s = 0; s < T::SPW; ++s)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        acc0[s][r] = bv[r];
-        acc1[s][r] = 0.f;
-      }
+    for (int r = 0; r < 16; ++r) zero[r] = 0.f;
 #pragma unroll
     for (int t = 0; t < 5; ++t) {
 #pragma unroll
       for (int s = 0; s < T::SPW; ++s) {
         const int seg = wave * T::SPW + s;
-        const int srow = seg >> 1, scol = (seg & 1) * 32;
+        const int srow = seg / T::CSEG, scol = (seg % T::CSEG) * 32;
         const uint4 xv = buf[koff[t] + srow * T::COLS + scol + j];
         const half8 xb = *reinterpret_cast<const half8*>(&xv);
-        acc0[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[t], xb, acc0[s], 0, 0, 0);
-        acc1[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[t], xb, acc1[s], 0, 0, 0);
+        // the first K-step starts the accumulators at the bias / at zero through the C operand (no seeding moves)
+        acc0[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[t], xb, t == 0 ? bv : acc0[s], 0, 0, 0);
+        acc1[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[t], xb, t == 0 ? zero : acc1[s], 0, 0, 0);
       }
     }
     {
       const int img = tile / per_img, rem = tile - img * per_img;
       const int ty = rem / g.tiles_x, tx = rem - ty * g.tiles_x;
+      const int y0 = ty * T::TH, x0 = tx * T::TW;
+      const bool interior = y0 + T::TH <= g.H && x0 + T::TW <= g.W;            // wave-uniform
+      // uniform byte offset of (image, block 0, padded row y0, padded col x0); the host keeps a tensor below 4 GiB
+      const unsigned tb = (((unsigned)img * 4u * (unsigned)g.Hs + (unsigned)(y0 + kRefPad)) * (unsigned)g.Ws +
+                           (unsigned)(x0 + kRefPad)) * 16u;
 #pragma unroll
       for (int s = 0; s < T::SPW; ++s) {
-        const int seg = wave * T::SPW + s;
-        const int y = ty * T::TH + (seg >> 1), x = tx * T::TW + (seg & 1) * 32 + j;
-        if (y < g.H && x < g.W) {
-          char* o = reinterpret_cast<char*>(out) +
-                    ((((size_t)img * 4) * g.Hs + (y + kRefPad)) * g.Ws + (x + kRefPad)) * 16 + gk * 8;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            half4 hh, hl4;
+        for (int q = 0; q < 4; ++q) {
+          char* oq = reinterpret_cast<char*>(out) + (tb + (unsigned)q * plane_b);                  // uniform
+          char* oql = oq + lo_off_bytes;
+          half4 hh, hl4;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              float v = acc0[s][4 * q + e] + acc1[s][4 * q + e] * kSplitInv;
-              v = lrelu_fast(v);
-              const _Float16 hi = (_Float16)v;
-              hh[e] = hi;
-              if (SPLIT) hl4[e] = (_Float16)((v - (float)hi) * kSplitScale);
-            }
-            *reinterpret_cast<half4*>(o + (size_t)q * plane_b) = hh;
-            if (SPLIT) *reinterpret_cast<half4*>(o + (size_t)q * plane_b + lo_off_bytes) = hl4;
+          for (int e = 0; e < 4; ++e) {
+            float v = acc0[s][4 * q + e] + acc1[s][4 * q + e] * kSplitInv;
+            v = lrelu_fast(v);
+            const _Float16 hi = (_Float16)v;
+            hh[e] = hi;
+            if (SPLIT) hl4[e] = (_Float16)((v - (float)hi) * kSplitScale);
+          }
+          bool ok = true;
+          if (!interior) {
+            const int seg = wave * T::SPW + s;
+            ok = y0 + seg / T::CSEG < g.H && x0 + (seg % T::CSEG) * 32 + j < g.W;   // never write the zero border
+          }
+          if (ok) {
+            *reinterpret_cast<half4*>(oq + io_voff[s]) = hh;
+            if (SPLIT) *reinterpret_cast<half4*>(oql + io_voff[s]) = hl4;
           }
         }
       }

@@ -308,23 +308,36 @@ int upload_refin_f16(sn_handle* h, const HostLayer& l, Down0F16* out) {
   return SN_OK;
 }
 
-// img_src: the int8 model input [n][6][H][W] (pyr = false) or the float image pyramid level [n][3][g.H][g.W]
-hipError_t launch_refin_f16(hipStream_t st, const Down0F16& L, const float* bias, const float* disp_low,
-                            const void* img_src, bool pyr, int hl, int wl, int H, int W, float inv_d, UpScale ups,
-                            const RefGeom& g, int nimg, uint4* out, bool split, size_t lo_off_bytes, int num_cu) {
+// img_src: the int8 model input [n][6][H][W] (pyr = false) or the float image pyramid level [n][3][g.H][g.W].
+template <int TW>
+hipError_t launch_refin_f16_tw(hipStream_t st, const Down0F16& L, const float* bias, const float* disp_low,
+                               const void* img_src, bool pyr, int hl, int wl, int H, int W, float inv_d, UpScale ups,
+                               RefGeom g, int nimg, uint4* out, bool split, size_t lo_off_bytes, int num_cu) {
+  using T = RefInTile<TW>;
+  g.tiles_x = (g.W + TW - 1) / TW;
+  g.tiles_y = (g.H + T::TH - 1) / T::TH;
   const int total = g.tiles_x * g.tiles_y * nimg;
   int blocks = 2 * num_cu;
   if (blocks > total) blocks = total;
   const int al4 = !pyr && (W % 4 == 0) && (reinterpret_cast<uintptr_t>(img_src) % 4 == 0);
-#define SN_REFIN(S, P)                                                                                              \
-  hipLaunchKernelGGL((k_refin_f16<S, P>), dim3(blocks), dim3(256), RefInTile::LDS_BYTES, st, disp_low, img_src, hl, wl, \
-                     H, W, inv_d, ups, L.wfrag, bias, out, lo_off_bytes, g, nimg, al4)
+#define SN_REFIN(S, P)                                                                                             \
+  hipLaunchKernelGGL((k_refin_f16<S, P, TW>), dim3(blocks), dim3(256), T::LDS_BYTES, st, disp_low, img_src, hl, wl, H, \
+                     W, inv_d, ups, L.wfrag, bias, out, lo_off_bytes, g, nimg, al4)
   if (split && pyr) SN_REFIN(true, true);
   else if (split) SN_REFIN(true, false);
   else if (pyr) SN_REFIN(false, true);
   else SN_REFIN(false, false);
 #undef SN_REFIN
   return hipGetLastError();
+}
+
+// (8x32 tiles, which pay off for the tower's dilation-1 / -2 launches, were measured for this kernel too: 54.8 us
+// against 41.5 us per two pairs at 1280x720 — only 100 of the 256 threads have a staging unit then.)
+hipError_t launch_refin_f16(hipStream_t st, const Down0F16& L, const float* bias, const float* disp_low,
+                            const void* img_src, bool pyr, int hl, int wl, int H, int W, float inv_d, UpScale ups,
+                            const RefGeom& g, int nimg, uint4* out, bool split, size_t lo_off_bytes, int num_cu) {
+  return launch_refin_f16_tw<64>(st, L, bias, disp_low, img_src, pyr, hl, wl, H, W, inv_d, ups, g, nimg, out, split,
+                                 lo_off_bytes, num_cu);
 }
 
 hipError_t launch_down0_f16(hipStream_t st, const Down0F16& L, const float* bias, const int8_t* in6, int H, int W,
