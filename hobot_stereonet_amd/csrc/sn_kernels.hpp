@@ -793,7 +793,7 @@ struct Down0Tile {
 };
 
 template <int TC>
-__global__ __launch_bounds__(256) void k_down0_f16(const int8_t* __restrict__ in6, int H, int W,
+__global__ __launch_bounds__(256, 2) void k_down0_f16(const int8_t* __restrict__ in6, int H, int W,
                                                    const uint4* __restrict__ wfrag,   // [8][hi|lo][64]
                                                    const float* __restrict__ bias, float* __restrict__ out, int Ho,
                                                    int Wo, int tiles_x, int tiles_y, int nimg, int lrelu,
@@ -811,7 +811,7 @@ __global__ __launch_bounds__(256) void k_down0_f16(const int8_t* __restrict__ in
     wh[t] = *reinterpret_cast<const half8*>(&a);
     wl[t] = *reinterpret_cast<const half8*>(&b);
   }
-  float bv[16];
+  f32x16 bv;
 #pragma unroll
   for (int r = 0; r < 16; ++r) bv[r] = bias[(r & 3) + 8 * (r >> 2) + 4 * g];
 
@@ -878,18 +878,23 @@ __global__ __launch_bounds__(256) void k_down0_f16(const int8_t* __restrict__ in
   commit(s_x);
   __syncthreads();
   int cur = 0;
+  // outputs: uniform 64-bit address of (image, block q, part, tile origin) + a fixed 32-bit offset per lane
+  unsigned io_voff[T::SPW];
+#pragma unroll
+  for (int s = 0; s < T::SPW; ++s) {
+    const int seg = wave * T::SPW + s;
+    io_voff[s] = ((unsigned)(seg / T::CSEG) * (unsigned)Wo + (unsigned)((seg % T::CSEG) * 32 + j)) * 16u + g * 8u;
+  }
+  const size_t plane_b = (size_t)Ho * Wo * 16;                 // bytes of one (block, part) plane
+  const float slope = lrelu ? kSlope : 1.0f;                  // max(v, v) = v: one code path
+  f32x16 zero;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) zero[r] = 0.f;
   for (; tile < total; tile += gridDim.x) {
     const int nxt = tile + gridDim.x;
     if (nxt < total) fetch(nxt);
     const _Float16* buf = s_x + cur * T::BUF;
     f32x16 acc0[T::SPW], acc1[T::SPW];
-#pragma unroll
-    for (int s = 0; s < T::SPW; ++s)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        acc0[s][r] = bv[r];
-        acc1[s][r] = 0.f;
-      }
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
 #pragma unroll
@@ -904,36 +909,40 @@ __global__ __launch_bounds__(256) void k_down0_f16(const int8_t* __restrict__ in
         xv.z = px[2];
         xv.w = px[3];
         const half8 xb = *reinterpret_cast<const half8*>(&xv);
-        acc0[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t], xb, acc0[s], 0, 0, 0);
-        acc1[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[t], xb, acc1[s], 0, 0, 0);
+        // first K-step: accumulators start at the bias / at zero through the C operand (no seeding moves)
+        acc0[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t], xb, t == 0 ? bv : acc0[s], 0, 0, 0);
+        acc1[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[t], xb, t == 0 ? zero : acc1[s], 0, 0, 0);
       }
     }
     {
       const int tx = tile % tiles_x, t2 = tile / tiles_x;
       const int ty = t2 % tiles_y, img = t2 / tiles_y;
-      const size_t plane_o = (size_t)Ho * Wo;
+      const int y0 = ty * T::TR, x0 = tx * TC;
+      const bool interior = y0 + T::TR <= Ho && x0 + TC <= Wo;             // wave-uniform
+      // split-slot tensor for the next down-conv (see SlotIn / low_slot_index): [img][4 blocks][hi | lo][Ho][Wo]
+      char* const tbase = reinterpret_cast<char*>(out) + (size_t)img * 8 * plane_b + ((size_t)y0 * Wo + x0) * 16;
 #pragma unroll
       for (int s = 0; s < T::SPW; ++s) {
-        const int seg = wave * T::SPW + s;
-        const int y = ty * T::TR + seg / T::CSEG, x = tx * TC + (seg % T::CSEG) * 32 + j;
-        if (y < Ho && x < Wo) {
-          {                     // split-slot tensor for the next down-conv (see SlotIn)
-            char* o = reinterpret_cast<char*>(out);
+        bool ok = true;
+        if (!interior) {
+          const int seg = wave * T::SPW + s;
+          ok = y0 + seg / T::CSEG < Ho && x0 + (seg % T::CSEG) * 32 + j < Wo;
+        }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const size_t bh_ = low_slot_index(img, q, 0, y, x, Ho, Wo) * 16 + g * 8;
-              half4 hh, hl;
+        for (int q = 0; q < 4; ++q) {
+          char* oq = tbase + (size_t)(2 * q) * plane_b;                    // uniform
+          half4 hh, hl;
 #pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                float v = acc0[s][4 * q + e] + acc1[s][4 * q + e] * kSplitInv;
-                if (lrelu) v = v > 0.f ? v : v * kSlope;
-                const _Float16 hi = (_Float16)v;
-                hh[e] = hi;
-                hl[e] = (_Float16)((v - (float)hi) * kSplitScale);
-              }
-              *reinterpret_cast<half4*>(o + bh_) = hh;
-              *reinterpret_cast<half4*>(o + bh_ + plane_o * 16) = hl;
-            }
+          for (int e = 0; e < 4; ++e) {
+            float v = acc0[s][4 * q + e] + acc1[s][4 * q + e] * kSplitInv;
+            v = fmaxf(v, v * slope);
+            const _Float16 hi = (_Float16)v;
+            hh[e] = hi;
+            hl[e] = (_Float16)((v - (float)hi) * kSplitScale);
+          }
+          if (ok) {
+            *reinterpret_cast<half4*>(oq + io_voff[s]) = hh;
+            *reinterpret_cast<half4*>(oq + plane_b + io_voff[s]) = hl;
           }
         }
       }
