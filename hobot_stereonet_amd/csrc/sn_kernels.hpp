@@ -643,12 +643,13 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
     for (int r = 0; r < (HASRES ? 16 : 1); ++r) rv[r] = 0.f;
     if (HASRES && e_in) {
       if (OUTSLOT) {
-        const char* rs = reinterpret_cast<const char*>(a.res);
+        const char* rs = reinterpret_cast<const char*>(a.res) + (size_t)e_img * 8 * plane_o * 16;     // uniform
+        const unsigned lane_off = ((unsigned)e_y * (unsigned)a.Wo + (unsigned)e_x) * 16u + gh * 8u;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const size_t bh_ = low_slot_index(e_img, q, 0, e_y, e_x, a.Ho, a.Wo) * 16 + gh * 8;
-          const half4 rh = *reinterpret_cast<const half4*>(rs + bh_);
-          const half4 rl = *reinterpret_cast<const half4*>(rs + bh_ + plane_o * 16);
+          const char* rq = rs + (size_t)(2 * q) * plane_o * 16;
+          const half4 rh = *reinterpret_cast<const half4*>(rq + lane_off);
+          const half4 rl = *reinterpret_cast<const half4*>(rq + plane_o * 16 + lane_off);
 #pragma unroll
           for (int e = 0; e < 4; ++e) rv[4 * q + e] = (float)rh[e] + (float)rl[e] * kSplitInv;
         }
@@ -661,13 +662,9 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
     if (nxt < t_end) fetch(nxt);
 
     f32x16 acc0[2], acc1[2];
+    f32x16 zero;                        // C operand of the first K-step (an inline constant: no seeding moves)
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        acc0[s][r] = 0.f;
-        acc1[s][r] = 0.f;
-      }
+    for (int r = 0; r < 16; ++r) zero[r] = 0.f;
     // B operands are fetched one K-step ahead (this kernel runs one wave per SIMD: an LDS read issued right
     // before its MFMA would expose the full LDS latency 100 times per tile); the scheduling barriers keep hipcc
     // from sinking the reads back to their uses.
@@ -697,8 +694,8 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
       for (int s = 0; s < 2; ++s) {
         const half8 xh = *reinterpret_cast<const half8*>(&bh[cur][s]);
         const half8 xl = *reinterpret_cast<const half8*>(&bl[cur][s]);
-        acc0[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[k], xh, acc0[s], 0, 0, 0);
-        acc1[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[k], xh, acc1[s], 0, 0, 0);
+        acc0[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[k], xh, k == 0 ? zero : acc0[s], 0, 0, 0);
+        acc1[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[k], xh, k == 0 ? zero : acc1[s], 0, 0, 0);
         acc1[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[k], xl, acc1[s], 0, 0, 0);
       }
       // staging copies of the next tile: FPK per K-step from the start of the loop, so that the last of them still
@@ -730,23 +727,26 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
         if (OUTSLOT) {
           // channel block q = r >> 2 holds couts 8q .. 8q+7; this lane owns 4gh .. 4gh+3 of it: one 8-byte store
           // into the hi slot and one into the lo slot (the two half-waves fill the 16-byte slot together)
-          char* o = reinterpret_cast<char*>(a.out);
+          // address = uniform 64-bit base of (image, block q, hi) + the lane's pixel offset inside the plane
+          char* const o = reinterpret_cast<char*>(a.out) + (size_t)e_img * 8 * plane_o * 16;
+          const unsigned lane_off = ((unsigned)e_y * (unsigned)a.Wo + (unsigned)e_x) * 16u + gh * 8u;
+          const float slope = a.lrelu ? kSlope : 1.0f;        // max(v, v) = v: one code path
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const size_t bh_ = low_slot_index(e_img, q, 0, e_y, e_x, a.Ho, a.Wo) * 16 + gh * 8;
+            char* oq = o + (size_t)(2 * q) * plane_o * 16;                          // uniform
             half4 hh, hl;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const int r = 4 * q + e;
               float v = acc0[0][r] + acc1[0][r] * kSplitInv + src[r * 64] + s_bias[8 * q + 4 * gh + e];
               if (HASRES) v += rv[HASRES ? r : 0];
-              if (a.lrelu) v = v > 0.f ? v : v * kSlope;
+              v = fmaxf(v, v * slope);
               const _Float16 hi = (_Float16)v;
               hh[e] = hi;
               hl[e] = (_Float16)((v - (float)hi) * kSplitScale);
             }
-            *reinterpret_cast<half4*>(o + bh_) = hh;
-            *reinterpret_cast<half4*>(o + bh_ + plane_o * 16) = hl;
+            *reinterpret_cast<half4*>(oq + lane_off) = hh;
+            *reinterpret_cast<half4*>(oq + plane_o * 16 + lane_off) = hl;
           }
         } else {
           const size_t base = (size_t)e_img * kC * plane_o + (size_t)e_y * a.Wo + e_x;
