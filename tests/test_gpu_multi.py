@@ -100,3 +100,36 @@ def test_multi_full_size_1280x720(model_factory, oracle, weights_multi):
     epe = float(np.abs(disp - odisp).mean())
     print(f"multi 1280x720 D=192 f16: EPE {epe:.3e} px")
     assert epe < EPE_TOL
+
+
+def _random_cases():
+    rng = np.random.default_rng(2026)
+    cases = []
+    for i in range(10):
+        w = int(rng.integers(34, 330))
+        h = int(rng.integers(18, 200))
+        d = int(rng.choice([16, 32, 48, 64, 96, 128, 192, 256]))
+        d = min(d, max(16, (w // 2) // 16 * 16))              # keep some columns with a full disparity range
+        prec = [api.PREC_F16, api.PREC_FP32, api.PREC_F16X3][i % 3]
+        cases.append((w, h, d, prec, bool(i % 2), int(rng.integers(1, 6))))
+    return cases
+
+
+@pytest.mark.parametrize("w,h,d,prec,multi,n", _random_cases())
+def test_random_shapes_vs_oracle(model_factory, oracle, weights_blob, weights_multi, w, h, d, prec, multi, n):
+    """Seeded random geometries (odd sizes, widths that are not multiples of 4 / 16 / 32 / 64, every D), batch sizes
+    and both refinement forms against the oracle: exercises the tile-overhang paths of every kernel variant."""
+    blob = weights_multi if multi else weights_blob
+    xs = np.stack([synth.model_input_i8(w, h, d, 700 + i) for i in range(n)])
+    with api.StereoNetHIP(model_factory(w, h, d, multi=multi), max_batch=n, precision=prec, refine_chunk=2, piece=3) as eng:
+        disp, raw = eng.infer(xs)
+        one, one_raw = eng.infer(xs[n - 1])
+    disp = disp.reshape(n, h, w)
+    raw = raw.reshape(n, h, w)
+    assert np.array_equal(disp[n - 1], one.reshape(h, w)) and np.array_equal(raw[n - 1], one_raw.reshape(h, w))
+    for i in (0, n - 1):
+        odisp, oraw, _ = oracle.forward(blob, xs[i], d)
+        err = np.abs(disp[i] - odisp)
+        print(f"{w}x{h} D={d} prec={prec} multi={multi} n={n} pair {i}: EPE {err.mean():.2e} max {err.max():.2e}")
+        assert err.mean() < EPE_TOL and np.isfinite(disp[i]).all()
+        assert raw[i].min() >= 0
