@@ -133,3 +133,20 @@ def test_random_shapes_vs_oracle(model_factory, oracle, weights_blob, weights_mu
         print(f"{w}x{h} D={d} prec={prec} multi={multi} n={n} pair {i}: EPE {err.mean():.2e} max {err.max():.2e}")
         assert err.mean() < EPE_TOL and np.isfinite(disp[i]).all()
         assert raw[i].min() >= 0
+
+
+def test_large_geometry_and_refusal(model_factory, oracle, weights_blob):
+    """A frame larger than any BASELINE config (2048x1088, D=256: 2.4x the pixels of 1280x720) against the oracle, and the
+    size sn_create must refuse (a tensor would pass the 32-bit byte offsets the kernels use)."""
+    w, h, d = 2048, 1088, 256
+    x = synth.model_input_i8(w, h, d, 77)
+    with api.StereoNetHIP(model_factory(w, h, d), precision=api.PREC_F16) as eng:
+        assert eng.refine_chunk >= 1
+        disp, raw = eng.infer(x)
+    odisp, _, _ = oracle.forward(weights_blob, x, d)
+    epe = float(np.abs(disp - odisp).mean())
+    print(f"2048x1088 D=256 f16: EPE {epe:.3e} px")
+    assert epe < EPE_TOL and raw.min() >= 0
+    with pytest.raises(api.StereoNetError):
+        api.StereoNetHIP(model_factory(w, h, d), width=16384, height=16384, precision=api.PREC_F16, refine_chunk=8,
+                         max_batch=8)
