@@ -465,7 +465,12 @@ struct X3sTile {
   static constexpr int NSEG = (TR / SEGH) * (TC / SEGW), SPW = NSEG / 2;
   static constexpr int ROWS_IN = (TR - 1) * STRIDE + KS;
   static constexpr int COLS_IN = (TC - 1) * STRIDE + KS;
-  static constexpr int HALF = (COLS_IN + 1) / 2;
+  // stride 2: columns are split by parity into two halves of a row.  The staging store (ds_write_b128, groups of 8
+  // consecutive lanes, bank = dword address mod 32) alternates between the halves, so the second half must start
+  // 4 slots (mod 8) after the first for the eight slots of a group to cover the 32 banks once: HALF = 4 (mod 8)
+  // (34 -> 36 for the 5x5 tile; PMC: 22 % of that kernel's LDS cycles were bank conflicts).
+  static constexpr int HALF0 = (COLS_IN + 1) / 2;
+  static constexpr int HALF = STRIDE == 1 ? HALF0 : HALF0 + ((4 - HALF0 % 8) + 8) % 8;
   static constexpr int PITCH = STRIDE == 1 ? COLS_IN : 2 * HALF;
   static constexpr int PLANE = ROWS_IN * PITCH;
   static constexpr int NSLOT = NCB * ROWS_IN * COLS_IN;
@@ -513,14 +518,22 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
     }
 #endif
   }
-  // per-lane slot offset of each of the wave's two segments (pixel j of the segment, channel-block parity gh)
+  // Pixel of the segment that lane j computes: row pr, column pc.  A ds_read_b128 is served in groups of 16 lanes
+  // ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} per half-wave) that must hit 64 distinct banks = 16 distinct slots modulo
+  // 16.  With one row of 32 pixels per segment the slots are consecutive: conflict-free.  With two rows of 16 (SEGW = 16)
+  // the second row starts PITCH slots later (18 for a 16-column 3x3 tile): taken in plain order, lanes 20-27 land on
+  // the banks of lanes 12-15 (PMC: 35-40 % of these kernels' LDS cycles were bank conflicts).  Rotating the columns of
+  // row pr by -pr * PITCH makes the slot of lane j congruent to j modulo 16 again; the epilogue uses the same map.
+  constexpr int ROT = (SEGW == 16 && STRIDE == 1) ? T::PITCH % 16 : 0;
+  const int pr = j / SEGW, pc = (SEGW == 16) ? ((j % SEGW) - pr * ROT) & 15 : j % SEGW;
+  // per-lane slot offset of each of the wave's two segments (pixel (pr, pc) of the segment, channel-block parity gh)
   // slot 0 = the segment this wave finishes (pset * 2 + khalf), slot 1 = the one whose partial it ships to its
   // pair partner (wave ^ 2: same pixels, other K half, the roles swapped)
   int lane_base[2];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int seg = pset * 2 + (s == 0 ? khalf : 1 - khalf);
-    const int srow = (seg / (TC / SEGW)) * T::SEGH + j / SEGW, scol = (seg % (TC / SEGW)) * SEGW + j % SEGW;
+    const int srow = (seg / (TC / SEGW)) * T::SEGH + pr, scol = (seg % (TC / SEGW)) * SEGW + pc;
     lane_base[s] = (khalf * T::HCB + gh) * T::PLANE + srow * STRIDE * T::PITCH + scol;
   }
   if (tid < kC) s_bias[tid] = a.bias[tid];
@@ -635,8 +648,8 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
     const int e_tx = tile % a.tiles_x, e_t2 = tile / a.tiles_x;
     const int e_ty = e_t2 % a.tiles_y, e_img = e_t2 / a.tiles_y;
     const int e_seg = pset * 2 + khalf;
-    const int e_y = e_ty * TR + (e_seg / (TC / SEGW)) * T::SEGH + j / SEGW;
-    const int e_x = e_tx * TC + (e_seg % (TC / SEGW)) * SEGW + j % SEGW;
+    const int e_y = e_ty * TR + (e_seg / (TC / SEGW)) * T::SEGH + pr;
+    const int e_x = e_tx * TC + (e_seg % (TC / SEGW)) * SEGW + pc;
     const bool e_in = e_y < a.Ho && e_x < a.Wo;
     float rv[HASRES ? 16 : 1];
 #pragma unroll
