@@ -1182,6 +1182,21 @@ __device__ __forceinline__ void block_barrier() {
   asm volatile("" ::: "memory");
 }
 
+// Exact unsigned division by a loop-invariant divisor: q = umulhi(t, floor((2^32 - 1) / d)) is floor(t / d) or one
+// less for every t < 2^32 (t m / 2^32 > t / d - 1), so one conditional correction finishes it.
+struct FastDiv {
+  unsigned d, m;
+  __device__ __forceinline__ explicit FastDiv(unsigned d_) : d(d_), m(0xFFFFFFFFu / d_) {}
+  __device__ __forceinline__ unsigned divmod(unsigned t, unsigned& rem) const {
+    unsigned q = __umulhi(t, m);
+    unsigned r = t - q * d;
+    const bool up = r >= d;
+    q += up ? 1u : 0u;
+    rem = up ? r - d : r;
+    return q;
+  }
+};
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -1292,20 +1307,26 @@ __global__ __launch_bounds__(256, MINW) void k_ref_conv_f16_v2(const uint4* __re
     io_voff[s] = ((unsigned)(seg / T::CSEG) * (unsigned)g.Ws + (unsigned)((seg % T::CSEG) * 32 + j)) * 16u + gh * 8u;
   }
 
+  // tile index -> (image, row, column): FastDiv (one multiply-high + one correction per division); hipcc's general
+  // signed division was ~40 scalar instructions per tile in a loop whose instruction count is what bounds it.
+  const FastDiv div_img((unsigned)per_img), div_tx((unsigned)g.tiles_x);
   auto tile_xy = [&](int t, int& img, int& y0, int& x0) {      // t = global tile index
-    img = t / per_img;
-    const int rem = t - img * per_img;
-    const int ty = rem / g.tiles_x;
+    unsigned rem, tx;
+    img = (int)div_img.divmod((unsigned)t, rem);
+    const int ty = (int)div_tx.divmod(rem, tx);
     y0 = ty * T::TH;
-    x0 = (rem - ty * g.tiles_x) * T::TW;
+    x0 = (int)tx * T::TW;
   };
   // uniform byte offset of (image, channel block 0, padded row y, padded col x)
   auto tile_base = [&](int img, int y, int x) -> unsigned {
     return (((unsigned)img * 4u * (unsigned)g.Hs + (unsigned)(y + kRefPad)) * (unsigned)g.Ws + (unsigned)(x + kRefPad)) * 16u;
   };
-  auto issue = [&](int gp, int img, int y0, int x0) {         // DMA group of phase gp (tile img,y0,x0) -> ring slot gp % 3
-    const char* src = reinterpret_cast<const char*>(in) + (tile_base(img, y0 - DIL, x0 - DIL) + 2u * (gp & 1) * plane_b);
-    uint4* dst = lds + (gp % NB) * T::BUF;
+  // DMA group of channel half `half` of tile (img, y0, x0) -> ring buffer `slot`.  The ring position of phase g0 = 2 ti
+  // is carried in r0 and advanced by two per tile (g % 3 through a multiply-high, several times per tile, was another
+  // ~25 scalar instructions)
+  auto issue = [&](int slot, int half, unsigned src_base) {   // src_base = tile_base(img, y0 - DIL, x0 - DIL)
+    const char* src = reinterpret_cast<const char*>(in) + (src_base + 2u * (unsigned)half * plane_b);
+    uint4* dst = lds + slot * T::BUF;
 #pragma unroll
     for (int k = 0; k < T::KW; ++k) {
       int i = wave + 4 * k;
@@ -1317,8 +1338,9 @@ __global__ __launch_bounds__(256, MINW) void k_ref_conv_f16_v2(const uint4* __re
 
   int img, y0, x0, nimg_ = 0, ny0 = 0, nx0 = 0;
   tile_xy(t0, img, y0, x0);
-  issue(0, img, y0, x0);
-  if (NB == 3) issue(1, img, y0, x0);
+  unsigned cur_base = tile_base(img, y0 - DIL, x0 - DIL), nxt_base = 0;   // DMA source of this / the next tile
+  issue(0, 0, cur_base);
+  if (NB == 3) issue(1, 1, cur_base);
   // Weights and bias are fetched AFTER the first tile's DMA groups are on their way, so the two latencies of a
   // workgroup's start-up overlap (~1-2 us of every launch).  The loads are consumed HERE (hipcc waits for them with
   // vmcnt(0), which also lands the first groups) so that its own vmcnt bookkeeping is clean before the loop; otherwise
@@ -1342,10 +1364,17 @@ __global__ __launch_bounds__(256, MINW) void k_ref_conv_f16_v2(const uint4* __re
   unsigned* const my_ctr = tile_ctr + 16 * xcd;
 
   f32x16 acc[T::SPW];
+  int r0 = 0;                                                 // ring buffer of phase g0 = 2 ti: g0 % NB
   for (int ti = 0;; ++ti) {
-    const int g0 = 2 * ti;
-    const bool has_next = t_next < t_end;                     // wave-uniform
-    if (has_next) tile_xy(t_next, nimg_, ny0, nx0);           // one coordinate decode per tile
+    const int r1 = NB == 2 ? 1 : (r0 + 1 >= 3 ? r0 - 2 : r0 + 1);          // (g0 + 1) % NB
+    const int r2 = NB == 2 ? 0 : (r0 + 2 >= 3 ? r0 - 1 : r0 + 2);          // (g0 + 2) % NB; (g0 + 3) % 3 = r0
+    // an SGPR integer, not an i1: hipcc otherwise carries the flag as a lane mask and re-derives its negation through
+    // v_cndmask / v_cmp at every use
+    const int has_next = __builtin_amdgcn_readfirstlane(t_next < t_end ? 1 : 0);
+    if (has_next) {                                           // one coordinate decode per tile
+      tile_xy(t_next, nimg_, ny0, nx0);
+      nxt_base = tile_base(nimg_, ny0 - DIL, nx0 - DIL);
+    }
     // ---- phase g0 (channels 0..15) ----
     if (NB == 3) {
       if (ti == 0) wait_vmcnt<T::KW>();                       // younger than group 0: group 1
@@ -1373,9 +1402,9 @@ __global__ __launch_bounds__(256, MINW) void k_ref_conv_f16_v2(const uint4* __re
           : "memory");
     }
     if (NB == 3) {
-      if (has_next) issue(g0 + 2, nimg_, ny0, nx0);
+      if (has_next) issue(r2, 0, nxt_base);                   // phase g0 + 2: first channel half of the next tile
     } else {
-      issue(g0 + 1, img, y0, x0);                             // second channel half of THIS tile
+      issue(1, 1, cur_base);                                  // second channel half of THIS tile
     }
     // residual: NSTORE 8-byte loads as inline asm, spread over THIS phase's MFMAs (one after every second MFMA), a
     // whole tile before the epilogue needs them.  They sit between two DMA groups in the in-order VMEM queue, so the
@@ -1392,7 +1421,7 @@ __global__ __launch_bounds__(256, MINW) void k_ref_conv_f16_v2(const uint4* __re
       }
     };
     // accumulators start at the bias (C operand of each segment's first MFMA): no add in the epilogue, no seeding moves
-    ref2_compute_init<DIL, TW, TH>(lds + (g0 % NB) * T::BUF + lane_off, wf, bv, acc, res_load);
+    ref2_compute_init<DIL, TW, TH>(lds + r0 * T::BUF + lane_off, wf, bv, acc, res_load);
 
     // ---- phase g0+1 (channels 16..31) ----
     // younger than group g0+1: (NB = 3, another tile follows) group g0+2, and the residual loads behind it
@@ -1416,9 +1445,9 @@ __global__ __launch_bounds__(256, MINW) void k_ref_conv_f16_v2(const uint4* __re
     if (has_next) t_next2 = t_begin + 2 * nlb + (int)__builtin_amdgcn_readfirstlane(tile_slot[ti & 1]);
     else t_next2 = t_end;
 
-    const bool more = has_next;
-    if (more) issue(NB == 3 ? g0 + 3 : g0 + 2, nimg_, ny0, nx0);     // NB = 2: first half of the next tile
-    ref2_compute<DIL, TW, 1, TH>(lds + ((g0 + 1) % NB) * T::BUF + lane_off, wf, acc);
+    const int more = has_next;
+    if (more) issue(NB == 3 ? r0 : 0, NB == 3 ? 1 : 0, nxt_base);          // phase g0 + 3 (NB = 2: g0 + 2, first half of the next tile)
+    ref2_compute<DIL, TW, 1, TH>(lds + r1 * T::BUF + lane_off, wf, acc);
     if (RES) {
       if (more) wait_vmcnt<T::KW>(); else wait_vmcnt<0>();
 #pragma unroll
@@ -1431,7 +1460,9 @@ __global__ __launch_bounds__(256, MINW) void k_ref_conv_f16_v2(const uint4* __re
     const float slope = lrelu ? kSlope : 1.0f;         // max(v, v) = v: one code path with and without the activation
     float one = 1.0f;
     asm volatile("" : "+v"(one));                      // opaque: keeps the multiply so that hipcc selects v_fma_mix_f32
-    auto finish = [&](int s, int q) -> uint2 {          // bias is in the accumulator; + residual, activation, fp16
+    // (the epilogue body exists twice, selected by ONE uniform branch per tile: with the test inside, hipcc put two
+    // v_cndmask and a scalar mask sequence in front of every store of the interior path as well)
+    auto finish = [&](int s, int q, auto inside) -> uint2 {   // bias is in the accumulator; + residual, activation, fp16
       float v[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = acc[s][4 * q + e];
@@ -1450,28 +1481,35 @@ __global__ __launch_bounds__(256, MINW) void k_ref_conv_f16_v2(const uint4* __re
       half4 hv;
 #pragma unroll
       for (int e = 0; e < 4; ++e) hv[e] = (_Float16)v[e];
-      if (!interior) {
+      if (!decltype(inside)::value) {
         const int seg = seg0 + s;
         const int y = y0 + seg / T::CSEG, x = x0 + (seg % T::CSEG) * 32 + j;
         if (!(y < g.H && x < g.W)) hv = half4{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
       }
       return *reinterpret_cast<const uint2*>(&hv);
     };
+    auto store_tile = [&](auto inside) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      char* oq = reinterpret_cast<char*>(out) + (tb + (unsigned)q * plane_b);                  // uniform
+      for (int q = 0; q < 4; ++q) {
+        char* oq = reinterpret_cast<char*>(out) + (tb + (unsigned)q * plane_b);                  // uniform
 #pragma unroll
-      for (int s = 0; s < T::SPW; ++s) {
-        const uint2 hv = finish(s, q);          // SGPR base + 32-bit VGPR offset: no 64-bit VALU add per store
-        asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(io_voff[s]), "v"(hv), "s"(oq) : "memory");
+        for (int s = 0; s < T::SPW; ++s) {
+          const uint2 hv = finish(s, q, inside);  // SGPR base + 32-bit VGPR offset: no 64-bit VALU add per store
+          const unsigned voff = io_voff[s];       // (a local: an asm operand inside a generic lambda cannot name the capture)
+          asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(voff), "v"(hv), "s"(oq) : "memory");
+        }
       }
-    }
+    };
+    if (interior) store_tile(std::true_type{});
+    else store_tile(std::false_type{});
     if (!has_next) break;
     img = nimg_;
     y0 = ny0;
     x0 = nx0;
     t_next = t_next2;
     t_next2 = t_end;
+    r0 = r2;
+    cur_base = nxt_base;
   }
 }
 
