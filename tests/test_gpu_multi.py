@@ -150,3 +150,43 @@ def test_large_geometry_and_refusal(model_factory, oracle, weights_blob):
     with pytest.raises(api.StereoNetError):
         api.StereoNetHIP(model_factory(w, h, d), width=16384, height=16384, precision=api.PREC_F16, refine_chunk=8,
                          max_batch=8)
+
+
+_ENV_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from hobot_stereonet_amd import api, synth
+w, h, d, n = 200, 120, 64, 5
+xs = np.stack([synth.model_input_i8(w, h, d, 40 + i) for i in range(n)])
+with api.StereoNetHIP(sys.argv[2], max_batch=n, precision=api.PREC_F16, refine_chunk=2, piece=3) as eng:
+    disp, raw = eng.infer(xs)
+np.save(sys.argv[3], disp)
+"""
+
+
+@pytest.mark.parametrize("env,exact", [({"SN_TOWER_STREAMS": "2"}, True), ({"SN_NO_OVERLAP": "1"}, True),
+                                       ({"SN_HEAD_FUSE": "0"}, False), ({"SN_FUSE": "3"}, False),
+                                       ({"SN_TOWER_STREAMS": "2", "SN_HEAD_FUSE": "0"}, False)])
+def test_diagnostic_switches_run_the_same_network(model_factory, oracle, weights_blob, tmp_path, env, exact):
+    """The library's diagnostic environment switches select other schedules / kernel pairings of the
+    SAME arithmetic: stream layout switches must be bit-identical to the default, kernel pairings within the EPE bar."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    w, h, d, n = 200, 120, 64, 5
+    model = model_factory(w, h, d)
+    script = tmp_path / "run.py"
+    script.write_text(_ENV_SCRIPT)
+    outs = {}
+    for tag, e in (("default", {}), ("switch", env)):
+        out = str(tmp_path / f"{tag}.npy")
+        r = subprocess.run([sys.executable, str(script), root, model, out], env=dict(os.environ, **e), capture_output=True,
+                           text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = np.load(out).reshape(n, h, w)
+    if exact:
+        assert np.array_equal(outs["default"], outs["switch"])
+    for i in (0, n - 1):
+        odisp, _, _ = oracle.forward(weights_blob, synth.model_input_i8(w, h, d, 40 + i), d)
+        assert np.abs(outs["switch"][i] - odisp).mean() < EPE_TOL
