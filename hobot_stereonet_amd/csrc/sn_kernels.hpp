@@ -457,6 +457,21 @@ __global__ __launch_bounds__(256, MINW) void k_conv_c32_mfma(ConvArgs a, Loader 
 // The input is a split-slot tensor (SlotIn supplies the virtual-channel mapping of the 3-D layers); the output is a
 // split-slot tensor (OUTSLOT) or fp32 NCHW (the feature map and the last aggregation volume).
 // ------------------------------------------------------------------------------------------
+// Exact unsigned division by a loop-invariant divisor: q = umulhi(t, floor((2^32 - 1) / d)) is floor(t / d) or one
+// less for every t < 2^32 (t m / 2^32 > t / d - 1), so one conditional correction finishes it.
+struct FastDiv {
+  unsigned d, m;
+  __device__ __forceinline__ explicit FastDiv(unsigned d_) : d(d_), m(0xFFFFFFFFu / d_) {}
+  __device__ __forceinline__ unsigned divmod(unsigned t, unsigned& rem) const {
+    unsigned q = __umulhi(t, m);
+    unsigned r = t - q * d;
+    const bool up = r >= d;
+    q += up ? 1u : 0u;
+    rem = up ? r - d : r;
+    return q;
+  }
+};
+
 template <int KS, int STRIDE, int VCH, int TR, int TC, int SEGW>
 struct X3sTile {
   static constexpr int TAPS = KS * KS;
@@ -577,6 +592,7 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
   // 64 cycles per MFMA instead of 32 — so the validity test is branch-free integer arithmetic, and tiles that lie
   // inside the image with all their depth planes present (f_fast, wave-uniform) skip it altogether.
   const char* const f_base = reinterpret_cast<const char*>(ld.p);
+  const FastDiv div_tx((unsigned)a.tiles_x), div_ty((unsigned)a.tiles_y);    // tile index -> (image, row, column)
   int f_iy0 = 0, f_ix0 = 0;
   unsigned f_toff = 0, f_pmask = 0;
   bool f_fast = false;
@@ -596,8 +612,10 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
     *reinterpret_cast<f4v*>(&pre[e * 4]) = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(f_base + off));
   };
   auto fetch = [&](int tile) {
-    const int tx = tile % a.tiles_x, t2 = tile / a.tiles_x;
-    const int ty = t2 % a.tiles_y, img = t2 / a.tiles_y;
+    unsigned txu, tyu;
+    const unsigned t2 = div_tx.divmod((unsigned)tile, txu);
+    const int img = (int)div_ty.divmod(t2, tyu);
+    const int tx = (int)txu, ty = (int)tyu;
     const int iy0 = ty * TR * STRIDE - a.pad, ix0 = tx * TC * STRIDE - a.pad;
     {
       // branch-free: every lane loads; a slot outside the tensor (zero padding, missing depth plane) reads slot 0
@@ -646,8 +664,10 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
   for (; tile < t_end; tile += nlb) {
     const int nxt = tile + nlb;
     // residual of the segment this wave finishes: requested before the MFMAs, consumed in the epilogue
-    const int e_tx = tile % a.tiles_x, e_t2 = tile / a.tiles_x;
-    const int e_ty = e_t2 % a.tiles_y, e_img = e_t2 / a.tiles_y;
+    unsigned e_txu, e_tyu;
+    const unsigned e_t2 = div_tx.divmod((unsigned)tile, e_txu);
+    const int e_img = (int)div_ty.divmod(e_t2, e_tyu);
+    const int e_tx = (int)e_txu, e_ty = (int)e_tyu;
     const int e_seg = pset * 2 + khalf;
     const int e_y = e_ty * TR + (e_seg / (TC / SEGW)) * T::SEGH + pr;
     const int e_x = e_tx * TC + (e_seg % (TC / SEGW)) * SEGW + pc;
@@ -673,7 +693,8 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
         for (int r = 0; r < 16; ++r) rv[r] = a.res[base + (size_t)((r & 3) + 8 * (r >> 2) + 4 * gh) * plane_o];
       }
     }
-    if (nxt < t_end) fetch(nxt);
+    const int more = __builtin_amdgcn_readfirstlane(nxt < t_end ? 1 : 0);
+    fetch(more ? nxt : tile);             // no next tile: the staging loads run once more on this one (no branch per K-step)
 
     f32x16 acc0[2], acc1[2];
     f32x16 zero;                        // C operand of the first K-step (an inline constant: no seeding moves)
@@ -714,17 +735,13 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
       }
       // staging copies of the next tile: FPK per K-step from the start of the loop, so that the last of them still
       // has most of the loop's MFMAs (not one K-step) between its issue and the commit that waits for it
-      if (nxt < t_end) {
 #pragma unroll
-        for (int f = 0; f < FPK; ++f)
-          if (FPK * k + f < LPT) fetch_one(FPK * k + f);
-      }
+      for (int f = 0; f < FPK; ++f)
+        if (FPK * k + f < LPT) fetch_one(FPK * k + f);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (nxt < t_end) {
 #pragma unroll
-      for (int e = FPK * T::NK; e < LPT; ++e) fetch_one(e);   // (only when a tile has more copies than the loop takes)
-    }
+    for (int e = FPK * T::NK; e < LPT; ++e) fetch_one(e);     // (only when a tile has more copies than the loop takes)
     // ship the partial of the segment the pair partner finishes
     {
       float* dst = s_red + (size_t)wave * 16 * 64 + lane;
@@ -732,7 +749,7 @@ __global__ __launch_bounds__(256, MINB) void k_conv_x3s(ConvArgs a, Loader ld) {
       for (int r = 0; r < 16; ++r) dst[r * 64] = acc0[1][r] + acc1[1][r] * kSplitInv;
     }
     lds_barrier();                      // halo tile free, partials visible
-    if (nxt < t_end) commit();
+    if (more) commit();
 
 
     {
@@ -1184,21 +1201,6 @@ __device__ __forceinline__ void block_barrier() {
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 }
-
-// Exact unsigned division by a loop-invariant divisor: q = umulhi(t, floor((2^32 - 1) / d)) is floor(t / d) or one
-// less for every t < 2^32 (t m / 2^32 > t / d - 1), so one conditional correction finishes it.
-struct FastDiv {
-  unsigned d, m;
-  __device__ __forceinline__ explicit FastDiv(unsigned d_) : d(d_), m(0xFFFFFFFFu / d_) {}
-  __device__ __forceinline__ unsigned divmod(unsigned t, unsigned& rem) const {
-    unsigned q = __umulhi(t, m);
-    unsigned r = t - q * d;
-    const bool up = r >= d;
-    q += up ? 1u : 0u;
-    rem = up ? r - d : r;
-    return q;
-  }
-};
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
