@@ -1155,6 +1155,7 @@ struct RefGeom {
   int Hs, Ws;          // padded plane dims (pixels)
   int H, W;            // valid image area (the network's Hp x Wp)
   int tiles_x, tiles_y;
+  int rev;             // 1: this launch walks its tiles in reverse order (see refine_level)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -1317,6 +1318,7 @@ __global__ __launch_bounds__(256, MINW) void k_ref_conv_f16_v2(const uint4* __re
   const FastDiv div_img((unsigned)per_img), div_tx((unsigned)g.tiles_x);
   auto tile_xy = [&](int t, int& img, int& y0, int& x0) {      // t = global tile index
     unsigned rem, tx;
+    if (g.rev) t = t_begin + (t_end - 1 - t);                  // reverse walk inside the XCD band
     img = (int)div_img.divmod((unsigned)t, rem);
     const int ty = (int)div_tx.divmod(rem, tx);
     y0 = ty * T::TH;
@@ -1604,6 +1606,7 @@ __global__ __launch_bounds__(256, 2) void k_ref_conv_head_f16(const uint4* __res
   }
 
   auto tile_xy = [&](int t, int& img, int& y0, int& x0) {      // conv tile origin = head tile origin - 1
+    if (g.rev) t = t_begin + (t_end - 1 - t);
     img = t / per_img;
     const int rem = t - img * per_img;
     const int ty = rem / g.tiles_x;
@@ -2422,6 +2425,7 @@ __global__ __launch_bounds__(256, 2) void k_refin_f16(const float* __restrict__ 
   float pd[4];
   bool pval[4];
   auto fetch = [&](int tile) {
+    if (g.rev) tile = total - 1 - tile;
     const int img = tile / per_img, rem = tile - img * per_img;
     const int ty = rem / g.tiles_x, tx = rem - ty * g.tiles_x;
     const int y = ty * T::TH - 1 + ur, x = tx * T::TW - 4 + 4 * uq;
@@ -2544,7 +2548,8 @@ __global__ __launch_bounds__(256, 2) void k_refin_f16(const float* __restrict__ 
       }
     }
     {
-      const int img = tile / per_img, rem = tile - img * per_img;
+      const int tile_m = g.rev ? total - 1 - tile : tile;
+      const int img = tile_m / per_img, rem = tile_m - img * per_img;
       const int ty = rem / g.tiles_x, tx = rem - ty * g.tiles_x;
       const int y0 = ty * T::TH, x0 = tx * T::TW;
       const bool interior = y0 + T::TH <= g.H && x0 + T::TW <= g.W;            // wave-uniform
