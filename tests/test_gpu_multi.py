@@ -164,7 +164,7 @@ np.save(sys.argv[3], disp)
 """
 
 
-@pytest.mark.parametrize("env,exact", [({"SN_TOWER_STREAMS": "2"}, True), ({"SN_NO_OVERLAP": "1"}, True),
+@pytest.mark.parametrize("env,exact", [({"SN_TOWER_STREAMS": "2"}, True), ({"SN_NO_OVERLAP": "1"}, True), ({"SN_REV": "0"}, True),
                                        ({"SN_HEAD_FUSE": "0"}, False), ({"SN_FUSE": "3"}, False),
                                        ({"SN_TOWER_STREAMS": "2", "SN_HEAD_FUSE": "0"}, False)])
 def test_diagnostic_switches_run_the_same_network(model_factory, oracle, weights_blob, tmp_path, env, exact):
