@@ -162,3 +162,30 @@ def test_identical_eyes_reference_fixture_oracle(oracle, weights_blob):
         assert (cv[:, dd, :, :dd] == 0).all()        # x < d: defined as zero
     disp, raw, low = oracle.forward(weights_blob, x, 96)
     assert np.isfinite(disp).all() and raw.min() >= 0
+
+
+def test_baseline_config0_cpu_plumbing_960x540_d48(oracle, weights_blob):
+    """BASELINE.json configs[0]: one 960x540 pair, D=48, CPU-float, no GPU — plumbing from an NV12 stereo frame to the
+    consumer's depth image: reference pre-processing (split, YUV444, ^0x80) -> oracle network -> wire int32 -> the render
+    node's view (uint32 * scale * 16 * 12, depth = f*B/disp/1000) -> colour image."""
+    from hobot_stereonet_amd import render
+    w, h, d = 960, 540, 48
+    lt, rt = synth.stereo_pair_u8(w, h, d, 31)
+    frame = np.random.default_rng(31).integers(0, 256, (h * 3 // 2, 2 * w), dtype=np.uint8)
+    frame[:h, :w] = lt[0]
+    frame[:h, w:] = rt[0]
+    left, right = oracle.split_sbs_nv12(frame.ravel(), w, h)
+    ten = oracle.preprocess_nv12(left, right, w, h)
+    assert ten.shape == (6, h, w) and ten.dtype == np.int8
+    assert np.array_equal(ten[0], (frame[:h, :w] ^ 0x80).view(np.int8))            # Quantize == b ^ 0x80 on the luma plane
+    disp, raw, low = oracle.forward(weights_blob, ten, d)
+    assert disp.shape == (h, w) and low.shape == (34, 60) and np.isfinite(disp).all() and raw.min() >= 0
+    payload = raw.astype(np.int32).tobytes() + b"\xff\xd8jpeg-bytes-of-the-left-eye"
+    raw_u32, rest = render.split_payload(payload, w, h)
+    assert rest.startswith(b"\xff\xd8")
+    dpx, depth = render.disparity_and_depth(raw_u32)
+    assert np.abs(dpx - disp).max() <= 0.51 * 192 * spec.OUT_SCALE + 1e-6
+    m = dpx > 1.0
+    assert np.allclose(depth[m], 527.1931762695312 * 119.89382172 / dpx[m] / 1000.0, rtol=1e-5)
+    rgb = render.colorize_depth(depth)
+    assert rgb.shape == (h, w, 3) and rgb.dtype == np.uint8
