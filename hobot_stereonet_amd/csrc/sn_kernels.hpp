@@ -2704,3 +2704,5 @@ __global__ __launch_bounds__(256) void k_head_final_f16(const uint4* __restrict_
 }
 
 }  // namespace sn
+
+#include "sn_stream_block.hpp"

@@ -132,7 +132,8 @@ struct sn_handle {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_tow_join[kMaxTowerStreams] = {}, ev_piece[kMaxPieceEvents] = {};
   bool overlap = true;
   int tower_streams = kMaxTowerStreams;
-  bool fuse_dil1 = false;    // SN_FUSE=3: dilation-1 residual blocks through the fused kernel (opt-in)
+  bool stream_last = false;  // SN_STREAM_LAST=1: the last block streamed too + separate head launch (default: conv + fused conv/head)
+  int fuse_mode = 4;         // SN_FUSE: 4 = streaming fused blocks (default), 3 = tile-fused dilation-1 blocks, 0 = two launches per block
   bool head_fuse = true;     // last tower conv + head in one kernel (fp16 mode; SN_HEAD_FUSE=0 separates them)
   unsigned* dump = nullptr;  // 2 KB device scratch: where lanes without an output pixel store (fused head)
   bool use_graphs = true;    // hipGraph replay for the async single-pair path (SN_NO_GRAPH disables)
@@ -493,7 +494,13 @@ RefGeom make_ref_geom(int Hp, int Wp) {
 }
 
 size_t ref16_slots(const RefGeom& g, int nimg) { return (size_t)nimg * 4 * g.Hs * g.Ws; }
-constexpr size_t kRefSlack = 4096;   // slots: the fused block's x tile may over-read past the last padded row
+// Slots behind a tensor that kernels may over-read (never written, zero): the fused blocks fetch whole x tiles / row
+// groups past the last padded row of the last image (tile-fused kernel: < 4096 slots; streaming kernel: up to
+// (R + 2) * DIL + DIL - 1 rows of Ws slots below the image, of which 8 are the tensor's own border).
+size_t ref_slack(const RefGeom& g) {
+  const size_t rows = (size_t)16 * g.Ws;
+  return rows > 4096 ? rows : 4096;
+}
 
 // [co][ci][ky][kx] fp32 -> wfrag[tap][kk][lane][e] fp16 = w[co = lane&31][ci = 16kk + 8(lane>>5) + e][tap]
 int upload_ref_f16(sn_handle* h, const HostLayer& l, RefLayerF16* out) {
@@ -614,6 +621,41 @@ hipError_t launch_ref_block_f16_h(hipStream_t st, const RefLayerF16& L1, const R
   return hipGetLastError();
 }
 
+
+// Fused residual block, row-streaming form (sn_stream_block.hpp): one 512-thread workgroup per CU walks its share of
+// the flattened (image, row phase, strip, sub-row) sequence.  x and y must be different tensors.  dump: >= 1 KB scratch.
+template <int DIL>
+hipError_t launch_ref_block_stream(hipStream_t st, const RefLayerF16& L1, const RefLayerF16& L2, const RefGeom& g, int num_cu,
+                                   const uint4* x, uint4* y, int nimg, unsigned* dump) {
+  using T = StreamTile<DIL, 64, 4, 6>;
+  auto kern = k_ref_block_stream_f16<DIL, 64, 4, 6>;
+  if (dump == nullptr) return hipErrorInvalidValue;
+  hipError_t e = ensure_lds_attr(kern, T::LDS_BYTES);
+  if (e != hipSuccess) return e;
+  StreamSched sc;
+  sc.nstrips = (g.W + T::OW - 1) / T::OW;
+  sc.hsub = (g.H + DIL - 1) / DIL;
+  sc.total_rows = nimg * DIL * sc.nstrips * sc.hsub;
+  int nwg = num_cu;
+  if (nwg > sc.total_rows) nwg = sc.total_rows;
+  if (nwg < 1) nwg = 1;
+  sc.rows_per_wg = (sc.total_rows + nwg - 1) / nwg;
+  const int grid = (sc.total_rows + sc.rows_per_wg - 1) / sc.rows_per_wg;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), T::LDS_BYTES, st, x, y, L1.wfrag, L1.bias, L2.wfrag, L2.bias, g, sc,
+                     reinterpret_cast<uint4*>(dump));
+  return hipGetLastError();
+}
+
+hipError_t ref_block_stream(hipStream_t st, const RefLayerF16& L1, const RefLayerF16& L2, const RefGeom& g, int num_cu, int dil,
+                            const uint4* x, uint4* y, int nimg, unsigned* dump) {
+  switch (dil) {
+    case 1: return launch_ref_block_stream<1>(st, L1, L2, g, num_cu, x, y, nimg, dump);
+    case 2: return launch_ref_block_stream<2>(st, L1, L2, g, num_cu, x, y, nimg, dump);
+    default: return hipErrorInvalidValue;
+  }
+}
+inline bool stream_block_supports(int dil) { return dil == 1 || dil == 2; }
+
 hipError_t launch_head_final_f16(hipStream_t st, bool split, const uint4* x, size_t lo_slots, const RefGeom& g,
                                  const float* w, float bias, const float* disp_low, int hl, int wl, int H, int W, float dmax,
                                  float inv_q, UpScale ups, float* out_disp, int32_t* out_raw, int nimg) {
@@ -662,9 +704,11 @@ bool head_fuse_env() {   // SN_HEAD_FUSE=0: separate last conv + head launches (
   return on;
 }
 
-bool fuse_env() {        // SN_FUSE=3: the dilation-1 blocks of the pipeline run through the fused kernel
-  static const bool on = getenv("SN_FUSE") != nullptr && atoi(getenv("SN_FUSE")) == 3;
-  return on;
+// SN_FUSE: how the residual blocks of the fp16 tower run.  4 (default) = the row-streaming fused kernel for the
+// dilations it supports, 3 = the tile-fused kernel for dilation 1 (round 2, kept for A/B), 0 = two launches per block.
+int fuse_env() {
+  static const int mode = getenv("SN_FUSE") != nullptr ? atoi(getenv("SN_FUSE")) : 4;
+  return mode;
 }
 
 // Tile width of a dilation-1 / -2 launch.  The persistent grid (two workgroups per CU) works through the tiles in
@@ -700,15 +744,24 @@ hipError_t ref_conv_f16(hipStream_t st, const RefLayerF16& L, const RefGeom& g, 
 // One residual block of the fp16 tower on `*cur` (input and, on return, output); `*oth` is scratch.  tile_ctr: the
 // block's two tile queues (kTileCtrStride apart).
 hipError_t ref_block_f16(hipStream_t st, const RefLayerF16& L1, const RefLayerF16& L2, const RefGeom& g, int num_cu,
-                         int dil, uint4** cur, uint4** oth, int nimg, unsigned* tile_ctr, bool fused, bool alt = false) {
-  if (fused && dil == 1) {
-    hipError_t e = launch_ref_block_f16_h(st, L1, L2, g, num_cu, *cur, *oth, nimg);
+                         int dil, uint4** cur, uint4** oth, int nimg, unsigned* tile_ctr, int fuse_mode, unsigned* dump,
+                         bool alt = false) {
+  hipError_t e = hipErrorInvalidValue;
+  bool fused = false;
+  if (fuse_mode == 4 && stream_block_supports(dil)) {
+    e = ref_block_stream(st, L1, L2, g, num_cu, dil, *cur, *oth, nimg, dump);
+    fused = true;
+  } else if (fuse_mode == 3 && dil == 1) {
+    e = launch_ref_block_f16_h(st, L1, L2, g, num_cu, *cur, *oth, nimg);
+    fused = true;
+  }
+  if (fused) {
     uint4* t = *cur;
     *cur = *oth;
     *oth = t;
     return e;
   }
-  hipError_t e = ref_conv_f16(st, L1, g, num_cu, dil, *cur, *oth, nullptr, nimg, true, tile_ctr);
+  e = ref_conv_f16(st, L1, g, num_cu, dil, *cur, *oth, nullptr, nimg, true, tile_ctr);
   if (e != hipSuccess) return e;
   RefGeom g2 = g;
   if (alt) g2.rev ^= 1;                  // the second conv walks the tiles the other way round (refine_level)
@@ -738,7 +791,7 @@ int alloc_ws(sn_handle* h, Workspace* ws, int nb, int rb, int ns) {
     for (int k = 0; k < 2 * ws->ns; ++k) HIP_TRY(h, dalloc(&ws->ref[k], (size_t)rb * kC * HWp));
   } else {
     for (int k = 0; k < 2 * ws->ns; ++k) {
-      const size_t slots = (ref16_slots(h->tw[0].rg, rb) + kRefSlack) * (h->precision == SN_PREC_F16X3 ? 2 : 1);
+      const size_t slots = (ref16_slots(h->tw[0].rg, rb) + ref_slack(h->tw[0].rg)) * (h->precision == SN_PREC_F16X3 ? 2 : 1);
       HIP_TRY(h, dalloc(&ws->ref16[k], slots));
       HIP_TRY(h, hipMemset(ws->ref16[k], 0, slots * sizeof(uint4)));   // the zero border is never written again
     }
@@ -764,7 +817,7 @@ int alloc_ws(sn_handle* h, Workspace* ws, int nb, int rb, int ns) {
       if (h->precision == SN_PREC_FP32) {
         HIP_TRY(h, dalloc(&ws->ref_lv[lv][k], (size_t)ws->rbk[lv] * kC * HWk));
       } else {
-        const size_t slots = (ref16_slots(T.rg, ws->rbk[lv]) + kRefSlack) * (h->precision == SN_PREC_F16X3 ? 2 : 1);
+        const size_t slots = (ref16_slots(T.rg, ws->rbk[lv]) + ref_slack(T.rg)) * (h->precision == SN_PREC_F16X3 ? 2 : 1);
         HIP_TRY(h, dalloc(&ws->ref16_lv[lv][k], slots));
         HIP_TRY(h, hipMemset(ws->ref16_lv[lv][k], 0, slots * sizeof(uint4)));
       }
@@ -964,14 +1017,17 @@ int refine_level(sn_handle* h, Workspace& ws, hipStream_t st, const Tower& T, fl
     auto flip = [&]() { g.rev = rev_env ? (launch_no++ & 1) : 0; };
     flip();
     const bool x3 = h->precision == SN_PREC_F16X3;
-    const size_t lo_slots = ref16_slots(g, cap) + kRefSlack;         // hi tensor -> lo tensor (F16X3); cap = pairs the buffers hold
+    const size_t lo_slots = ref16_slots(g, cap) + ref_slack(g);         // hi tensor -> lo tensor (F16X3); cap = pairs the buffers hold
     HIP_TRY(h, launch_refin_f16(st, T.refin, T.rin.bias, src, img_src, pyr, sh, sw, H, W, 1.0f / dnorm, ups, g, c, x16, x3,
                                 lo_slots * 16, ncu));
     if (pe) HIP_TRY(h, hipEventRecord(h->ev[4], st));
     flip();
     // fp16 mode: the last conv of the tower and the head run as one kernel (the tower's output tensor is never
     // written); needs the last block to be an unfused dilation-1 block
-    const bool head_fused = !x3 && h->head_fuse && kRefDil[kNRefRes - 1] == 1 && !h->fuse_dil1;
+    // (a streamed or tile-fused last block leaves its output in memory: the head then runs as its own launch)
+    const bool last_block_fused = (h->fuse_mode == 4 && stream_block_supports(kRefDil[kNRefRes - 1]) && h->stream_last) ||
+                                  (h->fuse_mode == 3 && kRefDil[kNRefRes - 1] == 1);
+    const bool head_fused = !x3 && h->head_fuse && kRefDil[kNRefRes - 1] == 1 && !last_block_fused;
     for (int i = 0; i < kNRefRes; ++i) {
       if (x3) {
         HIP_TRY(h, ref_conv_f16x3(st, T.rres16[i][0], g, ncu, kRefDil[i], x16, t16, nullptr, lo_slots, c, true));
@@ -985,7 +1041,7 @@ int refine_level(sn_handle* h, Workspace& ws, hipStream_t st, const Tower& T, fl
                                             T.rout.bias, src, sh, sw, H, W, dnorm, inv_q, ups, od, orw, h->dump));
       } else {
         HIP_TRY(h, ref_block_f16(st, T.rres16[i][0], T.rres16[i][1], g, ncu, kRefDil[i], &x16, &t16, c,
-                                 chunk_ctr + 2 * i * kTileCtrStride, h->fuse_dil1, rev_env != 0));
+                                 chunk_ctr + 2 * i * kTileCtrStride, h->fuse_mode, h->dump, rev_env != 0));
       }
     }
     if (!head_fused) {
@@ -1352,7 +1408,8 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(SN_ERR_DEVICE);
   h->overlap = getenv("SN_NO_OVERLAP") == nullptr;
   h->use_graphs = getenv("SN_NO_GRAPH") == nullptr;
-  h->fuse_dil1 = fuse_env();
+  h->fuse_mode = fuse_env();
+  h->stream_last = getenv("SN_STREAM_LAST") != nullptr && atoi(getenv("SN_STREAM_LAST")) == 1;
   h->head_fuse = head_fuse_env();
   if (hipMalloc(reinterpret_cast<void**>(&h->dump), 4096) != hipSuccess) return fail(SN_ERR_NOMEM);
 
@@ -1838,7 +1895,7 @@ int sn_get_dominant_kernel(sn_handle* h, char* name, size_t cap, int* launches, 
                                              : "k_conv_c32_mfma<3,1,*> (refinement 3x3 C->C, fp32 MFMA 32x32x2)");
   const double px = (double)h->Hp * h->Wp * h->ws.rb;
   // fp16 mode with the fused last layer: the timed span holds the 11 plain tower launches (6 without, 5 with residual)
-  const bool hf = f16 && h->head_fuse && !h->fuse_dil1;
+  const bool hf = f16 && h->head_fuse && !(h->fuse_mode == 3) && !(h->fuse_mode == 4 && h->stream_last);
   const int n_plain = kNRefRes, n_res = hf ? kNRefRes - 1 : kNRefRes;
   if (launches) *launches = n_plain + n_res;   // per refinement chunk
   if (flops) *flops = 2.0 * px * kC * kC * 9;
@@ -1966,7 +2023,7 @@ int sn_dbg_refin(sn_handle* h, const float* disp_low, const int8_t* in6, int h_p
   if (rc) return rc;
   const int Hp = (h_px + 15) / 16 * 16, Wp = (w + 15) / 16 * 16, hl = Hp / 16, wl = Wp / 16;
   const RefGeom g = make_ref_geom(Hp, Wp);
-  const size_t slots = ref16_slots(g, 1) + kRefSlack;
+  const size_t slots = ref16_slots(g, 1) + ref_slack(g);
   Down0F16 L;
   HostLayer hl_{wt, bias, kC, 4, 9};
   if ((rc = upload_refin_f16(h, hl_, &L))) return rc;
@@ -2139,7 +2196,7 @@ int sn_dbg_ref_conv_f16x3(sn_handle* h, const float* in, int h_px, int w, const 
   int rc = check_device(h);
   if (rc) return rc;
   const RefGeom g = make_ref_geom(h_px, w);
-  const size_t lo_slots = ref16_slots(g, 1) + kRefSlack, slots = 2 * lo_slots;
+  const size_t lo_slots = ref16_slots(g, 1) + ref_slack(g), slots = 2 * lo_slots;
   auto idx = [&](int c, int y, int x) { return ((((size_t)(c >> 3)) * g.Hs + y + kRefPad) * g.Ws + x + kRefPad) * 8 + (c & 7); };
   auto split_to = [&](const float* src, std::vector<_Float16>& dst) {
     dst.assign(slots * 8, (_Float16)0.f);
@@ -2198,7 +2255,9 @@ int sn_dbg_ref_conv_f16x3(sn_handle* h, const float* in, int h_px, int w, const 
 int sn_dbg_ref_block_f16(sn_handle* h, const float* in, int h_px, int w, const float* w1, const float* b1,
                          const float* w2, const float* b2, int dil, float* out) {
   if (!h || !in || !w1 || !b1 || !w2 || !b2 || !out || h_px <= 0 || w <= 0) return SN_ERR_ARG;
-  const bool fused = (dil >> 8) != 0;  // tests: bit 8 selects the fused kernel (dilation 1)
+  // tests: bits 8.. select the form: 0 = two launches, 1 = tile-fused kernel (dilation 1), 2 = row-streaming fused kernel
+  const int form = dil >> 8;
+  const int fuse_mode = form == 2 ? 4 : (form == 1 ? 3 : 0);
   dil &= 0xff;
   if (dil != 1 && dil != 2 && dil != 4 && dil != 8) return SN_ERR_ARG;
   int rc = check_device(h);
@@ -2214,10 +2273,10 @@ int sn_dbg_ref_block_f16(sn_handle* h, const float* in, int h_px, int w, const f
   if ((rc = upload_ref_f16(h, HostLayer{w1, b1, kC, kC, 9}, &L1))) return rc;
   if ((rc = upload_ref_f16(h, HostLayer{w2, b2, kC, kC, 9}, &L2))) return rc;
   uint4 *da = nullptr, *db = nullptr;
-  HIP_TRY(h, dalloc(&da, slots + kRefSlack));
-  HIP_TRY(h, dalloc(&db, slots + kRefSlack));
-  HIP_TRY(h, hipMemset(da, 0, (slots + kRefSlack) * 16));
-  HIP_TRY(h, hipMemset(db, 0, (slots + kRefSlack) * 16));
+  HIP_TRY(h, dalloc(&da, slots + ref_slack(g)));
+  HIP_TRY(h, dalloc(&db, slots + ref_slack(g)));
+  HIP_TRY(h, hipMemset(da, 0, (slots + ref_slack(g)) * 16));
+  HIP_TRY(h, hipMemset(db, 0, (slots + ref_slack(g)) * 16));
   HIP_TRY(h, hipMemcpy(da, hin.data(), slots * 16, hipMemcpyHostToDevice));
   uint4 *cur = da, *oth = db;
   if (!h->ws.tile_ctr) {
@@ -2226,7 +2285,8 @@ int sn_dbg_ref_block_f16(sn_handle* h, const float* in, int h_px, int w, const f
   }
   HIP_TRY(h, hipMemsetAsync(h->ws.tile_ctr, 0, kTileCtrBytes, h->stream));
   // dilation 1 can go through the fused kernel here even when the pipeline does not use it
-  HIP_TRY(h, ref_block_f16(h->stream, L1, L2, g, h->num_cu, dil, &cur, &oth, 1, h->ws.tile_ctr, fused));
+  if (fuse_mode == 4 && !stream_block_supports(dil)) return SN_ERR_ARG;
+  HIP_TRY(h, ref_block_f16(h->stream, L1, L2, g, h->num_cu, dil, &cur, &oth, 1, h->ws.tile_ctr, fuse_mode, h->dump));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   std::vector<_Float16> hout(slots * 8);
   HIP_TRY(h, hipMemcpy(hout.data(), cur, slots * 16, hipMemcpyDeviceToHost));

@@ -1,0 +1,17 @@
+#!/bin/bash
+# rocprofv3 --pmc passes (kernel-trace only, one counter group per pass) over an arbitrary command, summarised per kernel:
+#   bash scripts/pmc_cmd.sh <tag> "<command>" "<group 1 counters>" "<group 2 counters>" ...
+set -u
+TAG=$1; CMD=$2; shift; shift
+ROOT=$(pwd); OUT=$ROOT/gpurun_out; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+i=0; files=""
+for grp in "$@"; do
+  i=$((i+1))
+  (cd $ROOT && timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pmc_${TAG}_$i -- $CMD) > $OUT/${TAG}_pass$i.log 2>&1
+  f=$(find /tmp/pmc_${TAG}_$i -name "*counter_collection.csv" | head -1)
+  if [ -n "$f" ]; then files="$files $f"; else echo "pass $i ($grp): no counters collected"; tail -3 $OUT/${TAG}_pass$i.log; fi
+done
+cd $ROOT
+python scripts/pmc_generic.py $OUT/${TAG}_counters.json $files > $OUT/${TAG}_counters.txt
+head -40 $OUT/${TAG}_counters.txt
