@@ -90,6 +90,11 @@ def load_library(path: Optional[str] = None):
     lib.sn_mgpu_get_handle.argtypes = [vp, ip, C.POINTER(vp)]
     lib.sn_mgpu_infer_batch.argtypes = [vp, ip, i8p, i32p, fp]
     lib.sn_mgpu_infer_batch_device.argtypes = [vp, ip, C.POINTER(vp), i32p, fp]
+    lib.sn_mgpu_submit_device.argtypes = [vp, ip, C.POINTER(vp), i32p, fp, C.POINTER(C.c_uint64)]
+    lib.sn_mgpu_wait.argtypes = [vp, C.c_uint64]
+    lib.sn_mgpu_ring_init.argtypes = [vp]
+    lib.sn_mgpu_ring_submit.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(ip)]
+    lib.sn_mgpu_ring_wait.argtypes = [vp, C.c_uint64, C.POINTER(ip)]
     lib.sn_mgpu_last_error.restype = C.c_char_p
     lib.sn_mgpu_last_error.argtypes = [vp]
     lib.sn_dbg_conv2d.argtypes = [vp, fp, ip, ip, ip, fp, fp, ip, ip, ip, ip, fp, fp]
@@ -103,7 +108,8 @@ def load_library(path: Optional[str] = None):
     for name in ("sn_create", "sn_destroy", "sn_get_io_info", "sn_infer_i8", "sn_infer_batch", "sn_preprocess_nv12",
                  "sn_infer_sbs_nv12", "sn_preprocess_sbs_nv12_batch", "sn_submit", "sn_submit_nv12", "sn_wait", "sn_synchronize", "sn_set_profiling",
                  "sn_get_stage_ms", "sn_get_dominant_kernel", "sn_mgpu_shard", "sn_mgpu_create", "sn_mgpu_destroy",
-                 "sn_mgpu_get_info", "sn_mgpu_get_handle", "sn_mgpu_infer_batch", "sn_mgpu_infer_batch_device", "sn_dbg_conv2d", "sn_dbg_down0", "sn_dbg_refin", "sn_dbg_conv3d", "sn_dbg_ref_conv_f16", "sn_dbg_ref_conv_f16x3", "sn_dbg_ref_block_f16", "sn_dbg_read"):
+                 "sn_mgpu_get_info", "sn_mgpu_get_handle", "sn_mgpu_infer_batch", "sn_mgpu_infer_batch_device",
+                 "sn_mgpu_submit_device", "sn_mgpu_wait", "sn_mgpu_ring_init", "sn_mgpu_ring_submit", "sn_mgpu_ring_wait", "sn_dbg_conv2d", "sn_dbg_down0", "sn_dbg_refin", "sn_dbg_conv3d", "sn_dbg_ref_conv_f16", "sn_dbg_ref_conv_f16x3", "sn_dbg_ref_block_f16", "sn_dbg_read"):
         getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
@@ -369,6 +375,33 @@ def mgpu_shard(n: int, ndev: int, k: int):
     return first.value, count.value
 
 
+class SnMgpuRing(C.Structure):
+    _fields_ = [("next", C.c_uint64), ("slot_ticket", C.c_uint64 * 2)]
+
+
+class MgpuRing:
+    """The ticket / buffer-slot bookkeeping of sn_mgpu_submit_device / sn_mgpu_wait (pure; needs no GPU)."""
+
+    def __init__(self):
+        self._lib = load_library()
+        self._r = SnMgpuRing()
+        self._lib.sn_mgpu_ring_init(C.byref(self._r))
+
+    def submit(self):
+        t, s = C.c_uint64(), C.c_int()
+        rc = self._lib.sn_mgpu_ring_submit(C.byref(self._r), C.byref(t), C.byref(s))
+        if rc != 0:
+            raise StereoNetError(rc, "sn_mgpu_ring_submit")
+        return t.value, s.value
+
+    def wait(self, ticket: int) -> int:
+        s = C.c_int()
+        rc = self._lib.sn_mgpu_ring_wait(C.byref(self._r), C.c_uint64(ticket), C.byref(s))
+        if rc != 0:
+            raise StereoNetError(rc, "sn_mgpu_ring_wait")
+        return s.value
+
+
 class StereoNetMultiGPU:
     """sn_mgpu_*: one batch sharded over the GPUs of one node inside ONE process (one host thread per GPU)."""
 
@@ -377,6 +410,11 @@ class StereoNetMultiGPU:
         self._lib = load_library()
         self._m = C.c_void_p()
         devs = list(devices) if devices is not None else None
+        if devs is None and ndev <= 0:      # neither given: every visible GPU (sn_mgpu_create itself rejects ndev <= 0)
+            import torch
+            ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+            if ndev <= 0:
+                raise StereoNetError(-4, "StereoNetMultiGPU: no GPU visible and neither devices nor ndev given")
         n = len(devs) if devs is not None else ndev
         arr = (C.c_int * n)(*devs) if devs is not None else None
         cfg = SnConfig(-1, max_batch, width, height, dmax, precision, 4, refine_chunk, piece)
@@ -413,6 +451,17 @@ class StereoNetMultiGPU:
         arr = (C.c_void_p * self.ndev)(*[C.c_void_p(p) for p in in_ptrs])
         self._check(self._lib.sn_mgpu_infer_batch_device(self._m, n, arr, raw_root_ptr or None, disp_root_ptr or None),
                     "sn_mgpu_infer_batch_device")
+
+    def submit_device(self, n: int, in_ptrs, raw_root_ptr: int, disp_root_ptr: int) -> int:
+        """Asynchronous infer_device: returns a ticket once every device has its shard enqueued (two may be in flight)."""
+        arr = (C.c_void_p * self.ndev)(*[C.c_void_p(p) for p in in_ptrs])
+        t = C.c_uint64()
+        self._check(self._lib.sn_mgpu_submit_device(self._m, n, arr, raw_root_ptr or None, disp_root_ptr or None, C.byref(t)),
+                    "sn_mgpu_submit_device")
+        return t.value
+
+    def wait(self, ticket: int):
+        self._check(self._lib.sn_mgpu_wait(self._m, C.c_uint64(ticket)), "sn_mgpu_wait")
 
     def close(self):
         if getattr(self, "_m", None) and self._m.value:

@@ -4,8 +4,13 @@
 //
 // Reference semantics: frames are independent units of work — dnn_node keeps task_num = 4 of them in flight
 // (stereonet_infer/src/stereonet_node.cpp:144) behind the one Run() call site (:812); this spreads such units over
-// devices instead of over BPU task slots.  Built only on the single-GPU C ABI plus HIP peer copies; RCCL (dlopen'ed,
-// opt-in with SN_MGPU_GATHER=rccl) replaces the peer copies with one grouped ncclSend/ncclRecv exchange.
+// devices instead of over BPU task slots.  Built only on the single-GPU C ABI; the gather is one grouped RCCL
+// ncclSend/ncclRecv exchange per batch (RCCL is dlopen'ed; the default whenever more than one distinct device takes
+// part and the library loads), with HIP peer copies as the fallback (SN_MGPU_GATHER=peer forces them).
+// Device-resident batches are ASYNCHRONOUS and double buffered: sn_mgpu_submit_device enqueues shard compute on each
+// device's compute stream and the exchange on its exchange stream behind an event, and returns a ticket; two tickets
+// may be in flight, so the gather of batch k crosses xGMI while batch k+1 computes (the reference's async Run with
+// task slots, stereonet_node.cpp:144,812).  sn_mgpu_infer_batch_device = submit + wait.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
@@ -50,12 +55,16 @@ struct Rccl {
 };
 constexpr int kNcclInt8 = 0;      // ncclInt8 / ncclChar (rccl.h): the maps travel as bytes
 
+constexpr int kSlots = 2;            // batches in flight per sn_mgpu (double buffering)
+
 struct Worker {
   int dev = 0;
   sn_handle* h = nullptr;
   hipStream_t st = nullptr;          // exchange stream of this device
-  int32_t* raw = nullptr;            // local int32 maps of this device's shard (device mode, shards 1..)
-  float* disp = nullptr;
+  hipStream_t cs = nullptr;          // compute stream of this device (device-resident batches)
+  int32_t* raw[kSlots] = {nullptr, nullptr};     // local int32 maps of this device's shard (device mode, shards 1..)
+  float* disp[kSlots] = {nullptr, nullptr};
+  hipEvent_t ev_compute[kSlots] = {nullptr, nullptr}, ev_done[kSlots] = {nullptr, nullptr};
   void* comm = nullptr;
   std::thread th;
   std::mutex mu;
@@ -67,11 +76,39 @@ struct Worker {
 
 }  // namespace
 
+// All workers agree on one status between "my shard's compute is enqueued" and "I join the exchange": a failed or
+// missing shard must keep EVERY rank out of the grouped RCCL exchange, otherwise the root's posted recv never
+// completes and the call hangs instead of returning an error.
+struct StatusBarrier {
+  std::mutex mu;
+  std::condition_variable cv;
+  int n = 0, arrived = 0, rc = 0, result = 0;
+  unsigned long long gen = 0;
+  int arrive_and_wait(int my_rc) {
+    std::unique_lock<std::mutex> lk(mu);
+    if (my_rc != 0 && rc == 0) rc = my_rc;
+    const unsigned long long g = gen;
+    if (++arrived == n) {
+      result = rc;
+      rc = 0;
+      arrived = 0;
+      ++gen;
+      cv.notify_all();
+      return result;
+    }
+    cv.wait(lk, [&] { return gen != g; });
+    return result;
+  }
+};
+
 struct sn_mgpu {
   int ndev = 0, max_batch = 0, per_dev = 0, W = 0, H = 0;
   int gather = 1;                    // 1 = hipMemcpyPeerAsync over xGMI, 2 = RCCL grouped send/recv
   std::vector<Worker*> w;
   Rccl rccl;
+  StatusBarrier agree;
+  sn_mgpu_ring ring{};
+  std::mutex api_mu;                 // submit / wait bookkeeping
   std::string err;
 };
 
@@ -137,6 +174,33 @@ int sn_mgpu_shard(int n, int ndev, int k, int* first, int* count) {
   return SN_OK;
 }
 
+// ---- ticket ring of the asynchronous form (pure bookkeeping; needs no GPU, tests/test_mgpu.py) -------------------
+// Tickets count 1, 2, 3, ..; ticket t uses buffer slot t % SN_MGPU_SLOTS; a slot is busy from submit until the wait of
+// its ticket, so at most SN_MGPU_SLOTS tickets are in flight and they may be waited for in any order.
+int sn_mgpu_ring_init(sn_mgpu_ring* r) {
+  if (!r) return SN_ERR_ARG;
+  r->next = 1;
+  for (int i = 0; i < SN_MGPU_SLOTS; ++i) r->slot_ticket[i] = 0;
+  return SN_OK;
+}
+int sn_mgpu_ring_submit(sn_mgpu_ring* r, uint64_t* ticket, int* slot) {
+  if (!r || !ticket || !slot || r->next == 0) return SN_ERR_ARG;
+  const int s = (int)(r->next % SN_MGPU_SLOTS);
+  if (r->slot_ticket[s] != 0) return SN_ERR_BUSY;          // its previous batch has not been waited for
+  r->slot_ticket[s] = r->next;
+  *ticket = r->next++;
+  *slot = s;
+  return SN_OK;
+}
+int sn_mgpu_ring_wait(sn_mgpu_ring* r, uint64_t ticket, int* slot) {
+  if (!r || !slot || ticket == 0) return SN_ERR_ARG;
+  const int s = (int)(ticket % SN_MGPU_SLOTS);
+  if (r->slot_ticket[s] != ticket) return SN_ERR_TICKET;   // unknown, or consumed already
+  r->slot_ticket[s] = 0;
+  *slot = s;
+  return SN_OK;
+}
+
 const char* sn_mgpu_last_error(const sn_mgpu* m) { return m ? m->err.c_str() : ""; }
 
 int sn_mgpu_destroy(sn_mgpu* m) {
@@ -151,10 +215,17 @@ int sn_mgpu_destroy(sn_mgpu* m) {
       w->th.join();
     }
     hipSetDevice(w->dev);
+    if (w->st) hipStreamSynchronize(w->st);
+    if (w->cs) hipStreamSynchronize(w->cs);
     if (w->comm && m->rccl.CommDestroy) m->rccl.CommDestroy(w->comm);
-    if (w->raw) hipFree(w->raw);
-    if (w->disp) hipFree(w->disp);
+    for (int i = 0; i < kSlots; ++i) {
+      if (w->raw[i]) hipFree(w->raw[i]);
+      if (w->disp[i]) hipFree(w->disp[i]);
+      if (w->ev_compute[i]) hipEventDestroy(w->ev_compute[i]);
+      if (w->ev_done[i]) hipEventDestroy(w->ev_done[i]);
+    }
     if (w->st) hipStreamDestroy(w->st);
+    if (w->cs) hipStreamDestroy(w->cs);
     if (w->h) sn_destroy(w->h);
     delete w;
   }
@@ -167,20 +238,34 @@ int sn_mgpu_create(const char* model_file, const sn_config* cfg, const int* devi
   *out = nullptr;
   int have = 0;
   if (hipGetDeviceCount(&have) != hipSuccess || have <= 0) return SN_ERR_DEVICE;
+  // SN_MGPU_ALLOW_DUP=1 (tests): several shards may name the same device, so the worker threads, the shard
+  // arithmetic and the gather run for ndev > 1 on a one-GPU box.  RCCL needs distinct devices: peer copies then.
+  const bool allow_dup = getenv("SN_MGPU_ALLOW_DUP") != nullptr && atoi(getenv("SN_MGPU_ALLOW_DUP")) == 1;
+  bool distinct = true;
   for (int k = 0; k < ndev; ++k) {
     const int d = devices ? devices[k] : k;
     if (d < 0 || d >= have) return SN_ERR_ARG;
     for (int j = 0; j < k; ++j)
-      if ((devices ? devices[j] : j) == d) return SN_ERR_ARG;      // a device may hold one shard only
+      if ((devices ? devices[j] : j) == d) {
+        if (!allow_dup) return SN_ERR_ARG;                           // a device may hold one shard only
+        distinct = false;
+      }
   }
   sn_mgpu* m = new sn_mgpu();
   m->ndev = ndev;
+  m->agree.n = ndev;
+  sn_mgpu_ring_init(&m->ring);
   sn_config c{};
   if (cfg) c = *cfg;
   m->max_batch = c.max_batch > 0 ? c.max_batch : ndev;
   m->per_dev = (m->max_batch + ndev - 1) / ndev;
-  if (const char* e = getenv("SN_MGPU_GATHER")) m->gather = !strcmp(e, "rccl") ? 2 : 1;
-  if (m->gather == 2 && (ndev == 1 || !m->rccl.load())) m->gather = 1;
+  // the north-star's exchange is RCCL over xGMI: the default whenever it can run; SN_MGPU_GATHER=peer / rccl force one
+  m->gather = (ndev > 1 && distinct) ? 2 : 1;
+  if (const char* e = getenv("SN_MGPU_GATHER")) {
+    if (!strcmp(e, "peer")) m->gather = 1;
+    else if (!strcmp(e, "rccl") && ndev > 1 && distinct) m->gather = 2;
+  }
+  if (m->gather == 2 && !m->rccl.load()) m->gather = 1;
   int rc = SN_OK;
   for (int k = 0; k < ndev && rc == SN_OK; ++k) {
     Worker* w = new Worker();
@@ -199,17 +284,26 @@ int sn_mgpu_create(const char* model_file, const sn_config* cfg, const int* devi
     sn_get_io_info(w->h, &info);
     m->W = info.width;
     m->H = info.height;
-    if (hipSetDevice(w->dev) != hipSuccess || hipStreamCreateWithFlags(&w->st, hipStreamNonBlocking) != hipSuccess) rc = SN_ERR_DEVICE;
-    if (rc == SN_OK && k > 0) {          // staging for the maps that travel to the root in device mode
+    if (hipSetDevice(w->dev) != hipSuccess || hipStreamCreateWithFlags(&w->st, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&w->cs, hipStreamNonBlocking) != hipSuccess)
+      rc = SN_ERR_DEVICE;
+    for (int i = 0; i < kSlots && rc == SN_OK; ++i)
+      if (hipEventCreateWithFlags(&w->ev_compute[i], hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&w->ev_done[i], hipEventDisableTiming) != hipSuccess)
+        rc = SN_ERR_DEVICE;
+    if (rc == SN_OK && k > 0) {          // staging for the maps that travel to the root in device mode, one set per slot
       const size_t bytes = (size_t)m->per_dev * m->W * m->H * 4;
-      if (hipMalloc(reinterpret_cast<void**>(&w->raw), bytes) != hipSuccess ||
-          hipMalloc(reinterpret_cast<void**>(&w->disp), bytes) != hipSuccess)
-        rc = SN_ERR_NOMEM;
+      for (int i = 0; i < kSlots && rc == SN_OK; ++i)
+        if (hipMalloc(reinterpret_cast<void**>(&w->raw[i]), bytes) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&w->disp[i]), bytes) != hipSuccess)
+          rc = SN_ERR_NOMEM;
       // direct xGMI copies in both directions between this device and the root (an "already enabled" error is fine)
-      int can = 0;
-      if (hipDeviceCanAccessPeer(&can, w->dev, m->w[0]->dev) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(m->w[0]->dev, 0);
-      hipSetDevice(m->w[0]->dev);
-      if (hipDeviceCanAccessPeer(&can, m->w[0]->dev, w->dev) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(w->dev, 0);
+      if (w->dev != m->w[0]->dev) {
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, w->dev, m->w[0]->dev) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(m->w[0]->dev, 0);
+        hipSetDevice(m->w[0]->dev);
+        if (hipDeviceCanAccessPeer(&can, m->w[0]->dev, w->dev) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(w->dev, 0);
+      }
       (void)hipGetLastError();
     }
   }
@@ -266,30 +360,43 @@ int sn_mgpu_infer_batch(sn_mgpu* m, int n, const int8_t* in, int32_t* out_i32, f
   });
 }
 
-// Device buffers: in_per_device[k] holds shard k's pairs in the memory of device k; the int32 / float maps of all n
-// pairs are gathered, in batch order, into out_* in the memory of device 0 (the root) over xGMI.
-int sn_mgpu_infer_batch_device(sn_mgpu* m, int n, const int8_t* const* in_per_device, int32_t* out_i32_root,
-                               float* out_disp_root) {
+// Device buffers, asynchronous: in_per_device[k] holds shard k's pairs in the memory of device k; the int32 / float maps
+// of all n pairs are gathered, in batch order, into out_* in the memory of device 0 (the root) over xGMI.  Returns as soon
+// as every device has its work enqueued; the inputs and the root buffers belong to the call until sn_mgpu_wait(ticket).
+int sn_mgpu_submit_device(sn_mgpu* m, int n, const int8_t* const* in_per_device, int32_t* out_i32_root, float* out_disp_root,
+                          uint64_t* ticket) {
   if (!m) return SN_ERR_ARG;
-  if (!in_per_device || (!out_i32_root && !out_disp_root) || n <= 0 || n > m->max_batch) {
-    m->err = "sn_mgpu_infer_batch_device: bad arguments";
+  if (!in_per_device || !ticket || (!out_i32_root && !out_disp_root) || n <= 0 || n > m->max_batch) {
+    m->err = "sn_mgpu_submit_device: bad arguments";
     return SN_ERR_ARG;
+  }
+  std::lock_guard<std::mutex> api(m->api_mu);
+  int slot = 0;
+  uint64_t t = 0;
+  int rc = sn_mgpu_ring_submit(&m->ring, &t, &slot);
+  if (rc != SN_OK) {
+    m->err = "sn_mgpu_submit_device: two batches are in flight already (wait for a ticket first)";
+    return rc;
   }
   const size_t HW = (size_t)m->W * m->H;
   const int root = m->w[0]->dev;
-  return run_all(m, [&](int k) -> int {
+  rc = run_all(m, [&](int k) -> int {
     Worker* w = m->w[k];
     int first = 0, cnt = 0;
     sn_mgpu_shard(n, m->ndev, k, &first, &cnt);
-    int32_t* raw = !out_i32_root ? nullptr : (k == 0 ? out_i32_root : w->raw);
-    float* disp = !out_disp_root ? nullptr : (k == 0 ? out_disp_root : w->disp);
+    int32_t* raw = !out_i32_root ? nullptr : (k == 0 ? out_i32_root : w->raw[slot]);
+    float* disp = !out_disp_root ? nullptr : (k == 0 ? out_disp_root : w->disp[slot]);
+    int my = SN_OK;
     if (cnt > 0) {
-      if (!in_per_device[k]) return SN_ERR_ARG;
-      const int rc = sn_infer_batch(w->h, cnt, in_per_device[k], raw, disp, SN_MEM_DEVICE, nullptr);   // synchronous
-      if (rc != SN_OK) return rc;
+      if (!in_per_device[k]) my = SN_ERR_ARG;
+      else my = sn_infer_batch(w->h, cnt, in_per_device[k], raw, disp, SN_MEM_DEVICE, w->cs);      // enqueued on the compute stream
     }
-    if (m->ndev == 1) return SN_OK;
-    if (m->gather == 2) {              // one grouped exchange: root posts a recv per peer, every peer one send per map kind
+    if (my == SN_OK && hipEventRecord(w->ev_compute[slot], w->cs) != hipSuccess) my = SN_ERR_DEVICE;
+    // every rank learns whether ALL shards are on their way before any of them enters the exchange
+    const int all = m->ndev > 1 ? m->agree.arrive_and_wait(my) : my;
+    if (all != SN_OK) return my != SN_OK ? my : all;
+    if (hipStreamWaitEvent(w->st, w->ev_compute[slot], 0) != hipSuccess) return SN_ERR_DEVICE;
+    if (m->ndev > 1 && m->gather == 2) {     // one grouped exchange: root posts a recv per peer, every peer one send per map kind
       bool ok = m->rccl.GroupStart() == 0;
       for (int kind = 0; kind < 2 && ok; ++kind) {
         char* root_buf = reinterpret_cast<char*>(kind == 0 ? (void*)out_i32_root : (void*)out_disp_root);
@@ -306,18 +413,49 @@ int sn_mgpu_infer_batch_device(sn_mgpu* m, int n, const int8_t* const* in_per_de
         }
       }
       ok = (m->rccl.GroupEnd() == 0) && ok;
-      if (!ok || hipStreamSynchronize(w->st) != hipSuccess) return SN_ERR_DEVICE;
-      return SN_OK;
-    }
-    if (k > 0 && cnt > 0) {            // peer copies: every non-root device pushes its maps over its own link
+      if (!ok) return SN_ERR_DEVICE;
+    } else if (k > 0 && cnt > 0) {       // peer copies: every non-root device pushes its maps over its own link
       if (raw && hipMemcpyPeerAsync(out_i32_root + (size_t)first * HW, root, raw, w->dev, (size_t)cnt * HW * 4, w->st) != hipSuccess)
         return SN_ERR_DEVICE;
       if (disp && hipMemcpyPeerAsync(out_disp_root + (size_t)first * HW, root, disp, w->dev, (size_t)cnt * HW * 4, w->st) != hipSuccess)
         return SN_ERR_DEVICE;
-      if (hipStreamSynchronize(w->st) != hipSuccess) return SN_ERR_DEVICE;
     }
-    return SN_OK;
+    return hipEventRecord(w->ev_done[slot], w->st) == hipSuccess ? SN_OK : SN_ERR_DEVICE;
   });
+  if (rc != SN_OK) {                     // nothing usable is in flight: drain what was enqueued and free the slot
+    run_all(m, [&](int k) -> int {
+      hipStreamSynchronize(m->w[k]->cs);
+      hipStreamSynchronize(m->w[k]->st);
+      return SN_OK;
+    });
+    int s2 = 0;
+    sn_mgpu_ring_wait(&m->ring, t, &s2);
+    return rc;
+  }
+  *ticket = t;
+  return SN_OK;
+}
+
+int sn_mgpu_wait(sn_mgpu* m, uint64_t ticket) {
+  if (!m) return SN_ERR_ARG;
+  std::lock_guard<std::mutex> api(m->api_mu);
+  int slot = 0;
+  const int rc = sn_mgpu_ring_wait(&m->ring, ticket, &slot);
+  if (rc != SN_OK) {
+    m->err = "sn_mgpu_wait: unknown or already-consumed ticket";
+    return rc;
+  }
+  return run_all(m, [&](int k) -> int {
+    return hipEventSynchronize(m->w[k]->ev_done[slot]) == hipSuccess ? SN_OK : SN_ERR_DEVICE;
+  });
+}
+
+int sn_mgpu_infer_batch_device(sn_mgpu* m, int n, const int8_t* const* in_per_device, int32_t* out_i32_root,
+                               float* out_disp_root) {
+  uint64_t t = 0;
+  const int rc = sn_mgpu_submit_device(m, n, in_per_device, out_i32_root, out_disp_root, &t);
+  if (rc != SN_OK) return rc;
+  return sn_mgpu_wait(m, t);
 }
 
 }  // extern "C"

@@ -63,24 +63,26 @@
 
 namespace sn {
 
-template <int DIL_, int TW_ = 64, int R_ = 4, int NXS_ = 6>
+template <int DIL_, int TW_ = 64, int R_ = 4, int NXS_ = 6, int NWR_ = 4>
 struct StreamTile {
   static constexpr int DIL = DIL_, TW = TW_, R = R_, NXS = NXS_, NTS = 3, PF = NXS_ - 4;
+  static constexpr int NWR = NWR_;                         // waves per role (conv1 / conv2): 4 or 8
   static constexpr int OW = TW - 2 * DIL;                  // output columns of a strip
   static constexpr int XW = TW + 2 * DIL;                  // x columns of a strip
   static constexpr int CSEG = TW / 32;                     // 32-pixel MFMA segments per row
-  static constexpr int SPW = R * CSEG / 4;                 // segments per MFMA wave and conv
+  static constexpr int SPW = R * CSEG / NWR;               // segments per wave and conv
   static constexpr int XROW = 4 * XW, TROW = 4 * TW;       // slots per ring row: [channel block][column]
   static constexpr int XGROUP = R * XROW;                  // slots of one DMA group (R rows)
   static constexpr int NINST = (XGROUP + 63) / 64;         // 1 KiB LDS-DMA instructions per group
-  static constexpr int KW = (NINST + 3) / 4;               // ... per helper wave (constant: tail instructions repeat)
+  static constexpr int KW = (NINST + NWR - 1) / NWR;       // ... per conv1 wave, at most
   static constexpr int XGP = NINST * 64;                   // ring pitch of a group (the last instruction may overshoot)
   static constexpr int TGP = R * TROW;
   static constexpr int XRING = NXS * XGP;
   static constexpr int TRING = NTS * TGP + 64;             // conv2's kx taps of the junk columns run past the last row
   static constexpr int NST = R * ((OW + 63) / 64);         // store instructions per helper wave and step (constant)
   static constexpr int LDS_BYTES = (XRING + TRING) * 16 + 2 * 2 * 16 * 4;      // + bias tables [conv][k-half][16]
-  static_assert(SPW == 2, "four MFMA waves, two segments each per conv");
+  static_assert(SPW == 1 || SPW == 2, "segments per wave");
+  static_assert(CSEG % SPW == 0, "a wave's segments lie in one row");
   static_assert(PF == 2, "prefetch distance the counted waits are written for");
   static_assert(R == 4 || R == 2, "rows per step");
   static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
@@ -127,17 +129,18 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 // included), COLW = slots per channel block row.  The B fragments are fetched in batches of six (one tap row of one
 // channel half: 3 kx x 2 segments) one batch ahead of the MFMAs that consume them — left to itself hipcc used a
 // single fragment register set (read, wait, MFMA, read, ...), exposing the full LDS latency 36 times per conv.
-template <int DIL, int COLW>
+template <int DIL, int COLW, int SPW>
 __device__ __forceinline__ void stream_conv36(const uint4* const (&rp)[3], const half8 (&wf)[18], const f32x16& bv,
-                                              f32x16 (&acc)[2]) {
-  half8 b[2][6];
-  auto fetch = [&](int batch, half8 (&dst)[6]) {
+                                              f32x16 (&acc)[SPW]) {
+  constexpr int NB = 3 * SPW;            // fragments per batch
+  half8 b[2][NB];
+  auto fetch = [&](int batch, half8 (&dst)[NB]) {
     const int kk = batch / 3, ky = batch - kk * 3;
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
-        dst[kx * 2 + s] = *reinterpret_cast<const half8*>(rp[ky] + (2 * kk * COLW + s * 32 + kx * DIL));
+      for (int s = 0; s < SPW; ++s)
+        dst[kx * SPW + s] = *reinterpret_cast<const half8*>(rp[ky] + (2 * kk * COLW + s * 32 + kx * DIL));
   };
   fetch(0, b[0]);
 #pragma unroll
@@ -147,21 +150,22 @@ __device__ __forceinline__ void stream_conv36(const uint4* const (&rp)[3], const
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
+      for (int s = 0; s < SPW; ++s) {
         const int tap = ky * 3 + kx;
         if (batch == 0 && kx == 0) acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[tap * 2 + kk], b[0][s], bv, 0, 0, 0);
-        else acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[tap * 2 + kk], b[batch & 1][kx * 2 + s], acc[s], 0, 0, 0);
+        else acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[tap * 2 + kk], b[batch & 1][kx * SPW + s], acc[s], 0, 0, 0);
       }
   }
-  // issue order for the machine scheduler: the bias + the first eight fragments up front, then one read per MFMA, so
-  // that eight LDS reads are always in flight (0x100 = DS read, 0x008 = MFMA)
-  __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+  // issue order for the machine scheduler: the bias + the first fragments up front, then one read per MFMA, so that
+  // AHEAD LDS reads are always in flight (0x100 = DS read, 0x008 = MFMA)
+  constexpr int AHEAD = SPW == 2 ? 8 : 5, NM = 18 * SPW;
+  __builtin_amdgcn_sched_group_barrier(0x100, 4 + AHEAD, 0);
 #pragma unroll
-  for (int i = 0; i < 28; ++i) {
+  for (int i = 0; i < NM - AHEAD; ++i) {
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
   }
-  __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+  __builtin_amdgcn_sched_group_barrier(0x008, AHEAD, 0);
 }
 
 // LDS-DMA as inline asm: hipcc models __builtin_amdgcn_global_load_lds as a pending LDS write and would put
@@ -181,12 +185,12 @@ __device__ __forceinline__ void glds16(unsigned lds_dst, unsigned voff, const vo
       : "memory");
 }
 
-template <int DIL, int TW, int R, int NXS>
-__global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ref_block_stream_f16(const uint4* __restrict__ xin, uint4* __restrict__ yout,
+template <int DIL, int TW, int R, int NXS, int NWR>
+__global__ __launch_bounds__(128 * NWR, NWR / 2) __attribute__((amdgpu_waves_per_eu(NWR / 2, NWR / 2))) void k_ref_block_stream_f16(const uint4* __restrict__ xin, uint4* __restrict__ yout,
                                                                 const uint4* __restrict__ wfrag1, const float* __restrict__ bias1,
                                                                 const uint4* __restrict__ wfrag2, const float* __restrict__ bias2,
                                                                 RefGeom g, StreamSched sc, uint4* __restrict__ dump) {
-  using T = StreamTile<DIL, TW, R, NXS>;
+  using T = StreamTile<DIL, TW, R, NXS, NWR>;
   extern __shared__ __attribute__((aligned(16))) uint4 lds[];
   uint4* const xring = lds;
   uint4* const tring = lds + T::XRING;
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, gh = lane >> 5;
-  const int role = wave >> 2, rw = wave & 3;                // role 0: conv1 + DMA, role 1: conv2 + stores
+  const int role = wave / NWR, rw = wave % NWR;             // role 0: conv1 + DMA, role 1: conv2 + stores
 
   const int f0 = (int)blockIdx.x * sc.rows_per_wg;
   int f1 = f0 + sc.rows_per_wg;
@@ -248,11 +252,11 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const int lane_w = cseg0 * 32 + j;                     // t write
     // this wave's DMA instructions i = rw, rw + 4, ..: per-lane source offsets relative to the group origin
     constexpr int KWMAX = T::KW;
-    const int kw = (T::NINST - rw + 3) / 4;                // instructions of this wave (uniform, 4 or 5 for 17)
+    const int kw = (T::NINST - rw + NWR - 1) / NWR;        // instructions of this wave (uniform: KWMAX or KWMAX - 1)
     unsigned dma_voff[KWMAX];
 #pragma unroll
     for (int k = 0; k < KWMAX; ++k) {
-      const int i = rw + 4 * k;
+      const int i = rw + NWR * k;
       int s = i * 64 + lane;
       s = s < T::XGROUP ? s : T::XGROUP - 1;               // the overshoot of the last instruction lands in the ring pitch
       const int r = s / T::XROW;
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       const unsigned dst = lds_addr(xring + grp * T::XGP);
 #pragma unroll
       for (int k = 0; k < KWMAX; ++k)
-        if (k < kw) glds16(dst + (unsigned)(rw + 4 * k) * 1024u, dma_voff[k], src);
+        if (k < kw) glds16(dst + (unsigned)(rw + NWR * k) * 1024u, dma_voff[k], src);
     };
     // `extra` = store instructions younger than the group that must have landed
     auto wait_group = [&](auto extra) {    // all but this wave's youngest DMA group have landed
@@ -315,8 +319,8 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
           xp[ky] = xring + (rr < 0 ? gx1 : gx0) * T::XGP + (rr & (R - 1)) * T::XROW + lane_x;
         }
         const f32x16 bv = *reinterpret_cast<const f32x16*>(s_bias + gh * 16);
-        f32x16 acc[2];
-        stream_conv36<DIL, T::XW>(xp, wf, bv, acc);
+        f32x16 acc[T::SPW];
+        stream_conv36<DIL, T::XW, T::SPW>(xp, wf, bv, acc);
         SN_STAMP(2);
         // epilogue: t = lrelu(acc) as fp16, zero outside the image (conv2's zero padding)
         const int trow = (c1.v0 - 1 + R * (c1.j - 1) + rowW) * DIL + c1_py;            // image row of this wave's t row
@@ -328,7 +332,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         // through a v_cndmask as well)
         auto write_t = [&](auto is_interior) {
 #pragma unroll
-          for (int s = 0; s < 2; ++s) {
+          for (int s = 0; s < T::SPW; ++s) {
             bool inside = true;
             if (!decltype(is_interior)::value) {
               const int c = tc0 + (cseg0 + s) * 32 + j;
@@ -371,9 +375,9 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     asm volatile("" : "+v"(one));          // opaque: keeps the multiply so that hipcc selects v_fma_mix_f32 for the residual
     // after the half exchange below lane (j, gh) owns the whole 16-byte slots of channel blocks 2 gh and 2 gh + 1
     const unsigned lane_o = (unsigned)(cseg0 * 32 + j) * 16u + (unsigned)(2 * gh) * plane_b;
-    f32x16 acc[2];
+    f32x16 acc[T::SPW];
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < T::SPW; ++s)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
     int qx = 0, qt = 0;
@@ -397,7 +401,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
           const unsigned ob = (((unsigned)ep_img * 4u * (unsigned)g.Hs + (unsigned)(row + kRefPad)) * (unsigned)g.Ws +
                                (unsigned)(ep_x0 + kRefPad)) * 16u;
 #pragma unroll
-          for (int s = 0; s < 2; ++s) {
+          for (int s = 0; s < T::SPW; ++s) {
             unsigned pk[4][2];               // [channel block][channels 4 gh + {0,1} | {2,3}] as packed fp16 pairs
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
@@ -455,7 +459,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
           tp[ky] = tring + (rr < 0 ? gt2 : gt1) * T::TGP + (rr & (R - 1)) * T::TROW + lane_t;
         }
         const f32x16 bv = *reinterpret_cast<const f32x16*>(s_bias + (2 + gh) * 16);
-        stream_conv36<DIL, T::TW>(tp, wf, bv, acc);
+        stream_conv36<DIL, T::TW, T::SPW>(tp, wf, bv, acc);
       }
       SN_STAMP(2);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -627,8 +627,8 @@ hipError_t launch_ref_block_f16_h(hipStream_t st, const RefLayerF16& L1, const R
 template <int DIL>
 hipError_t launch_ref_block_stream(hipStream_t st, const RefLayerF16& L1, const RefLayerF16& L2, const RefGeom& g, int num_cu,
                                    const uint4* x, uint4* y, int nimg, unsigned* dump) {
-  using T = StreamTile<DIL, 64, 4, 6>;
-  auto kern = k_ref_block_stream_f16<DIL, 64, 4, 6>;
+  using T = StreamTile<DIL, 64, 4, 6, 4>;
+  auto kern = k_ref_block_stream_f16<DIL, 64, 4, 6, 4>;
   if (dump == nullptr) return hipErrorInvalidValue;
   hipError_t e = ensure_lds_attr(kern, T::LDS_BYTES);
   if (e != hipSuccess) return e;

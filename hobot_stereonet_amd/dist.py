@@ -49,17 +49,29 @@ def gather_to_root(local: torch.Tensor, counts: List[int], dst: int = 0) -> Opti
 class AsyncGather:
     """gather_to_root for equal shards without blocking the compute stream: the collective is enqueued with
     async_op=True (RCCL runs it on its own stream behind an event on the current stream), so the next batch's
-    kernels overlap the transfer over xGMI.  Call wait() before reusing the source tensor."""
+    kernels overlap the transfer over xGMI.  Call wait() before reusing the source tensor.
+
+    gloo has no gather for device tensors: a device-resident shard is staged through host memory (a synchronous copy,
+    then the same asynchronous gather on the host copies) and rank `dst` gets its buffers back on the shard's device.
+    That form exists so that the whole multi-rank path — real engine, real maps — can run where RCCL cannot, e.g. two
+    ranks on ONE GPU in the tests; it is not a throughput path."""
 
     def __init__(self, local: torch.Tensor, dst: int = 0):
         world, rank = dist.get_world_size(), dist.get_rank()
-        self.bufs = [torch.empty_like(local) for _ in range(world)] if rank == dst else None
-        self.work = dist.gather(local.contiguous(), self.bufs, dst=dst, async_op=True)
+        self.device = local.device
+        self.staged = local.is_cuda and dist.get_backend() == "gloo"
+        send = local.contiguous()
+        if self.staged:
+            send = send.cpu()                 # waits for the producing stream
+        self.bufs = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+        self.work = dist.gather(send, self.bufs, dst=dst, async_op=True)
 
     def wait(self):
         if self.work is not None:
             self.work.wait()
             self.work = None
+            if self.staged and self.bufs is not None:
+                self.bufs = [b.to(self.device) for b in self.bufs]
         return self.bufs
 
 

@@ -149,8 +149,13 @@ int sn_synchronize(sn_handle *h);
  * the largest TOTAL n; devices == NULL selects 0..ndev-1.
  *   sn_mgpu_infer_batch         host buffers: every device copies its shard in and its maps out — the host is the root.
  *   sn_mgpu_infer_batch_device  in_per_device[k] = shard k resident on device k; maps gathered in batch order into
- *                               out_* on device 0 over xGMI (hipMemcpyPeerAsync from each peer over its own link, or —
- *                               SN_MGPU_GATHER=rccl — one grouped RCCL ncclSend/ncclRecv exchange).
+ *                               out_* on device 0 over xGMI: one grouped RCCL ncclSend/ncclRecv exchange per batch
+ *                               (the default when ndev > 1 and librccl loads), or hipMemcpyPeerAsync from each peer over
+ *                               its own link (fallback; SN_MGPU_GATHER=peer forces it).  = submit + wait below.
+ *   sn_mgpu_submit_device /     the asynchronous form of the same (the reference's async Run with task slots): returns a
+ *   sn_mgpu_wait                ticket once every device has its shard enqueued; SN_MGPU_SLOTS = 2 tickets may be in
+ *                               flight (per-device staging is double buffered), so the gather of batch k overlaps the
+ *                               compute of batch k + 1.  Inputs and root buffers belong to the call until the wait.
  * Results are bit-identical to sn_infer_batch on one GPU (same kernels, no cross-pair reduction). */
 typedef struct sn_mgpu sn_mgpu;
 int sn_mgpu_shard(int n, int ndev, int k, int *first, int *count);         /* pure shard arithmetic */
@@ -161,7 +166,20 @@ int sn_mgpu_get_handle(sn_mgpu *m, int k, sn_handle **h);                  /* th
 int sn_mgpu_infer_batch(sn_mgpu *m, int n, const int8_t *in_nchw6_host, int32_t *out_i32_host, float *out_disp_host);
 int sn_mgpu_infer_batch_device(sn_mgpu *m, int n, const int8_t *const *in_per_device, int32_t *out_i32_root,
                                float *out_disp_root);
+int sn_mgpu_submit_device(sn_mgpu *m, int n, const int8_t *const *in_per_device, int32_t *out_i32_root,
+                          float *out_disp_root, uint64_t *ticket);      /* SN_ERR_BUSY: two tickets in flight */
+int sn_mgpu_wait(sn_mgpu *m, uint64_t ticket);                            /* SN_ERR_TICKET: unknown / consumed   */
 const char *sn_mgpu_last_error(const sn_mgpu *m);
+/* The ticket / buffer-slot bookkeeping of the asynchronous form as pure functions (no GPU; tests): tickets count from
+ * 1, ticket t uses slot t % SN_MGPU_SLOTS, a slot is busy from submit to the wait of its ticket. */
+#define SN_MGPU_SLOTS 2
+typedef struct sn_mgpu_ring {
+  uint64_t next;
+  uint64_t slot_ticket[SN_MGPU_SLOTS];
+} sn_mgpu_ring;
+int sn_mgpu_ring_init(sn_mgpu_ring *r);
+int sn_mgpu_ring_submit(sn_mgpu_ring *r, uint64_t *ticket, int *slot);
+int sn_mgpu_ring_wait(sn_mgpu_ring *r, uint64_t ticket, int *slot);
 
 /* Measurement hooks (bench.py): per-stage device time of the most recent sn_infer_batch, taken
  * with hipEvents on the stream the kernels ran on.  Stage ids: */

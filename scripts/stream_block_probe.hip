@@ -61,11 +61,14 @@ static void upload(Layer& L) {
 
 static float q16(float v) { return (float)(_Float16)v; }
 
+#ifndef PROBE_NWR
+#define PROBE_NWR 4
+#endif
 template <int DIL>
 static hipError_t launch_stream(hipStream_t st, const Layer& L1, const Layer& L2, const RefGeom& g, int ncu, const uint4* x, uint4* y,
                                 int nimg, uint4* dump, int wg_override = 0) {
-  using T = StreamTile<DIL, 64, 4, 6>;
-  auto kern = k_ref_block_stream_f16<DIL, 64, 4, 6>;
+  using T = StreamTile<DIL, 64, 4, 6, PROBE_NWR>;
+  auto kern = k_ref_block_stream_f16<DIL, 64, 4, 6, PROBE_NWR>;
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
@@ -80,7 +83,7 @@ static hipError_t launch_stream(hipStream_t st, const Layer& L1, const Layer& L2
   if (nwg > sc.total_rows) nwg = sc.total_rows;
   sc.rows_per_wg = (sc.total_rows + nwg - 1) / nwg;
   const int grid = (sc.total_rows + sc.rows_per_wg - 1) / sc.rows_per_wg;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), T::LDS_BYTES, st, x, y, L1.wfrag, L1.bias, L2.wfrag, L2.bias, g, sc, dump);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * PROBE_NWR), T::LDS_BYTES, st, x, y, L1.wfrag, L1.bias, L2.wfrag, L2.bias, g, sc, dump);
   return hipGetLastError();
 }
 

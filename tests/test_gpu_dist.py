@@ -1,0 +1,95 @@
+"""The N > 1 path with the REAL engine on a one-GPU box (BASELINE configs[3] / [4] are 8-GPU configurations; the driver's
+scaling run is the only place they execute for real).  `bench.py --gpus 2 --dist-backend gloo --device-map 0,0` starts
+two ranks that both drive GPU 0: each builds its own engine, infers its own seeded shard, the int32 maps are gathered to
+rank 0 (staged through host memory — gloo has no device gather), and rank 0 verifies the gathered maps of rank 1 against
+its OWN inference of rank 1's inputs.  A rank / device / shard mix-up that would zero an 8-GPU result fails here."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(extra, timeout=1200):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, BENCH] + extra, capture_output=True, text=True, cwd=ROOT, timeout=timeout, env=env)
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, lines
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_real_engine():
+    r, lines = _run(["--gpus", "2", "--dist-backend", "gloo", "--device-map", "0,0", "--batch", "4", "--steps", "2",
+                     "--warmup", "1", "--no-cpu-baseline", "--no-end-to-end"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["world_size_seen"] == 2 and d["self_launched"] is True
+    assert d["verified"] is True and "gathered maps of ranks 1..1" in d["verification"]
+    assert d["config"]["devices"] == [0, 0] and "gloo" in d["config"]["parallelism"]
+    assert d["config"]["pairs_per_gpu_per_step"] == 4 and d["steps"] == 2
+    assert d["value"] > 0 and abs(d["value"] - 2 * 4 * 2 / (d["ms_per_step"] * 2 / 1e3)) < 1e-6 * d["value"]
+
+
+@pytest.mark.gpu
+def test_shared_gpu_needs_gloo():
+    r, lines = _run(["--gpus", "2", "--device-map", "0,0", "--batch", "2", "--steps", "1"])
+    assert r.returncode != 0 and not lines
+    assert "gloo" in r.stderr
+
+
+@pytest.mark.gpu
+def test_timed_workload_batch_64_at_the_metric_size(model_factory, oracle, weights_blob):
+    """BASELINE configs[2] — the workload bench.py times: 64 pairs of 1280x720 D=192 through the fp16 path in one call.
+    Every pair equals its single-pair inference bit for bit (batching, pieces, tower chunks and streams change nothing)
+    and one pair is within the north-star bound of the CPU oracle."""
+    import numpy as np
+    from hobot_stereonet_amd import api, synth
+    w, h, d = 1280, 720, 192
+    base = [synth.model_input_i8(w, h, d, 300 + s) for s in range(4)]
+    xs = np.stack([np.roll(base[k % 4], 16 * (k // 4), axis=2) for k in range(64)])
+    with api.StereoNetHIP(model_factory(w, h, d), precision=api.PREC_F16, max_batch=64) as eng:
+        disp, raw = eng.infer(xs)
+        for k in (0, 1, 17, 38, 63):
+            d1, r1 = eng.infer(xs[k])
+            assert (r1 == raw[k]).all() and (d1 == disp[k]).all(), k
+    assert (raw >= 0).all() and np.isfinite(disp).all()
+    odisp = oracle.forward(weights_blob, xs[17], d)[0]
+    assert float(np.abs(disp[17] - odisp).mean()) < 1e-3
+
+
+@pytest.mark.gpu
+def test_stream_mode_contract_c5():
+    """BASELINE configs[4]'s mode on one GPU: bench.py --config c5 --stream (sustained host-to-host stream of the
+    hierarchical-refinement model at 1242x375 D=256)."""
+    r, lines = _run(["--config", "c5", "--stream", "2", "--batch", "8"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1
+    d = lines[0]
+    assert d["config"]["width"] == 1242 and d["config"]["height"] == 375 and d["config"]["dmax"] == 256
+    assert d["config"]["refine"] == "multi" and d["config"]["refine_levels"] == 4
+    assert d["stream"]["h2d_bytes_per_pair"] == 6 * 1242 * 375 and d["stream"]["d2h_bytes_per_pair"] == 4 * 1242 * 375
+    assert d["value"] > 0 and d["timed_seconds"] >= 2.0 and d["unit"] == "pairs/s"
+
+
+@pytest.mark.gpu
+def test_hierarchical_batch_larger_than_a_piece(model_factory, oracle, weights_multi):
+    """Hierarchical model at KITTI size, batch > piece: the coarse levels run once per low-resolution piece in chunks of
+    rb * 4^level pairs; 21 pairs with piece 8 leave ragged tails at every level."""
+    import numpy as np
+    from hobot_stereonet_amd import api, synth
+    w, h, d = 1242, 375, 256
+    base = [synth.model_input_i8(w, h, d, 400 + s) for s in range(3)]
+    xs = np.stack([np.roll(base[k % 3], 8 * (k // 3), axis=2) for k in range(21)])
+    with api.StereoNetHIP(model_factory(w, h, d, multi=True), precision=api.PREC_F16, max_batch=21, piece=8) as eng:
+        disp, raw = eng.infer(xs)
+        for k in (0, 7, 8, 15, 20):
+            d1, r1 = eng.infer(xs[k])
+            assert (r1 == raw[k]).all() and (d1 == disp[k]).all(), k
+    odisp = oracle.forward(weights_multi, xs[8], d)[0]
+    assert float(np.abs(disp[8] - odisp).mean()) < 1e-3

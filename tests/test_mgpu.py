@@ -25,6 +25,37 @@ def test_shard_arithmetic_matches_dist():
         api.mgpu_shard(4, 0, 0)
 
 
+def test_ticket_ring_state_machine():
+    """The double buffering of sn_mgpu_submit_device / sn_mgpu_wait: tickets count from 1, ticket t owns slot t % 2 from
+    submit to wait, two may be in flight, waits may come in either order, a submit whose slot is still owned is BUSY, a
+    stale or unknown ticket is refused."""
+    r = api.MgpuRing()
+    t1, s1 = r.submit()
+    t2, s2 = r.submit()
+    assert (t1, t2) == (1, 2) and {s1, s2} == {0, 1}
+    with pytest.raises(api.StereoNetError) as e:
+        r.submit()
+    assert e.value.code == -6                      # SN_ERR_BUSY: both slots in flight
+    assert r.wait(t2) == s2                        # out of order
+    with pytest.raises(api.StereoNetError) as e:
+        r.wait(t2)
+    assert e.value.code == -7                      # SN_ERR_TICKET: consumed
+    with pytest.raises(api.StereoNetError) as e:   # ticket 3 wants ticket 1's slot: waiting for ticket 2 did not free it
+        r.submit()
+    assert e.value.code == -6
+    assert r.wait(t1) == s1
+    t3, s3 = r.submit()
+    t4, s4 = r.submit()
+    assert (t3, s3, t4, s4) == (3, s1, 4, s2)
+    with pytest.raises(api.StereoNetError):
+        r.wait(99)
+    r.wait(t3)
+    for k in range(5, 12):                         # steady state: submit k, then wait for k - 1
+        t, s = r.submit()
+        assert t == k and s == k % 2
+        r.wait(k - 1)
+
+
 def test_create_without_gpu_fails_loudly(tmp_path, weights_blob):
     import torch
     if torch.cuda.is_available():
@@ -61,6 +92,50 @@ def test_one_device_equals_single_gpu_batch(model_factory):
         assert (traw.cpu().numpy() == raw1).all() and (tdisp.cpu().numpy() == disp1).all()
         with pytest.raises(api.StereoNetError):
             m.infer(np.concatenate([xs, xs]))             # n > max_batch
+
+
+@pytest.mark.gpu
+def test_two_shards_on_one_device_through_the_worker_threads(model_factory, monkeypatch):
+    """ndev = 2 with the real engine on a one-GPU box: SN_MGPU_ALLOW_DUP=1 (test switch) lets both shards name device 0, so
+    the per-shard worker threads, the shard arithmetic (ragged: 3 + 2), the status agreement, the peer-copy gather into
+    the root buffers and the double-buffered submit / wait all run with ndev > 1.  Bit-equal to sn_infer_batch."""
+    import torch
+    monkeypatch.setenv("SN_MGPU_ALLOW_DUP", "1")
+    w, h, d = 160, 96, 96
+    n = 5
+    xs = np.stack([synth.model_input_i8(w, h, d, 80 + s) for s in range(n)])
+    ys = np.stack([synth.model_input_i8(w, h, d, 90 + s) for s in range(n)])
+    with api.StereoNetHIP(model_factory(w, h, d), max_batch=n, precision=api.PREC_F16) as eng:
+        disp_x, raw_x = eng.infer(xs)
+        disp_y, raw_y = eng.infer(ys)
+    with api.StereoNetMultiGPU(model_factory(w, h, d), devices=[0, 0], max_batch=n, precision=api.PREC_F16) as m:
+        assert m.ndev == 2 and m.per_device_batch == 3 and m.gather_kind == 1      # duplicates: peer copies, not RCCL
+        disp, raw = m.infer(xs)                                                    # host form
+        assert (raw == raw_x).all() and (disp == disp_x).all()
+        dev = torch.device("cuda", 0)
+        tx, ty = torch.from_numpy(xs).to(dev), torch.from_numpy(ys).to(dev)
+        out = [(torch.empty((n, h, w), dtype=torch.int32, device=dev), torch.empty((n, h, w), dtype=torch.float32, device=dev))
+               for _ in range(2)]
+        ptrs = lambda t: [t[0:3].data_ptr(), t[3:5].data_ptr()]                    # shard 0 = pairs 0..2, shard 1 = pairs 3..4
+        m.infer_device(n, ptrs(tx), out[0][0].data_ptr(), out[0][1].data_ptr())    # synchronous device form
+        assert (out[0][0].cpu().numpy() == raw_x).all() and (out[0][1].cpu().numpy() == disp_x).all()
+        # asynchronous, two batches in flight; a third is refused until one is waited for
+        t1 = m.submit_device(n, ptrs(tx), out[0][0].data_ptr(), out[0][1].data_ptr())
+        t2 = m.submit_device(n, ptrs(ty), out[1][0].data_ptr(), out[1][1].data_ptr())
+        with pytest.raises(api.StereoNetError) as e:
+            m.submit_device(n, ptrs(tx), out[0][0].data_ptr(), out[0][1].data_ptr())
+        assert e.value.code == -6
+        m.wait(t2)
+        m.wait(t1)
+        assert (out[0][0].cpu().numpy() == raw_x).all() and (out[1][0].cpu().numpy() == raw_y).all()
+        assert (out[1][1].cpu().numpy() == disp_y).all()
+        with pytest.raises(api.StereoNetError):
+            m.wait(t1)
+        # a missing shard is an error on every rank, not a hang
+        with pytest.raises(api.StereoNetError):
+            m.infer_device(n, [tx.data_ptr(), 0], out[0][0].data_ptr(), out[0][1].data_ptr())
+        m.infer_device(n, ptrs(ty), out[0][0].data_ptr(), out[0][1].data_ptr())    # and the object still works
+        assert (out[0][0].cpu().numpy() == raw_y).all()
 
 
 @pytest.mark.gpu
