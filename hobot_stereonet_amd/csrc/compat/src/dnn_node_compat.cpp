@@ -176,11 +176,11 @@ int DnnNode::Run(std::vector<std::shared_ptr<DNNTensor>>& inputs, const std::sha
   out->output_tensors.push_back(ot);
   const int8_t* in = static_cast<const int8_t*>(inputs[0]->sysMem[0].virAddr);
   int32_t* raw = static_cast<int32_t*>(ot->sysMem[0].virAddr);
-  {
-    std::lock_guard<std::mutex> lk(mu_);
-    ++in_count_;
-  }
   if (is_sync_mode) {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      ++in_count_;
+    }
     const double t0 = now_s();
     if (sn_infer_i8(engine_, in, raw, nullptr, SN_MEM_HOST, nullptr) != SN_OK) {
       RCLCPP_ERROR(rclcpp::get_logger("dnn"), "infer failed: %s", sn_last_error(engine_));
@@ -200,6 +200,7 @@ int DnnNode::Run(std::vector<std::shared_ptr<DNNTensor>>& inputs, const std::sha
   }
   {
     std::lock_guard<std::mutex> lk(mu_);
+    ++in_count_;                       // only requests the engine accepted count as input frames
     pending_.push_back(Pending{ticket, out, ot});
   }
   cv_.notify_all();
@@ -215,11 +216,11 @@ int DnnNode::RunSbsNv12(const uint8_t* sbs, int width2, int height, const std::s
   out->output_tensors.clear();
   out->output_tensors.push_back(ot);
   int32_t* raw = static_cast<int32_t*>(ot->sysMem[0].virAddr);
-  {
-    std::lock_guard<std::mutex> lk(mu_);
-    ++in_count_;
-  }
   if (is_sync_mode) {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      ++in_count_;
+    }
     const double t0 = now_s();
     if (sn_infer_sbs_nv12(engine_, sbs, width2, height, raw, nullptr, nullptr, SN_MEM_HOST, nullptr) != SN_OK) {
       RCLCPP_ERROR(rclcpp::get_logger("dnn"), "infer failed: %s", sn_last_error(engine_));
@@ -239,6 +240,7 @@ int DnnNode::RunSbsNv12(const uint8_t* sbs, int width2, int height, const std::s
   }
   {
     std::lock_guard<std::mutex> lk(mu_);
+    ++in_count_;                       // only requests the engine accepted count as input frames
     pending_.push_back(Pending{ticket, out, ot});
   }
   cv_.notify_all();

@@ -128,7 +128,10 @@ void StereonetNode::OnStereoFrame(const hbm_img_msgs::msg::HbmMsg1080P::ConstSha
   const auto t_pre = std::chrono::steady_clock::now();
   // STEREONET_INGEST=tensor keeps the reference's host steps (split both eyes, CvtNV12Data2Tensors, Run on the int8
   // tensor); the default hands the message payload to the backend, which does the same byte mapping on the GPU
-  static const bool host_tensor = getenv("STEREONET_INGEST") != nullptr && !strcmp(getenv("STEREONET_INGEST"), "tensor");
+  // The device ingest reads the frame in 8-byte units (sn_submit_nv12: the side-by-side width must be a multiple of 8,
+  // the height even); any other even geometry the reference accepts goes through the host steps, as it does there.
+  static const bool want_tensor = getenv("STEREONET_INGEST") != nullptr && !strcmp(getenv("STEREONET_INGEST"), "tensor");
+  const bool host_tensor = want_tensor || ((2 * net_w_) & 7) != 0 || (net_h_ & 1) != 0;
   // de-interleave the eyes: every source row carries w bytes of the left eye, then w bytes of the right eye
   const unsigned char* row = frame->data.data();
   if (host_tensor || cfg_.publish_output) {

@@ -123,7 +123,7 @@ struct Slot {                // async request slot (sn_submit / sn_wait)
 struct sn_handle {
   int device = 0;
   int W = 0, H = 0, D = 0, Wp = 0, Hp = 0, wl = 0, hl = 0, Dl = 0;
-  int max_batch = 1, precision = 0, task_num = 4, refine_chunk = 1, piece = 8;
+  int max_batch = 1, precision = SN_PREC_F16, task_num = 4, refine_chunk = 1, piece = 16;
   hipStream_t stream = nullptr;
   // piece pipeline: the low-resolution branch of piece k+1 runs on s_low while the refinement towers of piece k run
   // on s_tow[]; consecutive tower chunks alternate between the tower streams so that the ramp-up / tail of one
@@ -769,14 +769,25 @@ hipError_t ref_block_f16(hipStream_t st, const RefLayerF16& L1, const RefLayerF1
 }
 
 // ---- workspace -----------------------------------------------------------------------------------
+// Pairs per low-resolution piece and per tower launch of level k for a workspace of nb pairs with rb pairs per
+// full-resolution launch: ONE definition shared by alloc_ws (buffer sizes) and sn_create's 32-bit offset guard.
+inline int piece_pairs(const sn_handle* h, int nb, int rb) {
+  int pb = h->piece > 0 ? h->piece : 16;
+  if (pb > nb) pb = nb;
+  if (pb < rb) pb = rb;
+  return pb;
+}
+inline int level_chunk_pairs(int rb, int pb, int lv) {     // coarse level lv runs rb * 4^lv pairs per launch, at most a piece
+  const long r = (long)rb << (2 * lv);
+  return lv == 0 ? rb : (r < pb ? (int)r : pb);
+}
+
 int alloc_ws(sn_handle* h, Workspace* ws, int nb, int rb, int ns) {
   ws->nb = nb;
   ws->rb = rb;
   ws->ns = (ns > 1 && nb > rb) ? (ns < kMaxTowerStreams ? ns : kMaxTowerStreams) : 1;
   if (h->levels > 1) ws->ns = 1;      // the level maps of a piece live in one buffer set: one tower stream
-  ws->pb = h->piece > 0 ? h->piece : 16;
-  if (ws->pb > nb) ws->pb = nb;
-  if (ws->pb < rb) ws->pb = rb;
+  ws->pb = piece_pairs(h, nb, rb);
   const int pb = ws->pb;
   const size_t HW = (size_t)h->H * h->W, HWp = (size_t)h->Hp * h->Wp, hw = (size_t)h->hl * h->wl;
   HIP_TRY(h, dalloc(&ws->in6, (size_t)nb * 6 * HW));
@@ -801,8 +812,7 @@ int alloc_ws(sn_handle* h, Workspace* ws, int nb, int rb, int ns) {
     // a hierarchical model adds the coarse-level launches of every piece: one block per (piece, level, coarse chunk)
     ws->n_chunks = (nb + rb - 1) / rb + (nb + pb - 1) / pb + 2;
     for (int lv = 1; lv < h->levels; ++lv) {
-      long r = (long)rb << (2 * lv);
-      const int rbk = r < pb ? (int)r : pb;
+      const int rbk = level_chunk_pairs(rb, pb, lv);
       ws->n_chunks += ((nb + pb - 1) / pb + 2) * ((pb + rbk - 1) / rbk + 1);
     }
     HIP_TRY(h, hipExtMallocWithFlags(reinterpret_cast<void**>(&ws->tile_ctr), kTileCtrBytes * ws->n_chunks, hipDeviceMallocFinegrained));
@@ -811,8 +821,7 @@ int alloc_ws(sn_handle* h, Workspace* ws, int nb, int rb, int ns) {
   for (int lv = 1; lv < h->levels; ++lv) {
     const Tower& T = h->tw[lv];
     const size_t HWk = (size_t)T.Hk * T.Wk;
-    long r = (long)rb << (2 * lv);
-    ws->rbk[lv] = r < pb ? (int)r : pb;
+    ws->rbk[lv] = level_chunk_pairs(rb, pb, lv);
     for (int k = 0; k < 2; ++k) {
       if (h->precision == SN_PREC_FP32) {
         HIP_TRY(h, dalloc(&ws->ref_lv[lv][k], (size_t)ws->rbk[lv] * kC * HWk));
@@ -1376,9 +1385,18 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
 
   // the kernels use 32-bit element / byte offsets inside one tensor: keep every tensor below 2^32
   {
-    const double low_elems = 2.0 * (h->piece < h->max_batch ? h->piece : h->max_batch) * kC * (h->Hp / 2.0) * (h->Wp / 2.0);
-    const double ref_bytes = (double)h->refine_chunk * 4.0 * h->tw[0].rg.Hs * h->tw[0].rg.Ws * 16.0;
-    const double vol_elems = (double)(h->piece < h->max_batch ? h->piece : h->max_batch) * h->Dl * kC * h->hl * h->wl;
+    // with the piece / chunk sizes alloc_ws will really use (a piece is never smaller than a chunk), and for the
+    // activation tensor of EVERY refinement level (a coarse level holds up to rb * 4^k pairs of a relatively more
+    // padded plane)
+    const int pb = piece_pairs(h, h->max_batch, h->refine_chunk);
+    const double low_elems = 2.0 * pb * kC * (h->Hp / 2.0) * (h->Wp / 2.0);
+    const double vol_elems = (double)pb * h->Dl * kC * h->hl * h->wl;
+    double ref_bytes = 0;
+    for (int lv = 0; lv < h->levels; ++lv) {
+      const RefGeom& rg = h->tw[lv].rg;
+      const double b = ((double)level_chunk_pairs(h->refine_chunk, pb, lv) * 4.0 * rg.Hs * rg.Ws + (double)ref_slack(rg)) * 16.0;
+      if (b > ref_bytes) ref_bytes = b;
+    }
     if (low_elems >= 4.0e9 || ref_bytes >= 4.0e9 || vol_elems >= 4.0e9) {
       delete h;
       return SN_ERR_ARG;
@@ -1558,6 +1576,8 @@ int sn_get_io_info(const sn_handle* h, sn_io_info* info) {
   info->tower_streams = h->ws.ns;
   return SN_OK;
 }
+
+int sn_abi_version(void) { return SN_ABI_VERSION; }
 
 int sn_infer_batch(sn_handle* h, int n, const int8_t* in, int32_t* out_i32, float* out_disp, int mem,
                    void* stream) {

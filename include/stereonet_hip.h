@@ -45,6 +45,12 @@ extern "C" {
 
 typedef struct sn_handle sn_handle;
 
+/* Version of this binary interface.  2 = the SN_PREC_* numbering below (0 means "default" = SN_PREC_F16 and exact fp32 is
+ * 3); version 1 (round 1) had 0 = exact fp32.  A caller built against an older header compares SN_ABI_VERSION with
+ * sn_abi_version() at start-up instead of silently running in another arithmetic. */
+#define SN_ABI_VERSION 2
+int sn_abi_version(void);
+
 enum {
   SN_OK = 0,
   SN_ERR_ARG = -1,       /* null / out-of-range argument, geometry mismatch          */

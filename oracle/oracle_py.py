@@ -12,7 +12,8 @@ import subprocess
 import numpy as np
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_DIR, "libstereonet_oracle.so")
+_SAN = os.environ.get("SN_SANITIZE") == "1"      # scripts/run_sanitized.sh: the ASan + UBSan build of the checker
+_LIB = os.path.join(_DIR, "libstereonet_oracle_asan.so" if _SAN else "libstereonet_oracle.so")
 _lib = None
 
 
@@ -20,7 +21,7 @@ def build(force: bool = False) -> str:
     src = [os.path.join(_DIR, f) for f in ("stereonet_oracle.c", "stereonet_oracle.h")]
     stale = (not os.path.exists(_LIB)) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in src)
     if force or stale:
-        subprocess.check_call(["make", "-C", _DIR, "-s", "-B", "libstereonet_oracle.so"])
+        subprocess.check_call(["make", "-C", _DIR, "-s", "-B", os.path.basename(_LIB)])
     return _LIB
 
 

@@ -20,9 +20,10 @@ FILELIST_BIN = os.path.join(COMPAT, "build", "stereonet_filelist")
 def hostlib():
     from hobot_stereonet_amd import build
     build.build()
-    subprocess.check_call(["make", "-C", COMPAT, "-s"])
+    san = os.environ.get("SN_SANITIZE") == "1"       # scripts/run_sanitized.sh: the ASan + UBSan build of the mirror
+    subprocess.check_call(["make", "-C", COMPAT, "-s"] + (["asan"] if san else []))
     import torch  # noqa: F401  (before anything that links HIP: one HIP runtime per process, see api.load_library)
-    lib = C.CDLL(os.path.join(COMPAT, "build", "libhobot_stereonet_node.so"))
+    lib = C.CDLL(os.path.join(COMPAT, "build", "asan" if san else "", "libhobot_stereonet_node.so"))
     vp, ci = C.c_void_p, C.c_int
     lib.snhost_bgr_to_nv12.argtypes = [vp, ci, ci, vp]
     lib.snhost_read_image_bgr.argtypes = [C.c_char_p, C.POINTER(ci), C.POINTER(ci), vp, C.c_long]

@@ -18,9 +18,10 @@ COMPAT = os.path.join(ROOT, "hobot_stereonet_amd", "csrc", "compat")
 def hostlib():
     from hobot_stereonet_amd import build
     build.build()
-    subprocess.check_call(["make", "-C", COMPAT, "-s"])
+    san = os.environ.get("SN_SANITIZE") == "1"       # scripts/run_sanitized.sh: the ASan + UBSan build of the mirror
+    subprocess.check_call(["make", "-C", COMPAT, "-s"] + (["asan"] if san else []))
     import torch  # noqa: F401  (before anything that links HIP: one HIP runtime per process, see api.load_library)
-    lib = C.CDLL(os.path.join(COMPAT, "build", "libhobot_stereonet_node.so"))
+    lib = C.CDLL(os.path.join(COMPAT, "build", "asan" if san else "", "libhobot_stereonet_node.so"))
     vp, ci = C.c_void_p, C.c_int
     lib.snhost_yuv420_to_yuv444.argtypes = [vp, vp, ci, ci]
     lib.snhost_quantize_byte.argtypes = [ci]
