@@ -19,7 +19,7 @@ from . import build as _build
 
 SN_MEM_HOST, SN_MEM_DEVICE = 0, 1
 PREC_DEFAULT, PREC_F16X3, PREC_F16, PREC_FP32 = 0, 1, 2, 3      # include/stereonet_hip.h; 0 selects PREC_F16
-STAGES = ("features", "aggregate", "refine", "refine_conv", "total")
+STAGES = ("features", "aggregate", "refine", "refine_conv", "total", "dominant")
 
 
 class SnConfig(C.Structure):

@@ -153,6 +153,8 @@ struct sn_handle {
   // profiling
   bool profiling = false;
   hipEvent_t ev[8] = {};
+  hipEvent_t ev_dom[2 * 6] = {};   // profiling: one pair around every streamed block of the first chunk (the dominant kernel)
+  int dom_pairs = 0;
   float stage_ms[SN_STAGE_COUNT] = {};
   mutable std::string err;
 };
@@ -1014,6 +1016,7 @@ int refine_level(sn_handle* h, Workspace& ws, hipStream_t st, const Tower& T, fl
     // reads fp16 and finishes in fp32
     uint4* x16 = rx16;
     uint4* t16 = rt16;
+    if (pe) h->dom_pairs = 0;
     // Consecutive launches of a tower walk their tiles in OPPOSITE directions (g.rev): a launch then starts on the part
     // of the tensor its predecessor wrote LAST — what a cache that is slightly too small for the chunk still holds —
     // instead of on the lines an LRU policy has just evicted.
@@ -1049,8 +1052,11 @@ int refine_level(sn_handle* h, Workspace& ws, hipStream_t st, const Tower& T, fl
         HIP_TRY(h, launch_ref_conv_head_f16(st, T.rres16[i][1], g, ncu, t16, x16, c, ctr + kTileCtrStride, T.rout.w,
                                             T.rout.bias, src, sh, sw, H, W, dnorm, inv_q, ups, od, orw, h->dump));
       } else {
+        const bool dom = pe && h->fuse_mode == 4 && stream_block_supports(kRefDil[i]) && h->dom_pairs < 6;
+        if (dom) HIP_TRY(h, hipEventRecord(h->ev_dom[2 * h->dom_pairs], st));
         HIP_TRY(h, ref_block_f16(st, T.rres16[i][0], T.rres16[i][1], g, ncu, kRefDil[i], &x16, &t16, c,
                                  chunk_ctr + 2 * i * kTileCtrStride, h->fuse_mode, h->dump, rev_env != 0));
+        if (dom) HIP_TRY(h, hipEventRecord(h->ev_dom[2 * h->dom_pairs++ + 1], st));
       }
     }
     if (!head_fused) {
@@ -1228,6 +1234,17 @@ int collect_profile(sn_handle* h) {
   h->stage_ms[SN_STAGE_REFINE_CONV] = ms;    // first refinement chunk only
   HIP_TRY(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[3]));
   h->stage_ms[SN_STAGE_TOTAL] = ms;
+  // the dominant kernel's launches of the first chunk: the streamed blocks one by one, else the tower span
+  if (h->dom_pairs > 0) {
+    float sum = 0.f;
+    for (int i = 0; i < h->dom_pairs; ++i) {
+      HIP_TRY(h, hipEventElapsedTime(&ms, h->ev_dom[2 * i], h->ev_dom[2 * i + 1]));
+      sum += ms;
+    }
+    h->stage_ms[SN_STAGE_DOMINANT] = sum;
+  } else {
+    h->stage_ms[SN_STAGE_DOMINANT] = h->stage_ms[SN_STAGE_REFINE_CONV];
+  }
   return SN_OK;
 }
 
@@ -1412,6 +1429,8 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(SN_ERR_DEVICE);
   for (auto& e : h->ev)
     if (hipEventCreate(&e) != hipSuccess) return fail(SN_ERR_DEVICE);
+  for (auto& e : h->ev_dom)
+    if (hipEventCreate(&e) != hipSuccess) return fail(SN_ERR_DEVICE);
   // (Disjoint CU sets for the pipeline streams through hipExtStreamCreateWithCUMask were measured and dropped:
   // 1940 pairs/s shared vs 1700 / 1680 / 1510 with 64 / 96 / 128 CUs split off for the low-resolution branch.)
   if (hipStreamCreateWithFlags(&h->s_low, hipStreamNonBlocking) != hipSuccess ||
@@ -1533,6 +1552,8 @@ int sn_destroy(sn_handle* h) {
     if (s.stream) hipStreamDestroy(s.stream);
   }
   for (auto& e : h->ev)
+    if (e) hipEventDestroy(e);
+  for (auto& e : h->ev_dom)
     if (e) hipEventDestroy(e);
   for (auto& e : h->ev_piece)
     if (e) hipEventDestroy(e);
@@ -1908,14 +1929,28 @@ int sn_get_stage_ms(sn_handle* h, float* ms, int count) {
 int sn_get_dominant_kernel(sn_handle* h, char* name, size_t cap, int* launches, double* flops, double* bytes) {
   if (!h) return SN_ERR_ARG;
   const bool f16 = h->precision == SN_PREC_F16;
+  const double px = (double)h->Hp * h->Wp * h->ws.rb;
+  if (f16 && h->fuse_mode == 4) {
+    // the row-streaming fused residual block: SN_STAGE_DOMINANT times its launches of the first chunk one by one
+    int n = 0;
+    for (int i = 0; i < kNRefRes; ++i) {
+      const bool last = i == kNRefRes - 1;
+      if (stream_block_supports(kRefDil[i]) && (!last || h->stream_last || !h->head_fuse)) ++n;
+    }
+    if (name && cap)
+      snprintf(name, cap, "%s", "k_ref_block_stream_f16<DIL> (fused residual block: two 3x3 C->C convs + residual, fp16 MFMA 32x32x16)");
+    if (launches) *launches = n;
+    if (flops) *flops = 2.0 * (2.0 * px * kC * kC * 9);           // two convolutions per launch
+    if (bytes) *bytes = px * kC * 2.0 * 2.0;                       // x read once + y written once; t never leaves LDS
+    return SN_OK;
+  }
   if (name && cap)
     snprintf(name, cap, "%s",
              h->precision == SN_PREC_F16     ? "k_ref_conv_f16<DIL> (refinement 3x3 C->C, fp16 MFMA 32x32x16)"
              : h->precision == SN_PREC_F16X3 ? "k_ref_conv_f16x3<DIL> (refinement 3x3 C->C, 3x fp16 MFMA on hi/lo split operands)"
                                              : "k_conv_c32_mfma<3,1,*> (refinement 3x3 C->C, fp32 MFMA 32x32x2)");
-  const double px = (double)h->Hp * h->Wp * h->ws.rb;
   // fp16 mode with the fused last layer: the timed span holds the 11 plain tower launches (6 without, 5 with residual)
-  const bool hf = f16 && h->head_fuse && !(h->fuse_mode == 3) && !(h->fuse_mode == 4 && h->stream_last);
+  const bool hf = f16 && h->head_fuse && !(h->fuse_mode == 3);
   const int n_plain = kNRefRes, n_res = hf ? kNRefRes - 1 : kNRefRes;
   if (launches) *launches = n_plain + n_res;   // per refinement chunk
   if (flops) *flops = 2.0 * px * kC * kC * 9;

@@ -193,9 +193,11 @@ enum {
   SN_STAGE_FEATURES = 0,   /* Siamese tower, both eyes            */
   SN_STAGE_AGGREGATE = 1,  /* cost volume + 3-D convs + soft-argmin */
   SN_STAGE_REFINE = 2,     /* upsample + refinement tower + output epilogue */
-  SN_STAGE_REFINE_CONV = 3,/* the 12 C->C 3x3 convs inside REFINE (dominant kernel) */
+  SN_STAGE_REFINE_CONV = 3,/* the span of the 12 C->C 3x3 convs inside REFINE (first chunk) */
   SN_STAGE_TOTAL = 4,
-  SN_STAGE_COUNT = 5
+  SN_STAGE_DOMINANT = 5,   /* the launches sn_get_dominant_kernel describes, first refinement chunk, timed one by one
+                            * (the streamed residual blocks); equals REFINE_CONV when the tower runs layer by layer */
+  SN_STAGE_COUNT = 6
 };
 int sn_set_profiling(sn_handle *h, int enable);
 int sn_get_stage_ms(sn_handle *h, float *ms, int count);
