@@ -265,14 +265,16 @@ __global__ __launch_bounds__(128 * NWR, NWR / 2) __attribute__((amdgpu_waves_per
       const int c = rem - blk * T::XW;
       dma_voff[k] = (unsigned)blk * plane_b + ((unsigned)(r * DIL) * (unsigned)g.Ws + (unsigned)c) * 16u;
     }
-    unsigned last_base = 0;
+    // signed: the group of a strip's first slot starts up to 2 DIL image rows above row 0 and 2 DIL columns left of column
+    // 0 — inside the tensor's zero border for dilation 1 / 2, in the zero slots IN FRONT of the tensor for dilation 4 / 8
+    // (ref_front() in the host code) when it is image 0, channel block 0
+    long last_base = 0;
     auto dma_issue = [&](const StreamIter<R>& it, int grp) {
       if (it.live) {
         int img, py, x0;
         decode_sp(it.sp, img, py, x0);
-        const int row = (it.v0 - R + R * it.j) * DIL + py;               // image row of the group's first row (>= -kRefPad)
-        last_base = (((unsigned)img * 4u * (unsigned)g.Hs + (unsigned)(row + kRefPad)) * (unsigned)g.Ws +
-                     (unsigned)(x0 - 2 * DIL + kRefPad)) * 16u;
+        const int row = (it.v0 - R + R * it.j) * DIL + py;               // image row of the group's first row (>= -2 DIL)
+        last_base = (((long)img * 4 * g.Hs + (row + kRefPad)) * (long)g.Ws + (x0 - 2 * DIL + kRefPad)) * 16;
       }
       const char* src = reinterpret_cast<const char*>(xin) + last_base;
       const unsigned dst = lds_addr(xring + grp * T::XGP);

@@ -77,12 +77,14 @@ struct Workspace {          // activations for up to `nb` pairs
   int ns = 1;                 // tower streams this workspace serves: one (x, t) activation pair per stream
   float* ref[2 * kMaxTowerStreams] = {};
   uint4* ref16[2 * kMaxTowerStreams] = {};   // fp16 NCHW8c padded (fp16 modes): [2 * stream + {x, t}]
+  uint4* ref16_raw[2 * kMaxTowerStreams] = {};            // the allocations behind them (alloc_ref16)
   // hierarchical refinement, levels 1..: the coarse levels run once per low-resolution PIECE (pb pairs), in chunks
   // of rbk[level] = min(pb, rb * 4^level) pairs (the same activation footprint per launch as level 0).  Activation
   // pairs (their own zero borders) for rbk pairs; image pyramid [pb][3][Hk][Wk] and level maps [pb][Hk][Wk].
   int rbk[kMaxLevels] = {};
   float* ref_lv[kMaxLevels][2] = {};
   uint4* ref16_lv[kMaxLevels][2] = {};
+  uint4* ref16_lv_raw[kMaxLevels][2] = {};
   float* pyr[kMaxLevels] = {};
   float* lvl_disp[kMaxLevels] = {};
   int n_chunks = 0;
@@ -500,8 +502,20 @@ size_t ref16_slots(const RefGeom& g, int nimg) { return (size_t)nimg * 4 * g.Hs 
 // groups past the last padded row of the last image (tile-fused kernel: < 4096 slots; streaming kernel: up to
 // (R + 2) * DIL + DIL - 1 rows of Ws slots below the image, of which 8 are the tensor's own border).
 size_t ref_slack(const RefGeom& g) {
-  const size_t rows = (size_t)16 * g.Ws;
+  const size_t rows = (size_t)24 * g.Ws;
   return rows > 4096 ? rows : 4096;
+}
+// Slots IN FRONT of a tensor (zero, never written): the streaming blocks of dilation 4 / 8 pre-load the two sub-rows above
+// a strip's first row, up to 2 * DIL = 16 image rows above row 0 where the tensor's own border is 8 rows.  An fp16
+// activation tensor is allocated as [front | tensor | slack] and handed around by the address of `tensor`.
+size_t ref_front(const RefGeom& g) { return (size_t)16 * g.Ws; }
+hipError_t alloc_ref16(const RefGeom& g, size_t tensor_and_slack_slots, uint4** raw, uint4** base) {
+  const size_t front = ref_front(g), all = front + tensor_and_slack_slots;
+  hipError_t e = dalloc(raw, all);
+  if (e != hipSuccess) return e;
+  e = hipMemset(*raw, 0, all * sizeof(uint4));        // the zero borders are never written again
+  *base = *raw + front;
+  return e;
 }
 
 // [co][ci][ky][kx] fp32 -> wfrag[tap][kk][lane][e] fp16 = w[co = lane&31][ci = 16kk + 8(lane>>5) + e][tap]
@@ -626,11 +640,11 @@ hipError_t launch_ref_block_f16_h(hipStream_t st, const RefLayerF16& L1, const R
 
 // Fused residual block, row-streaming form (sn_stream_block.hpp): one 512-thread workgroup per CU walks its share of
 // the flattened (image, row phase, strip, sub-row) sequence.  x and y must be different tensors.  dump: >= 1 KB scratch.
-template <int DIL>
+template <int DIL, int TW, int R>
 hipError_t launch_ref_block_stream(hipStream_t st, const RefLayerF16& L1, const RefLayerF16& L2, const RefGeom& g, int num_cu,
                                    const uint4* x, uint4* y, int nimg, unsigned* dump) {
-  using T = StreamTile<DIL, 64, 4, 6, 4>;
-  auto kern = k_ref_block_stream_f16<DIL, 64, 4, 6, 4>;
+  using T = StreamTile<DIL, TW, R, 6, 4>;
+  auto kern = k_ref_block_stream_f16<DIL, TW, R, 6, 4>;
   if (dump == nullptr) return hipErrorInvalidValue;
   hipError_t e = ensure_lds_attr(kern, T::LDS_BYTES);
   if (e != hipSuccess) return e;
@@ -648,15 +662,23 @@ hipError_t launch_ref_block_stream(hipStream_t st, const RefLayerF16& L1, const 
   return hipGetLastError();
 }
 
+// Strip shapes: 64 columns x 4 rows per step for dilation 1 / 2 (62 / 60 of 64 columns are outputs); 128 columns x 2 rows
+// for dilation 4 / 8, where a 64-wide strip would keep only 56 / 48 of its columns (120 / 112 of 128 here).
 hipError_t ref_block_stream(hipStream_t st, const RefLayerF16& L1, const RefLayerF16& L2, const RefGeom& g, int num_cu, int dil,
                             const uint4* x, uint4* y, int nimg, unsigned* dump) {
   switch (dil) {
-    case 1: return launch_ref_block_stream<1>(st, L1, L2, g, num_cu, x, y, nimg, dump);
-    case 2: return launch_ref_block_stream<2>(st, L1, L2, g, num_cu, x, y, nimg, dump);
+    case 1: return launch_ref_block_stream<1, 64, 4>(st, L1, L2, g, num_cu, x, y, nimg, dump);
+    case 2: return launch_ref_block_stream<2, 64, 4>(st, L1, L2, g, num_cu, x, y, nimg, dump);
+    case 4: return launch_ref_block_stream<4, 128, 2>(st, L1, L2, g, num_cu, x, y, nimg, dump);
+    case 8: return launch_ref_block_stream<8, 128, 2>(st, L1, L2, g, num_cu, x, y, nimg, dump);
     default: return hipErrorInvalidValue;
   }
 }
-inline bool stream_block_supports(int dil) { return dil == 1 || dil == 2; }
+// SN_STREAM_DIL: largest dilation that runs through the streaming kernel (default 8 = every block; 2 = round-3a behaviour)
+inline bool stream_block_supports(int dil) {
+  static const int max_dil = getenv("SN_STREAM_DIL") ? atoi(getenv("SN_STREAM_DIL")) : 8;
+  return (dil == 1 || dil == 2 || dil == 4 || dil == 8) && dil <= max_dil;
+}
 
 hipError_t launch_head_final_f16(hipStream_t st, bool split, const uint4* x, size_t lo_slots, const RefGeom& g,
                                  const float* w, float bias, const float* disp_low, int hl, int wl, int H, int W, float dmax,
@@ -805,8 +827,7 @@ int alloc_ws(sn_handle* h, Workspace* ws, int nb, int rb, int ns) {
   } else {
     for (int k = 0; k < 2 * ws->ns; ++k) {
       const size_t slots = (ref16_slots(h->tw[0].rg, rb) + ref_slack(h->tw[0].rg)) * (h->precision == SN_PREC_F16X3 ? 2 : 1);
-      HIP_TRY(h, dalloc(&ws->ref16[k], slots));
-      HIP_TRY(h, hipMemset(ws->ref16[k], 0, slots * sizeof(uint4)));   // the zero border is never written again
+      HIP_TRY(h, alloc_ref16(h->tw[0].rg, slots, &ws->ref16_raw[k], &ws->ref16[k]));
     }
     // fine-grained: the queue words must be coherent across the 8 XCD L2s at device scope and with the memset
     // one counter block per tower chunk of a forward(): chunks never straddle a low-resolution piece, so every
@@ -829,8 +850,7 @@ int alloc_ws(sn_handle* h, Workspace* ws, int nb, int rb, int ns) {
         HIP_TRY(h, dalloc(&ws->ref_lv[lv][k], (size_t)ws->rbk[lv] * kC * HWk));
       } else {
         const size_t slots = (ref16_slots(T.rg, ws->rbk[lv]) + ref_slack(T.rg)) * (h->precision == SN_PREC_F16X3 ? 2 : 1);
-        HIP_TRY(h, dalloc(&ws->ref16_lv[lv][k], slots));
-        HIP_TRY(h, hipMemset(ws->ref16_lv[lv][k], 0, slots * sizeof(uint4)));
+        HIP_TRY(h, alloc_ref16(T.rg, slots, &ws->ref16_lv_raw[lv][k], &ws->ref16_lv[lv][k]));
       }
     }
     HIP_TRY(h, dalloc(&ws->pyr[lv], (size_t)pb * 3 * HWk));
@@ -852,10 +872,10 @@ void free_ws(Workspace* ws) {
   hipFree(ws->cost);
   hipFree(ws->disp_low);
   for (auto p : ws->ref) hipFree(p);
-  for (auto p : ws->ref16) hipFree(p);
+  for (auto p : ws->ref16_raw) hipFree(p);
   for (auto& lv : ws->ref_lv)
     for (auto p : lv) hipFree(p);
-  for (auto& lv : ws->ref16_lv)
+  for (auto& lv : ws->ref16_lv_raw)
     for (auto p : lv) hipFree(p);
   for (auto p : ws->pyr) hipFree(p);
   for (auto p : ws->lvl_disp) hipFree(p);
@@ -1411,7 +1431,7 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
     double ref_bytes = 0;
     for (int lv = 0; lv < h->levels; ++lv) {
       const RefGeom& rg = h->tw[lv].rg;
-      const double b = ((double)level_chunk_pairs(h->refine_chunk, pb, lv) * 4.0 * rg.Hs * rg.Ws + (double)ref_slack(rg)) * 16.0;
+      const double b = ((double)level_chunk_pairs(h->refine_chunk, pb, lv) * 4.0 * rg.Hs * rg.Ws + (double)ref_slack(rg) + (double)ref_front(rg)) * 16.0;
       if (b > ref_bytes) ref_bytes = b;
     }
     if (low_elems >= 4.0e9 || ref_bytes >= 4.0e9 || vol_elems >= 4.0e9) {
@@ -2327,11 +2347,9 @@ int sn_dbg_ref_block_f16(sn_handle* h, const float* in, int h_px, int w, const f
   RefLayerF16 L1, L2;
   if ((rc = upload_ref_f16(h, HostLayer{w1, b1, kC, kC, 9}, &L1))) return rc;
   if ((rc = upload_ref_f16(h, HostLayer{w2, b2, kC, kC, 9}, &L2))) return rc;
-  uint4 *da = nullptr, *db = nullptr;
-  HIP_TRY(h, dalloc(&da, slots + ref_slack(g)));
-  HIP_TRY(h, dalloc(&db, slots + ref_slack(g)));
-  HIP_TRY(h, hipMemset(da, 0, (slots + ref_slack(g)) * 16));
-  HIP_TRY(h, hipMemset(db, 0, (slots + ref_slack(g)) * 16));
+  uint4 *da = nullptr, *db = nullptr, *da_raw = nullptr, *db_raw = nullptr;
+  HIP_TRY(h, alloc_ref16(g, slots + ref_slack(g), &da_raw, &da));
+  HIP_TRY(h, alloc_ref16(g, slots + ref_slack(g), &db_raw, &db));
   HIP_TRY(h, hipMemcpy(da, hin.data(), slots * 16, hipMemcpyHostToDevice));
   uint4 *cur = da, *oth = db;
   if (!h->ws.tile_ctr) {
@@ -2358,8 +2376,8 @@ int sn_dbg_ref_block_f16(sn_handle* h, const float* in, int h_px, int w, const f
             return SN_ERR_DEVICE;
           }
       }
-  hipFree(da);
-  hipFree(db);
+  hipFree(da_raw);
+  hipFree(db_raw);
   hipFree(L1.wfrag);
   hipFree(L1.bias);
   hipFree(L2.wfrag);

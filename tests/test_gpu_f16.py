@@ -121,7 +121,8 @@ def test_ragged_chunks_get_their_own_tile_queue(model_factory, rc, piece, n):
 
 @pytest.mark.parametrize("fused", [0, 1, 2])
 @pytest.mark.parametrize("h,w,dil", [(8, 62, 1), (64, 96, 1), (45, 80, 1), (100, 129, 1), (37, 250, 1), (720, 1280, 1),
-                                     (40, 70, 2), (45, 131, 2), (375, 1242, 2)])
+                                     (40, 70, 2), (45, 131, 2), (375, 1242, 2), (50, 140, 4), (375, 1242, 4), (37, 260, 8),
+                                     (720, 1280, 8)])
 def test_residual_block_f16(eng16, oracle, h, w, dil, fused):
     """y = lrelu(x + conv2(lrelu(conv1(x)+b1)) + b2).  fused = 0: two launches; 1: the tile-fused kernel of round 2 (dilation 1
     only, opt-in SN_FUSE=3 in the pipeline, t never leaves LDS); 2: the row-streaming fused kernel (the pipeline's default for
