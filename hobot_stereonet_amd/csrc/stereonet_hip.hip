@@ -134,7 +134,7 @@ struct sn_handle {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_tow_join[kMaxTowerStreams] = {}, ev_piece[kMaxPieceEvents] = {};
   bool overlap = true;
   int tower_streams = kMaxTowerStreams;
-  bool stream_last = false;  // SN_STREAM_LAST=1: the last block streamed too + separate head launch (default: conv + fused conv/head)
+  bool stream_last = true;   // the last block streamed too + separate head launch (SN_STREAM_LAST=0: conv + fused conv/head)
   int fuse_mode = 4;         // SN_FUSE: 4 = streaming fused blocks (default), 3 = tile-fused dilation-1 blocks, 0 = two launches per block
   bool head_fuse = true;     // last tower conv + head in one kernel (fp16 mode; SN_HEAD_FUSE=0 separates them)
   unsigned* dump = nullptr;  // 2 KB device scratch: where lanes without an output pixel store (fused head)
@@ -1415,6 +1415,14 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
     // streams (SN_TOWER_STREAMS=2), with fewer and fuller launches.
     const double tensor_mb = 4.0 * h->tw[0].rg.Hs * h->tw[0].rg.Ws * 16.0 / 1048576.0 * (c.precision == SN_PREC_F16X3 ? 2.0 : c.precision == SN_PREC_FP32 ? 2.0 : 1.0);
     int rc_auto = (int)(256.0 / (2.0 * tensor_mb * h->tower_streams) + 0.5);
+    // With every residual block streamed (fp16 mode, SN_FUSE=4) a launch reads x and writes y ONCE while it does two
+    // convolutions: ~2.8 TB/s at the rate the matrix pipes allow, which HBM sustains — the chunk no longer has to live in
+    // the Infinity Cache, and fuller launches amortise the restart rows and the launch itself: ~3.7 Mpx per launch
+    // (1280x720: 4 pairs, 2583 -> 2653 pairs/s; 8 pairs measured equal).
+    if (h->precision == SN_PREC_F16 && fuse_env() == 4 && stream_block_supports(8)) {
+      const int by_px = (int)(3.7e6 / ((double)h->Hp * h->Wp) + 0.5);
+      if (by_px > rc_auto) rc_auto = by_px;
+    }
     h->refine_chunk = rc_auto < 1 ? 1 : (rc_auto > 8 ? 8 : rc_auto);
   }
   h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -1466,7 +1474,8 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
   h->overlap = getenv("SN_NO_OVERLAP") == nullptr;
   h->use_graphs = getenv("SN_NO_GRAPH") == nullptr;
   h->fuse_mode = fuse_env();
-  h->stream_last = getenv("SN_STREAM_LAST") != nullptr && atoi(getenv("SN_STREAM_LAST")) == 1;
+  // the last block streamed as well + the head as its own launch (default); SN_STREAM_LAST=0: conv + fused conv / head
+  h->stream_last = !(getenv("SN_STREAM_LAST") != nullptr && atoi(getenv("SN_STREAM_LAST")) == 0);
   h->head_fuse = head_fuse_env();
   if (hipMalloc(reinterpret_cast<void**>(&h->dump), 4096) != hipSuccess) return fail(SN_ERR_NOMEM);
 
