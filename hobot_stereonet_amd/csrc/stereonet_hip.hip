@@ -993,7 +993,9 @@ int lowres(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, const int
 // branch is done: nothing overlaps that time), the others take ws.pb pairs (the low-resolution launches are dominated by
 // fixed costs: 13 of the 23 launches of a piece do ~1 us of matrix work in ~9 us).
 inline int first_piece(const Workspace& ws, int n) {
+  static const int forced = getenv("SN_FIRST_PIECE") ? atoi(getenv("SN_FIRST_PIECE")) : 0;     // experiment switch
   int m = ws.rb * ws.ns > 2 ? ws.rb * ws.ns : 2;
+  if (forced > 0) m = forced;
   if (m > ws.pb) m = ws.pb;
   return m < n ? m : n;
 }
