@@ -466,8 +466,44 @@ hipError_t conv3x3_d(hipStream_t st, const ConvLayer& L, const float* in, int ni
   return launch_conv<3, 1, DIL, 8, 8, 64>(st, L, ld, nimg, H, W, out, res, lrelu);
 }
 
+// Tower layers of SN_PREC_FP32 (plain fp32 NCHW, 32 -> 32, 3x3 dilated): the weights-stationary kernel of sn_tower_f32.hpp.
+template <int DIL, int CPH>
+hipError_t launch_ref_conv_f32(hipStream_t st, const ConvLayer& L, const float* in, int nimg, int H, int W, float* out,
+                               const float* res, bool lrelu, int num_cu) {
+  using T = F32Tile<DIL, CPH>;
+  auto kern = res ? k_ref_conv_f32<DIL, CPH, true> : k_ref_conv_f32<DIL, CPH, false>;
+  if (T::LDS_BYTES > 64 * 1024 - 1024) {
+    hipError_t e = ensure_lds_attr(kern, T::LDS_BYTES);
+    if (e != hipSuccess) return e;
+  }
+  const int total = ((W + T::TW - 1) / T::TW) * ((H + T::TH - 1) / T::TH) * nimg;
+  // persistent: two workgroups per CU, tiles strided over them; the grid is trimmed so that every workgroup gets the
+  // same number of tiles (1280x720, one pair: 1800 tiles = 450 workgroups x 4 instead of 512 x 3.5 -> 4 rounds)
+  const int cap = 2 * num_cu;
+  const int rounds = (total + cap - 1) / cap;
+  int grid = (total + rounds - 1) / rounds;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), T::LDS_BYTES, st, in, out, res, L.wpk, L.bias, nimg, H, W, lrelu ? 1 : 0);
+  return hipGetLastError();
+}
+
+// SN_F32_TOWER=0 keeps the generic kernel for the tower layers too (A/B)
+inline bool f32_tower_env() {
+  static const bool on = !(getenv("SN_F32_TOWER") != nullptr && atoi(getenv("SN_F32_TOWER")) == 0);
+  return on;
+}
+
 hipError_t conv3x3(hipStream_t st, const ConvLayer& L, const float* in, int nimg, int H, int W, int dil,
-                   float* out, const float* res, bool lrelu) {
+                   float* out, const float* res, bool lrelu, int tower_cu = 0) {
+  if (tower_cu > 0 && L.cin == kC && L.cin_pad == kC && f32_tower_env()) {
+    switch (dil) {
+      case 1: return launch_ref_conv_f32<1, 8>(st, L, in, nimg, H, W, out, res, lrelu, tower_cu);
+      case 2: return launch_ref_conv_f32<2, 8>(st, L, in, nimg, H, W, out, res, lrelu, tower_cu);
+      case 4: return launch_ref_conv_f32<4, 8>(st, L, in, nimg, H, W, out, res, lrelu, tower_cu);
+      case 8: return launch_ref_conv_f32<8, 4>(st, L, in, nimg, H, W, out, res, lrelu, tower_cu);
+      default: return hipErrorInvalidValue;
+    }
+  }
   switch (dil) {
     case 1: return conv3x3_d<1>(st, L, in, nimg, H, W, out, res, lrelu);
     case 2: return conv3x3_d<2>(st, L, in, nimg, H, W, out, res, lrelu);
@@ -1026,8 +1062,8 @@ int refine_level(sn_handle* h, Workspace& ws, hipStream_t st, const Tower& T, fl
       HIP_TRY(h, (launch_conv<3, 1, 1, 4, 8, 64>(st, T.rin, ld, c, Hk, Wk, rx, nullptr, true)));
     if (pe) HIP_TRY(h, hipEventRecord(h->ev[4], st));
     for (int i = 0; i < kNRefRes; ++i) {
-      HIP_TRY(h, conv3x3(st, T.rres[i][0], rx, c, Hk, Wk, kRefDil[i], rt, nullptr, true));
-      HIP_TRY(h, conv3x3(st, T.rres[i][1], rt, c, Hk, Wk, kRefDil[i], rx, rx, true));
+      HIP_TRY(h, conv3x3(st, T.rres[i][0], rx, c, Hk, Wk, kRefDil[i], rt, nullptr, true, ncu));
+      HIP_TRY(h, conv3x3(st, T.rres[i][1], rt, c, Hk, Wk, kRefDil[i], rx, rx, true, ncu));
     }
     if (pe) HIP_TRY(h, hipEventRecord(h->ev[5], st));
     dim3 grid((W + 63) / 64, (H + 3) / 4, c);
