@@ -35,7 +35,7 @@ struct F32Tile {
   static constexpr int NGRP = CPH * ROWS * GPR;          // groups per phase
   static constexpr int NPH = 32 / CPH;
   static constexpr int TILE_BYTES = (NGRP + 63) / 64 * 1024;             // whole 1 KiB DMA instructions
-  static constexpr int W_BYTES = 144 * 64 * 4;                           // weight table [operand][lane]
+  static constexpr int W_BYTES = 144 * 64 * 4 + 128;                     // weight table [operand][lane] + the 32 biases
   static constexpr int LDS_BYTES = W_BYTES + TILE_BYTES;
   static_assert(CPH % 2 == 0 && 32 % CPH == 0, "phases of whole channel pairs");
   static_assert(TILE_BYTES < 65536, "ds_read_b32 immediate offsets");
@@ -58,6 +58,8 @@ __global__ __launch_bounds__(512, 4) void k_ref_conv_f32(const float* __restrict
     const int m = i >> 6, l = i & 63, kk = m / 9, tap = m - kk * 9;
     wtab[i] = wpk[((2 * kk + (l >> 5)) * 9 + tap) * kC + (l & 31)];
   }
+  float* const s_bias = wtab + 144 * 64;
+  if (tid < kC) s_bias[tid] = bias[tid];
   const int tiles_x = (W + T::TW - 1) / T::TW, tiles_y = (H + T::TH - 1) / T::TH;
   const int per_img = tiles_x * tiles_y, total = per_img * nimg;
   const size_t HW = (size_t)H * W;
@@ -137,12 +139,16 @@ __global__ __launch_bounds__(512, 4) void k_ref_conv_f32(const float* __restrict
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int y = y0 + wave, x = x0 + s * 32 + px;
+#if defined(SN_F32_EXP) && SN_F32_EXP == 1
+      if (y < H && x < W && acc[s][0] == 123456.f) {      // experiment: (almost) no epilogue traffic
+#else
       if (y < H && x < W) {
+#endif
         const size_t o = (size_t)img * kC * HW + (size_t)y * W + x;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int co = (r & 3) + 8 * (r >> 2) + 4 * kh;
-          float v = acc[s][r] + bias[co];          // (the bias is re-read per tile: 16 registers the weights need)
+          float v = acc[s][r] + s_bias[co];
           if (RES) v += res[o + (size_t)co * HW];
           const float tt = v * slope;
           v = v > tt ? v : tt;

@@ -495,7 +495,9 @@ inline bool f32_tower_env() {
 
 hipError_t conv3x3(hipStream_t st, const ConvLayer& L, const float* in, int nimg, int H, int W, int dil,
                    float* out, const float* res, bool lrelu, int tower_cu = 0) {
-  if (tower_cu > 0 && L.cin == kC && L.cin_pad == kC && f32_tower_env()) {
+  // (the 16-byte staging wants rows that start 16-byte aligned: W % 4 == 0 — every level-0 geometry, not every coarse
+  // level of a hierarchical model)
+  if (tower_cu > 0 && L.cin == kC && L.cin_pad == kC && (W & 3) == 0 && f32_tower_env()) {
     switch (dil) {
       case 1: return launch_ref_conv_f32<1, 8>(st, L, in, nimg, H, W, out, res, lrelu, tower_cu);
       case 2: return launch_ref_conv_f32<2, 8>(st, L, in, nimg, H, W, out, res, lrelu, tower_cu);
