@@ -135,24 +135,49 @@ __global__ __launch_bounds__(512, 4) void k_ref_conv_f32(const float* __restrict
           }
         }
     }
-    // epilogue: accumulator register r of lane (px, kh) = channel (r & 3) + 8 (r >> 2) + 4 kh of pixel px
+    // epilogue: accumulator register r of lane (px, kh) = channel (r & 3) + 8 (r >> 2) + 4 kh of pixel px.  Stored as it
+    // lies that is sixteen 4-byte stores (and residual loads) per segment; the VMEM instructions of the epilogue cost
+    // 13 % of the kernel (measured with the traffic switched off).  So the values cross a 2 KB per-wave LDS scratch
+    // (the tile area, free after the last phase) sixteen channels at a time and leave as 16-byte accesses: lane l then
+    // owns pixels 4 (l & 7) .. + 3 of channel l >> 3 — four stores per segment, the same 128-byte runs per channel.
+    __syncthreads();                     // every wave is done reading the tile
+    {
+      float* scr = tile + wave * 512;    // [16 channels][32 pixels]
+      const int y = y0 + wave;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int y = y0 + wave, x = x0 + s * 32 + px;
-#if defined(SN_F32_EXP) && SN_F32_EXP == 1
-      if (y < H && x < W && acc[s][0] == 123456.f) {      // experiment: (almost) no epilogue traffic
-#else
-      if (y < H && x < W) {
-#endif
-        const size_t o = (size_t)img * kC * HW + (size_t)y * W + x;
+      for (int s = 0; s < 2; ++s) {
+        const int xg = x0 + s * 32 + 4 * (lane & 7);
+        const bool ok = y < H && xg < W;                 // W % 4 == 0: a group of four pixels is inside or outside
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int co = (r & 3) + 8 * (r >> 2) + 4 * kh;
-          float v = acc[s][r] + s_bias[co];
-          if (RES) v += res[o + (size_t)co * HW];
-          const float tt = v * slope;
-          v = v > tt ? v : tt;
-          out[o + (size_t)co * HW] = v;
+        for (int half = 0; half < 2; ++half) {           // channels 16 half .. 16 half + 15
+#pragma unroll
+          for (int r8 = 0; r8 < 8; ++r8) {
+            const int r = half * 8 + r8;
+            const int cl = (r & 3) + 8 * ((r >> 2) & 1) + 4 * kh;        // channel within the half
+            scr[cl * 32 + px] = acc[s][r];
+          }
+          // The lanes of a wave exchange values through LDS here without a barrier (the LDS queue of a wave is in order).
+          // To the compiler that is a thread whose stores nobody reads: where `ok` differs between lanes it made the
+          // stores of the not-ok lanes conditional (dead-store elimination against the next pass's stores) and the
+          // pixels those lanes own came out stale — only on tiles cut by the right image edge.  The clobbers pin the
+          // stores before and the loads after this point.
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int cl = (lane >> 3) + 8 * i, co = half * 16 + cl;
+            f32x4 v = *reinterpret_cast<const f32x4*>(scr + cl * 32 + 4 * (lane & 7));
+            const size_t o = ((size_t)img * kC + co) * HW + (size_t)y * W + xg;
+            const float bco = s_bias[co];
+            f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+            if (RES && ok) rv = *reinterpret_cast<const f32x4*>(res + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float u = v[e] + rv[e] + bco, tt = u * slope;
+              v[e] = u > tt ? u : tt;
+            }
+            if (ok) *reinterpret_cast<f32x4*>(out + o) = v;
+            asm volatile("" ::: "memory");
+          }
         }
       }
     }

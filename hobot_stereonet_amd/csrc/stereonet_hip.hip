@@ -1443,7 +1443,9 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
   }
   {
     const char* e = getenv("SN_TOWER_STREAMS");        // 2 = consecutive tower chunks alternate between two streams
-    h->tower_streams = e ? atoi(e) : 1;
+    // default 1; 2 in SN_PREC_FP32: a one-pair launch of the fp32 tower kernel is 3.5 rounds of tiles on the persistent
+    // grid, and the next chunk's launch on the other stream takes the CUs the last half round leaves idle (+6 %)
+    h->tower_streams = e ? atoi(e) : (h->precision == SN_PREC_FP32 ? 2 : 1);
     if (h->tower_streams < 1) h->tower_streams = 1;
     if (h->tower_streams > kMaxTowerStreams) h->tower_streams = kMaxTowerStreams;
   }
@@ -2040,6 +2042,7 @@ int sn_dbg_conv2d(sn_handle* h, const float* in, int cin, int h_px, int w, const
   const int Ho = stride == 1 ? h_px : h_px / 2, Wo = stride == 1 ? w : w / 2;
   if (stride == 2 && ((h_px & 1) || (w & 1))) return SN_ERR_ARG;
   const bool x3 = (lrelu & 2) != 0, slots = (lrelu & 4) != 0;
+  const bool tower32 = (lrelu & 8) != 0;     // bit 3: the fp32 tower kernel (k_ref_conv_f32) instead of the generic one
   lrelu &= 1;
   if (x3 != slots || (x3 && !(cin == kC && dil == 1))) return SN_ERR_ARG;     // the split-operand kernel reads slots
   if (slots) {          // split-slot tensors in and out through the weights-stationary kernel (fp16 modes' low-res path)
@@ -2098,7 +2101,8 @@ int sn_dbg_conv2d(sn_handle* h, const float* in, int cin, int h_px, int w, const
     e = (Ho * Wo <= 64 * 128) ? launch_conv<3, 1, 1, 4, 4, 32>(st, L, ld, 1, Ho, Wo, dout, dres, lrelu != 0)
                               : launch_conv<3, 1, 1, 4, 8, 64>(st, L, ld, 1, Ho, Wo, dout, dres, lrelu != 0);
   } else {
-    e = conv3x3(st, L, din, 1, h_px, w, dil, dout, dres, lrelu != 0);
+    if (tower32 && ((w & 3) != 0 || cin != kC)) return SN_ERR_ARG;
+    e = conv3x3(st, L, din, 1, h_px, w, dil, dout, dres, lrelu != 0, tower32 ? h->num_cu : 0);
   }
   HIP_TRY(h, e);
   HIP_TRY(h, hipStreamSynchronize(st));

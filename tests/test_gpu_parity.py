@@ -41,6 +41,26 @@ def test_conv3x3_c32(small_engine, oracle, h, w, dil):
     assert rel_err(got2, ref2) < 2e-5
 
 
+@pytest.mark.parametrize("h,w,dil", [(64, 128, 1), (64, 112, 1), (48, 176, 1), (45, 80, 1), (33, 72, 2), (72, 200, 4),
+                                     (130, 304, 8), (20, 20, 8), (90, 160, 2), (720, 1280, 1)])
+def test_tower_conv_fp32_kernel(small_engine, oracle, h, w, dil):
+    """The weights-stationary fp32 tower kernel (k_ref_conv_f32, what SN_PREC_FP32 runs for the twelve 32 -> 32 tower
+    layers) on full, partial (w % 64 != 0, h % 8 != 0) and single-tile geometries, plain and as the in-place
+    residual + LeakyReLU form."""
+    rng = np.random.default_rng(h * 1000 + w + dil)
+    x = rng.standard_normal((32, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((32, 32, 3, 3)) / 17.0).astype(np.float32)
+    b = rng.standard_normal(32).astype(np.float32)
+    ref = oracle.conv2d(x, wt, b, 1, dil, dil)
+    got = small_engine.dbg_conv2d(x, wt, b, 3, 1, dil, tower32=True)
+    assert rel_err(got, ref) < 2e-5
+    res = rng.standard_normal((32, h, w)).astype(np.float32)
+    v = ref + res
+    ref2 = np.where(v > 0, v, v * np.float32(0.2))
+    got2 = small_engine.dbg_conv2d(x, wt, b, 3, 1, dil, lrelu=True, residual=res, tower32=True)
+    assert rel_err(got2, ref2) < 2e-5
+
+
 @pytest.mark.parametrize("cin,h,w", [(3, 64, 96), (3, 360, 640), (32, 90, 160), (32, 46, 82), (32, 180, 320)])
 def test_conv5x5_stride2(small_engine, oracle, cin, h, w):
     rng = np.random.default_rng(cin * 7 + h + w)
