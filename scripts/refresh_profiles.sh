@@ -24,7 +24,7 @@ $T rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --outpu
 cd $ROOT
 python scripts/lds_conflicts.py $(find $OUT/${TAG}_pmc_lds -name "*counter_collection.csv" | head -1) $OUT/${TAG}_lds_conflicts.json > $OUT/${TAG}_lds_conflicts.txt 2>&1
 python scripts/pmc_traffic.py $(find $OUT/${TAG}_pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1) \
-    $(find $OUT/${TAG}_pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1) $OUT/${TAG}_pmc_traffic.json k_ref_block_stream_f16 ${PAIRS_PER_LAUNCH:-2} > $OUT/${TAG}_pmc_summary.txt 2>&1
+    $(find $OUT/${TAG}_pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1) $OUT/${TAG}_pmc_traffic.json k_ref_block_stream_f16 ${PAIRS_PER_LAUNCH:-4} > $OUT/${TAG}_pmc_summary.txt 2>&1
 python scripts/mfma_busy.py $(find $OUT/${TAG}_pmc_mfma -name "*counter_collection.csv" | head -1) $OUT/${TAG}_mfma_busy.json > $OUT/${TAG}_mfma_busy.txt 2>&1
 $T python bench.py --precision f16x3 --no-cpu-baseline --no-end-to-end --steps 20 > $OUT/${TAG}_f16x3_b64_bench.json 2>> $OUT/${TAG}_bench.err
 $T python bench.py --precision fp32 --no-cpu-baseline --no-end-to-end --steps 5 --batch 16 > $OUT/${TAG}_fp32_b16_bench.json 2>> $OUT/${TAG}_bench.err
@@ -32,13 +32,22 @@ $T python bench.py --no-cpu-baseline --no-end-to-end --batch 1 --steps 400 --war
 $T python bench.py --config c5 --steps 50 > $OUT/${TAG}_c5_f16_b64_bench.json 2>> $OUT/${TAG}_bench.err          # hierarchical refinement (c5 default)
 $T python bench.py --config c5 --refine single --steps 50 --no-cpu-baseline --no-end-to-end > $OUT/${TAG}_c5_single_f16_b64_bench.json 2>> $OUT/${TAG}_bench.err
 $T python bench.py --refine multi --steps 40 --no-cpu-baseline --no-end-to-end > $OUT/${TAG}_c2_multi_f16_b64_bench.json 2>> $OUT/${TAG}_bench.err
+$T python bench.py --gpus 2 --dist-backend gloo --device-map 0,0 --batch 16 --steps 10 --no-cpu-baseline --no-end-to-end > $OUT/${TAG}_two_ranks_one_gpu_gloo.json 2>> $OUT/${TAG}_bench.err   # functional N > 1 run
 $T python bench.py --stream 10 --batch 16 > $OUT/${TAG}_stream_c2_b16.json 2>> $OUT/${TAG}_bench.err
 $T python bench.py --config c5 --stream 10 --batch 16 > $OUT/${TAG}_stream_c5_b16.json 2>> $OUT/${TAG}_bench.err
 [ -x scripts/build/mall_probe ] && ./scripts/build/mall_probe > $OUT/${TAG}_mall_probe.txt 2>&1
+# clock and package power while the timed workload runs (the tower runs at the 1400 W cap)
+python bench.py --steps 400 --no-cpu-baseline --no-end-to-end --no-verify > /dev/null 2>&1 &
+LOADPID=$!
+sleep 25
+for i in 1 2 3 4 5; do rocm-smi --showclocks --showpower 2>&1 | grep -E "sclk|Power \(W\)"; sleep 1; done > $OUT/${TAG}_clock_power_under_load.txt 2>&1
+wait $LOADPID
+[ -x scripts/build/stream_block_probe ] && ./scripts/build/stream_block_probe 300 > $OUT/${TAG}_stream_block_probe.txt 2>&1
 python scripts/kstats.py $OUT/${TAG}_f16_b64_kernel_stats.csv 30 > $OUT/${TAG}_kernel_summary.txt
 python scripts/tower_sequence.py $(find $OUT/${TAG}_prof -name "*kernel_trace.csv" | head -1) > $OUT/${TAG}_tower_sequence.txt 2>&1
 cat $OUT/${TAG}_mfma_busy.txt | head -12
-for f in f16_b64 f16x3_b64 fp32_b16 f16_b1 c5_f16_b64 c5_single_f16_b64 c2_multi_f16_b64; do python - <<PY
+$T python bench.py --precision fp32 --no-cpu-baseline --no-end-to-end --batch 1 --steps 100 --warmup 5 > $OUT/${TAG}_fp32_b1_bench.json 2>> $OUT/${TAG}_bench.err
+for f in f16_b64 f16x3_b64 fp32_b16 fp32_b1 f16_b1 c5_f16_b64 c5_single_f16_b64 c2_multi_f16_b64; do python - <<PY
 import json
 try:
     d=json.loads(open("$OUT/${TAG}_${f}_bench.json").read().strip().splitlines()[-1])
@@ -47,7 +56,7 @@ except Exception as e:
     print("$f ERR", e)
 PY
 done
-for f in stream_c2_b16 stream_c5_b16; do python - <<PY
+for f in stream_c2_b16 stream_c5_b16 two_ranks_one_gpu_gloo; do python - <<PY
 import json
 try:
     d=json.loads(open("$OUT/${TAG}_${f}.json").read().strip().splitlines()[-1]); print("$f", round(d["value"],1), d["unit"], d["timed_seconds"])
