@@ -9,5 +9,5 @@ for spec in "$@"; do
     if [[ $p == --* ]]; then flags="$flags ${p/=/ }"; else envs="$envs $p"; fi
   done
   echo "== $spec"
-  env $envs python bench.py --steps ${AB_STEPS:-20} --no-cpu-baseline --no-end-to-end $flags 2>&1 | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['value'],1), d['verified'], d['config']['refine_chunk'], d['config']['piece'])"
+  env $envs python bench.py --steps ${AB_STEPS:-20} --no-cpu-baseline --no-end-to-end --no-long $flags 2>&1 | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['value'],1), d['verified'], d['config']['refine_chunk'], d['config']['piece'])"
 done

@@ -14,13 +14,13 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 T="timeout 600"
 $T python $ROOT/bench.py > $OUT/${TAG}_f16_b64_bench.json 2> $OUT/${TAG}_bench.err
-$T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-end-to-end > $OUT/${TAG}_bench_under_rocprof.log 2>&1
+$T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-end-to-end --no-long > $OUT/${TAG}_bench_under_rocprof.log 2>&1
 cp $(find $OUT/${TAG}_prof -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_f16_b64_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
-  $T rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${TAG}_pmc_$c -- python $ROOT/bench.py --steps 2 --warmup 1 --batch 8 --no-cpu-baseline --no-end-to-end --no-verify > $OUT/${TAG}_pmc_$c.log 2>&1
+  $T rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${TAG}_pmc_$c -- python $ROOT/bench.py --steps 2 --warmup 1 --batch 8 --no-cpu-baseline --no-end-to-end --no-verify --no-long > $OUT/${TAG}_pmc_$c.log 2>&1
 done
-$T rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_pmc_mfma -- python $ROOT/bench.py --steps 2 --warmup 1 --batch 8 --no-cpu-baseline --no-end-to-end --no-verify > $OUT/${TAG}_pmc_mfma.log 2>&1
-$T rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/${TAG}_pmc_lds -- python $ROOT/bench.py --steps 2 --warmup 1 --batch 8 --no-cpu-baseline --no-end-to-end --no-verify > $OUT/${TAG}_pmc_lds.log 2>&1
+$T rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_pmc_mfma -- python $ROOT/bench.py --steps 2 --warmup 1 --batch 8 --no-cpu-baseline --no-end-to-end --no-verify --no-long > $OUT/${TAG}_pmc_mfma.log 2>&1
+$T rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/${TAG}_pmc_lds -- python $ROOT/bench.py --steps 2 --warmup 1 --batch 8 --no-cpu-baseline --no-end-to-end --no-verify --no-long > $OUT/${TAG}_pmc_lds.log 2>&1
 cd $ROOT
 python scripts/lds_conflicts.py $(find $OUT/${TAG}_pmc_lds -name "*counter_collection.csv" | head -1) $OUT/${TAG}_lds_conflicts.json > $OUT/${TAG}_lds_conflicts.txt 2>&1
 python scripts/pmc_traffic.py $(find $OUT/${TAG}_pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1) \
@@ -45,6 +45,7 @@ wait $LOADPID
 [ -x scripts/build/stream_block_probe ] && ./scripts/build/stream_block_probe 300 > $OUT/${TAG}_stream_block_probe.txt 2>&1
 python scripts/kstats.py $OUT/${TAG}_f16_b64_kernel_stats.csv 30 > $OUT/${TAG}_kernel_summary.txt
 python scripts/tower_sequence.py $(find $OUT/${TAG}_prof -name "*kernel_trace.csv" | head -1) > $OUT/${TAG}_tower_sequence.txt 2>&1
+rm -rf $OUT/${TAG}_prof $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE $OUT/${TAG}_pmc_mfma $OUT/${TAG}_pmc_lds     # raw traces: scratch
 cat $OUT/${TAG}_mfma_busy.txt | head -12
 $T python bench.py --precision fp32 --no-cpu-baseline --no-end-to-end --batch 1 --steps 100 --warmup 5 > $OUT/${TAG}_fp32_b1_bench.json 2>> $OUT/${TAG}_bench.err
 for f in f16_b64 f16x3_b64 fp32_b16 fp32_b1 f16_b1 c5_f16_b64 c5_single_f16_b64 c2_multi_f16_b64; do python - <<PY
