@@ -690,7 +690,8 @@ hipError_t launch_ref_block_stream(hipStream_t st, const RefLayerF16& L1, const 
   sc.nstrips = (g.W + T::OW - 1) / T::OW;
   sc.hsub = (g.H + DIL - 1) / DIL;
   sc.total_rows = nimg * DIL * sc.nstrips * sc.hsub;
-  int nwg = num_cu;
+  static const int wg_env = getenv("SN_STREAM_WGS") ? atoi(getenv("SN_STREAM_WGS")) : 0;     // experiment switch
+  int nwg = wg_env > 0 ? wg_env : num_cu;
   if (nwg > sc.total_rows) nwg = sc.total_rows;
   if (nwg < 1) nwg = 1;
   sc.rows_per_wg = (sc.total_rows + nwg - 1) / nwg;
