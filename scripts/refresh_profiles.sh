@@ -37,7 +37,7 @@ $T python bench.py --stream 10 --batch 16 > $OUT/${TAG}_stream_c2_b16.json 2>> $
 $T python bench.py --config c5 --stream 10 --batch 16 > $OUT/${TAG}_stream_c5_b16.json 2>> $OUT/${TAG}_bench.err
 [ -x scripts/build/mall_probe ] && ./scripts/build/mall_probe > $OUT/${TAG}_mall_probe.txt 2>&1
 # clock and package power while the timed workload runs (the tower runs at the 1400 W cap)
-python bench.py --steps 400 --no-cpu-baseline --no-end-to-end --no-verify > /dev/null 2>&1 &
+python bench.py --steps 2000 --no-cpu-baseline --no-end-to-end --no-verify > /dev/null 2>&1 &
 LOADPID=$!
 sleep 25
 for i in 1 2 3 4 5; do rocm-smi --showclocks --showpower 2>&1 | grep -E "sclk|Power \(W\)"; sleep 1; done > $OUT/${TAG}_clock_power_under_load.txt 2>&1
