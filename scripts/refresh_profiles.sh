@@ -13,7 +13,7 @@ OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 T="timeout 600"
-$T python $ROOT/bench.py > $OUT/${TAG}_f16_b64_bench.json 2> $OUT/${TAG}_bench.err
+$T python $ROOT/bench.py --cpu-baseline-torch > $OUT/${TAG}_f16_b64_bench.json 2> $OUT/${TAG}_bench.err
 $T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-end-to-end --no-long > $OUT/${TAG}_bench_under_rocprof.log 2>&1
 cp $(find $OUT/${TAG}_prof -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_f16_b64_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do

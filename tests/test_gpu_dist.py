@@ -93,3 +93,33 @@ def test_hierarchical_batch_larger_than_a_piece(model_factory, oracle, weights_m
             assert (r1 == raw[k]).all() and (d1 == disp[k]).all(), k
     odisp = oracle.forward(weights_multi, xs[8], d)[0]
     assert float(np.abs(disp[8] - odisp).mean()) < 1e-3
+
+
+@pytest.mark.gpu
+def test_rccl_gather_path_single_rank():
+    """The RCCL form of the gather (backend "nccl", device tensors, async_op) executes for real, with the one rank a
+    one-GPU box can host: AsyncGather / gather_to_root / run_sharded on device tensors through RCCL — the code the 8-GPU run
+    uses, minus the peers."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from hobot_stereonet_amd import dist as sdist
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        dev = torch.device("cuda", 0)
+        a = torch.arange(5 * 7 * 9, dtype=torch.int32, device=dev).reshape(5, 7, 9)
+        g1, g2 = sdist.AsyncGather(a, dst=0), sdist.AsyncGather(a + 1, dst=0)     # two in flight, waited out of order
+        r2, r1 = g2.wait(), g1.wait()
+        assert len(r1) == 1 and r1[0].is_cuda and torch.equal(r1[0], a) and torch.equal(r2[0], a + 1)
+        out = sdist.run_sharded(5, lambda b, e: a[b:e], dst=0)
+        assert torch.equal(out, a)
+    finally:
+        dist.destroy_process_group()
