@@ -263,7 +263,7 @@ int sn_mgpu_create(const char* model_file, const sn_config* cfg, const int* devi
   m->gather = (ndev > 1 && distinct) ? 2 : 1;
   if (const char* e = getenv("SN_MGPU_GATHER")) {
     if (!strcmp(e, "peer")) m->gather = 1;
-    else if (!strcmp(e, "rccl") && ndev > 1 && distinct) m->gather = 2;
+    else if (!strcmp(e, "rccl") && distinct) m->gather = 2;      // (also with ndev = 1: loads RCCL, builds the communicator, runs an empty group)
   }
   if (m->gather == 2 && !m->rccl.load()) m->gather = 1;
   int rc = SN_OK;
@@ -396,7 +396,7 @@ int sn_mgpu_submit_device(sn_mgpu* m, int n, const int8_t* const* in_per_device,
     const int all = m->ndev > 1 ? m->agree.arrive_and_wait(my) : my;
     if (all != SN_OK) return my != SN_OK ? my : all;
     if (hipStreamWaitEvent(w->st, w->ev_compute[slot], 0) != hipSuccess) return SN_ERR_DEVICE;
-    if (m->ndev > 1 && m->gather == 2) {     // one grouped exchange: root posts a recv per peer, every peer one send per map kind
+    if (m->gather == 2) {     // one grouped exchange: root posts a recv per peer, every peer one send per map kind
       bool ok = m->rccl.GroupStart() == 0;
       for (int kind = 0; kind < 2 && ok; ++kind) {
         char* root_buf = reinterpret_cast<char*>(kind == 0 ? (void*)out_i32_root : (void*)out_disp_root);

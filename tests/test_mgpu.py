@@ -95,6 +95,28 @@ def test_one_device_equals_single_gpu_batch(model_factory):
 
 
 @pytest.mark.gpu
+def test_rccl_branch_loads_and_runs_with_one_device(model_factory, monkeypatch):
+    """SN_MGPU_GATHER=rccl with ndev = 1: librccl is dlopen'ed, ncclCommInitAll builds the (one-rank) communicator and every
+    batch runs its grouped exchange (empty: the root has no peer) on the exchange stream — the RCCL plumbing of sn_mgpu_*
+    executes on a one-GPU box; results equal sn_infer_batch."""
+    import torch
+    monkeypatch.setenv("SN_MGPU_GATHER", "rccl")
+    w, h, d, n = 160, 96, 96, 3
+    xs = np.stack([synth.model_input_i8(w, h, d, 110 + s) for s in range(n)])
+    with api.StereoNetHIP(model_factory(w, h, d), max_batch=n, precision=api.PREC_F16) as eng:
+        disp1, raw1 = eng.infer(xs)
+    with api.StereoNetMultiGPU(model_factory(w, h, d), devices=[0], max_batch=n, precision=api.PREC_F16) as m:
+        assert m.ndev == 1 and m.gather_kind == 2
+        dev = torch.device("cuda", 0)
+        x = torch.from_numpy(xs).to(dev)
+        traw = torch.empty((n, h, w), dtype=torch.int32, device=dev)
+        tdisp = torch.empty((n, h, w), dtype=torch.float32, device=dev)
+        for _ in range(2):
+            m.infer_device(n, [x.data_ptr()], traw.data_ptr(), tdisp.data_ptr())
+        assert (traw.cpu().numpy() == raw1).all() and (tdisp.cpu().numpy() == disp1).all()
+
+
+@pytest.mark.gpu
 def test_two_shards_on_one_device_through_the_worker_threads(model_factory, monkeypatch):
     """ndev = 2 with the real engine on a one-GPU box: SN_MGPU_ALLOW_DUP=1 (test switch) lets both shards name device 0, so
     the per-shard worker threads, the shard arithmetic (ragged: 3 + 2), the status agreement, the peer-copy gather into
