@@ -17,9 +17,10 @@
 //     offset.  The kernel therefore streams "sub-rows" with a global row stride of DIL * Ws.
 //   * ONE 512-thread workgroup per CU, two waves per SIMD with different jobs: waves 0-3 run conv1 (they hold only
 //     conv1's 18 weight fragments) and issue the LDS-DMA groups of the x ring; waves 4-7 run conv2 (conv2's weights)
-//     and store y straight from the accumulators.  A SIMD always has one wave of each kind, so one wave's epilogue /
-//     VMEM issue sits beside the other's MFMAs; per super-step a workgroup issues 17 DMA and 32 store instructions for
-//     288 MFMAs (the per-layer kernel: 24 + 16..32 for 72), which is what bounded the earlier tower kernels
+//     and store y straight from the accumulators as 16-byte slots (v_permlane32_swap half exchange).  A SIMD always has
+//     one wave of each kind, so one wave's epilogue / VMEM issue sits beside the other's MFMAs; per super-step a workgroup
+//     issues 17 DMA and 16 store instructions for 288 MFMAs (the per-layer kernel: 24 + 16..32 for 72), which is what
+//     bounded the earlier tower kernels
 //     (DESIGN.md §5).  (A first form with four MFMA waves holding both weight sets and four helper waves owning all
 //     VMEM traffic measured 116 us per block: with 244 VGPRs hipcc kept only three B fragments in flight, and a lone
 //     wave on a SIMD has nobody to cover its LDS latency — 72 cycles per MFMA.)
@@ -37,7 +38,7 @@
 // shares, one per workgroup, so the grid is balanced to within one step whatever the geometry.
 #pragma once
 
-// Development only (scripts/stream_block_probe.hip -DSN_STREAM_TIMING): s_memtime stamps of super-steps 8..23 of
+// Development only (scripts/stream_block_probe.hip -DSN_STREAM_TIMING; `dump` is otherwise unused): s_memtime stamps of super-steps 8..23 of
 // workgroup 17 into `dump` (wave w, stamp k of super-step q at u64 index ((w * 16 + q - 8) * 8 + k)).
 #ifdef SN_STREAM_TIMING
 #define SN_STAMP(k)                                                                                   \
@@ -79,7 +80,6 @@ struct StreamTile {
   static constexpr int TGP = R * TROW;
   static constexpr int XRING = NXS * XGP;
   static constexpr int TRING = NTS * TGP + 64;             // conv2's kx taps of the junk columns run past the last row
-  static constexpr int NST = R * ((OW + 63) / 64);         // store instructions per helper wave and step (constant)
   static constexpr int LDS_BYTES = (XRING + TRING) * 16 + 2 * 2 * 16 * 4;      // + bias tables [conv][k-half][16]
   static_assert(SPW == 1 || SPW == 2, "segments per wave");
   static_assert(CSEG % SPW == 0, "a wave's segments lie in one row");
