@@ -218,7 +218,7 @@ static int full_size(int H, int W, int nimg, int ncu, int iters) {
     for (int c = 0; c < kC; ++c)
       for (int y = 0; y < H; ++y) {
         _Float16* row = &hin[((((size_t)n * 4 + (c >> 3)) * g.Hs + y + kRefPad) * g.Ws + kRefPad) * 8];
-        for (int xx = 0; xx < W; ++xx) row[(size_t)xx * 8 + (c & 7)] = (_Float16)nd(rng);
+        for (int xx = 0; xx < W; ++xx) row[(size_t)xx * 8 + (c & 7)] = getenv("PROBE_ZERO") ? (_Float16)0.f : (_Float16)nd(rng);      // PROBE_ZERO: all-zero activations (how much of the time is data-dependent power)
       }
   uint4 *dx, *dt, *dy, *dy2, *dump;
   unsigned* ctr;
