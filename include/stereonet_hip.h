@@ -237,8 +237,9 @@ int sn_dbg_ref_conv_f16(sn_handle *h, const float *in, int h_px, int w, const fl
 /* the same layer through the split-operand (SN_PREC_F16X3) kernel */
 int sn_dbg_ref_conv_f16x3(sn_handle *h, const float *in, int h_px, int w, const float *wt, const float *bias,
                           int dil, int lrelu, const float *residual, float *out);
-/* one residual block y = lrelu(x + conv2(lrelu(conv1(x)+b1)) + b2) of the fp16 tower, exactly as the pipeline runs it
- * (one fused kernel for dilation 1, two convolution launches otherwise); fp32 [32][h][w] host tensors. */
+/* one residual block y = lrelu(x + conv2(lrelu(conv1(x)+b1)) + b2) of the fp16 tower; fp32 [32][h][w] host tensors.
+ * dil = 1 / 2 / 4 / 8 in bits 0..7; bits 8.. select the form: 0 = two convolution launches, 1 = the tile-fused kernel
+ * (dilation 1 only), 2 = the row-streaming fused kernel the pipeline runs by default (every dilation). */
 int sn_dbg_ref_block_f16(sn_handle *h, const float *in, int h_px, int w, const float *w1, const float *b1,
                          const float *w2, const float *b2, int dil, float *out);
 /* intermediates of the most recent batch-1 inference: "feat_l" / "feat_r" [32][hl][wl],
