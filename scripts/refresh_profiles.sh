@@ -16,6 +16,10 @@ T="timeout 600"
 $T python $ROOT/bench.py --cpu-baseline-torch > $OUT/${TAG}_f16_b64_bench.json 2> $OUT/${TAG}_bench.err
 $T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-end-to-end --no-long > $OUT/${TAG}_bench_under_rocprof.log 2>&1
 cp $(find $OUT/${TAG}_prof -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_f16_b64_kernel_stats.csv
+# the same with the streams serialised (SN_NO_OVERLAP=1): per-kernel durations as bench.py's profiling pass sees them
+SN_NO_OVERLAP=1 $T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_ser -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-end-to-end --no-long > /dev/null 2>&1
+python $ROOT/scripts/kstats.py $(find $OUT/${TAG}_prof_ser -name "*kernel_stats.csv" | head -1) 30 > $OUT/${TAG}_kernel_summary_serialised.txt
+rm -rf $OUT/${TAG}_prof_ser
 for c in FETCH_SIZE WRITE_SIZE; do
   $T rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${TAG}_pmc_$c -- python $ROOT/bench.py --steps 2 --warmup 1 --batch 8 --no-cpu-baseline --no-end-to-end --no-verify --no-long > $OUT/${TAG}_pmc_$c.log 2>&1
 done
