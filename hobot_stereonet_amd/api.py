@@ -311,14 +311,16 @@ class StereoNetHIP:
                                            bias.ctypes.data, int(split), out.ctypes.data), "sn_dbg_refin")
         return out
 
-    def dbg_conv3d(self, x, wt, bias, lrelu=False, x3=False, slots=False):
+    def dbg_conv3d(self, x, wt, bias, lrelu=False, x3=False, slots=False, dma=False):
+        """dma: the aggregation kernel on zero-bordered volumes (k_agg_x3s_dma; needs x3 and slots); the hook also checks that
+        the kernel left the borders untouched"""
         x = np.ascontiguousarray(x, np.float32)
         wt = np.ascontiguousarray(wt, np.float32)
         bias = np.ascontiguousarray(bias, np.float32)
         _, d, h, w = x.shape
         out = np.empty_like(x)
         self._check(self._lib.sn_dbg_conv3d(self._h, x.ctypes.data, d, h, w, wt.ctypes.data, bias.ctypes.data,
-                                            int(lrelu) | (2 if x3 else 0) | (4 if slots else 0), out.ctypes.data),
+                                            int(lrelu) | (2 if x3 else 0) | (4 if slots else 0) | (8 if dma else 0), out.ctypes.data),
                     "sn_dbg_conv3d")
         return out
 

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libstereonet_hip.so")
 SOURCES = [os.path.join(CSRC, "stereonet_hip.hip"), os.path.join(CSRC, "sn_mgpu.hip")]
-DEPS = SOURCES + [os.path.join(CSRC, "sn_kernels.hpp"), os.path.join(CSRC, "sn_stream_block.hpp"), os.path.join(CSRC, "sn_tower_f32.hpp"), os.path.join(ROOT, "include", "stereonet_hip.h")]
+DEPS = SOURCES + [os.path.join(CSRC, "sn_kernels.hpp"), os.path.join(CSRC, "sn_stream_block.hpp"), os.path.join(CSRC, "sn_tower_f32.hpp"), os.path.join(CSRC, "sn_agg_dma.hpp"), os.path.join(ROOT, "include", "stereonet_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-Wno-unused-value",
          "-I", os.path.join(ROOT, "include"), "-ldl", "-lpthread"]

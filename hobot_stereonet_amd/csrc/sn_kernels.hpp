@@ -2707,3 +2707,4 @@ __global__ __launch_bounds__(256) void k_head_final_f16(const uint4* __restrict_
 
 #include "sn_stream_block.hpp"
 #include "sn_tower_f32.hpp"
+#include "sn_agg_dma.hpp"

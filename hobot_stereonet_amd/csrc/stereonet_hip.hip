@@ -72,6 +72,7 @@ struct Workspace {          // activations for up to `nb` pairs
   float* low[3] = {nullptr, nullptr, nullptr};
   float* feat = nullptr;
   float* vol[2] = {nullptr, nullptr};
+  uint4* volp[2] = {nullptr, nullptr};   // zero-bordered split-slot volumes of the aggregation layers (fp16 modes, VolPad)
   float* cost = nullptr;     // [nb][Dl][hl][wl] (debug / parity)
   float* disp_low = nullptr;
   int ns = 1;                 // tower streams this workspace serves: one (x, t) activation pair per stream
@@ -394,6 +395,46 @@ hipError_t launch_conv_x3s(hipStream_t st, const ConvLayer& L, const Loader& ld,
   if (blocks > (total + 7) / 8 * 8) blocks = (total + 7) / 8 * 8;
   blocks = (blocks + 7) / 8 * 8;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), T::LDS_BYTES, st, a, ld);
+  return hipGetLastError();
+}
+
+// SN_AGG_DMA=0: aggregation layers on the plain split-slot volumes (k_conv_x3s) instead of the zero-bordered ones
+bool agg_dma_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("SN_AGG_DMA");
+    return !(e && *e == '0');
+  }();
+  return on;
+}
+
+VolPad vol_pad(int Dl, int hl, int wl) { return VolPad{Dl, hl, wl, VolPad::ph(hl), VolPad::pw(wl)}; }
+
+// 3x3x3 aggregation layer on zero-bordered split-slot volumes (sn_agg_dma.hpp): one persistent workgroup per CU
+template <bool OUTSLOT>
+hipError_t launch_agg_dma(hipStream_t st, const ConvLayer& L, const uint4* vin, const VolPad& g, int npairs, void* out,
+                          bool lrelu, int num_cu) {
+  ConvArgs a{};
+  a.wpk = reinterpret_cast<const float*>(L.wx3);
+  a.bias = L.bias;
+  a.out = reinterpret_cast<float*>(out);
+  a.res = nullptr;
+  a.nimg = npairs * g.Dl;
+  a.cin_pad = L.cin_pad;
+  a.Ho = g.H;
+  a.Wo = g.W;
+  a.dil = 1;
+  a.pad = 1;
+  a.lrelu = lrelu ? 1 : 0;
+  a.tiles_x = (g.W + 15) / 16;
+  a.tiles_y = (g.H + 7) / 8;
+  auto kern = k_agg_x3s_dma<OUTSLOT>;
+  hipError_t e = ensure_lds_attr(kern, (int)AggDma::LDS_BYTES);
+  if (e != hipSuccess) return e;
+  const int total = a.tiles_x * a.tiles_y * a.nimg;
+  int blocks = num_cu;
+  if (blocks > (total + 7) / 8 * 8) blocks = (total + 7) / 8 * 8;
+  blocks = (blocks + 7) / 8 * 8;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), AggDma::LDS_BYTES, st, a, vin, g);
   return hipGetLastError();
 }
 
@@ -859,6 +900,14 @@ int alloc_ws(sn_handle* h, Workspace* ws, int nb, int rb, int ns) {
   for (int k = 0; k < 3; ++k) HIP_TRY(h, dalloc(&ws->low[k], (size_t)2 * pb * kC * hw));
   HIP_TRY(h, dalloc(&ws->feat, (size_t)2 * pb * kC * hw));
   for (int k = 0; k < 2; ++k) HIP_TRY(h, dalloc(&ws->vol[k], (size_t)pb * h->Dl * kC * hw));
+  if (h->precision != SN_PREC_FP32 && agg_dma_enabled()) {
+    const VolPad g = vol_pad(h->Dl, h->hl, h->wl);
+    const size_t bytes = g.planes(pb) * g.plane_slots() * sizeof(uint4);
+    for (int k = 0; k < 2; ++k) {
+      HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&ws->volp[k]), bytes));
+      HIP_TRY(h, hipMemset(ws->volp[k], 0, bytes));       // the borders stay zero: kernels write image pixels only
+    }
+  }
   HIP_TRY(h, dalloc(&ws->cost, (size_t)nb * h->Dl * hw));
   HIP_TRY(h, dalloc(&ws->disp_low, (size_t)nb * hw));
   if (h->precision == SN_PREC_FP32) {
@@ -908,6 +957,7 @@ void free_ws(Workspace* ws) {
   for (auto p : ws->low) hipFree(p);
   hipFree(ws->feat);
   for (auto p : ws->vol) hipFree(p);
+  for (auto p : ws->volp) hipFree(p);
   hipFree(ws->cost);
   hipFree(ws->disp_low);
   for (auto p : ws->ref) hipFree(p);
@@ -962,6 +1012,19 @@ int lowres_slots(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, con
   }
   if (prof) HIP_TRY(h, hipEventRecord(h->ev[1], st));
   // cost volume -> slots (vol[1]), then every aggregation layer reads slots: agg0 vol[1] -> vol[0], agg1 -> vol[1], ...
+  // (zero-bordered volumes volp[] and the LDS-DMA kernel by default; the last layer writes fp32 into vol[] either way)
+  if (ws.volp[0] != nullptr) {
+    const VolPad g = vol_pad(Dl, hl, wl);
+    const long total = (long)m * Dl * 4 * hl * wl;
+    hipLaunchKernelGGL(k_cost_slots_pad, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ws.feat, ws.volp[1], g, m);
+    for (int i = 0; i < kNAgg; ++i) {
+      const uint4* src = ws.volp[(i + 1) & 1];
+      if (i + 1 < kNAgg)
+        HIP_TRY(h, launch_agg_dma<true>(st, h->agg[i], src, g, m, ws.volp[i & 1], true, ncu));
+      else
+        HIP_TRY(h, launch_agg_dma<false>(st, h->agg[i], src, g, m, ws.vol[i & 1], true, ncu));
+    }
+  } else {
   {
     const long total = (long)m * Dl * 4 * hl * wl;
     hipLaunchKernelGGL(k_cost_slots, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ws.feat,
@@ -975,6 +1038,7 @@ int lowres_slots(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, con
       HIP_TRY(h, (launch_conv_x3s<3, 1, 96, 8, 16, 16, 1, true, SlotIn>(st, h->agg[i], lv, m * Dl, hl, wl, ws.vol[i & 1], nullptr, true, ncu)));
     else
       HIP_TRY(h, (launch_conv_x3s<3, 1, 96, 8, 16, 16, 1, false, SlotIn>(st, h->agg[i], lv, m * Dl, hl, wl, ws.vol[i & 1], nullptr, true, ncu)));
+  }
   }
   const float* v = ws.vol[(kNAgg - 1) & 1];
   const int npix = m * hl * wl;
@@ -2203,9 +2267,9 @@ int sn_dbg_conv3d(sn_handle* h, const float* in, int d, int h_px, int w, const f
   if (!h || !in || !wt || !bias || !out || d <= 0) return SN_ERR_ARG;
   int rc = check_device(h);
   if (rc) return rc;
-  const bool x3 = (lrelu & 2) != 0, slots = (lrelu & 4) != 0;
+  const bool x3 = (lrelu & 2) != 0, slots = (lrelu & 4) != 0, dma = (lrelu & 8) != 0;   // dma: zero-bordered volumes
   lrelu &= 1;
-  if (slots != x3) return SN_ERR_ARG;        // the split-operand kernel reads split-slot volumes
+  if (slots != x3 || (dma && !slots)) return SN_ERR_ARG;        // the split-operand kernels read split-slot volumes
   ConvLayer L;
   HostLayer hl{wt, bias, kC, kC, 27};
   if ((rc = upload_conv3d(h, hl, &L))) return rc;
@@ -2225,11 +2289,44 @@ int sn_dbg_conv3d(sn_handle* h, const float* in, int d, int h_px, int w, const f
   if (slots) {       // the volume as d split-slot images (same byte count as fp32)
     std::vector<_Float16> hs, ho(n * 2);
     host_to_slots(tmp.data(), d, h_px, w, hs);
+    if (dma) {         // k_agg_x3s_dma on the padded layout: planes 1 .. d of d + 2, every (block, part) image with its border
+      const VolPad g = vol_pad(d, h_px, w);
+      const size_t phw = (size_t)g.PH * g.PW, nsl = g.planes(1) * g.plane_slots();
+      std::vector<_Float16> pin(nsl * 8, (_Float16)0.f), pout(nsl * 8);
+      for (size_t img = 0; img < (size_t)d * 8; ++img)      // (plane, block, part) images
+        for (int y = 0; y < h_px; ++y)
+          memcpy(&pin[(((img / 8 + 1) * 8 + img % 8) * phw + (size_t)(y + 1) * g.PW + 1) * 8], &hs[(img * plane + (size_t)y * w) * 8],
+                 (size_t)w * 16);
+      uint4 *pdin = nullptr, *pdout = nullptr;
+      HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&pdin), nsl * 16));
+      HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&pdout), nsl * 16));
+      HIP_TRY(h, hipMemcpy(pdin, pin.data(), nsl * 16, hipMemcpyHostToDevice));
+      HIP_TRY(h, hipMemset(pdout, 0, nsl * 16));
+      HIP_TRY(h, launch_agg_dma<true>(h->stream, L, pdin, g, 1, pdout, lrelu != 0, h->num_cu));
+      HIP_TRY(h, hipStreamSynchronize(h->stream));
+      HIP_TRY(h, hipMemcpy(pout.data(), pdout, nsl * 16, hipMemcpyDeviceToHost));
+      hipFree(pdin);
+      hipFree(pdout);
+      for (size_t img = 0; img < (size_t)d * 8; ++img)
+        for (int y = 0; y < h_px; ++y)
+          memcpy(&ho[(img * plane + (size_t)y * w) * 8], &pout[(((img / 8 + 1) * 8 + img % 8) * phw + (size_t)(y + 1) * g.PW + 1) * 8],
+                 (size_t)w * 16);
+      // the borders must still hold the zeros of the allocation
+      for (size_t i = 0; i < nsl * 8; ++i) {
+        const size_t sl = i / 8, P = sl / (8 * phw), y = (sl % phw) / g.PW, x = sl % g.PW;
+        const bool inside = P >= 1 && P <= (size_t)d && y >= 1 && y <= (size_t)h_px && x >= 1 && x <= (size_t)w;
+        if (!inside && (float)pout[i] != 0.f) {
+          set_err(h, "k_agg_x3s_dma wrote outside the image");
+          return SN_ERR_DEVICE;
+        }
+      }
+    } else {
     HIP_TRY(h, hipMemcpy(din, hs.data(), n * 4, hipMemcpyHostToDevice));
     SlotIn ls{reinterpret_cast<const uint4*>(din), d, h_px, w};
     HIP_TRY(h, (launch_conv_x3s<3, 1, 96, 8, 16, 16, 1, true, SlotIn>(h->stream, L, ls, d, h_px, w, dout, nullptr, lrelu != 0, h->num_cu)));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemcpy(ho.data(), dout, n * 4, hipMemcpyDeviceToHost));
+    }
     host_from_slots(ho, d, h_px, w, tmp.data());
   } else {
   HIP_TRY(h, hipMemcpy(din, tmp.data(), n * 4, hipMemcpyHostToDevice));

@@ -225,7 +225,8 @@ int sn_dbg_down0(sn_handle *h, const int8_t *in6, int h_px, int w, const float *
  * selects the hi/lo output of SN_PREC_F16X3 */
 int sn_dbg_refin(sn_handle *h, const float *disp_low, const int8_t *in6, int h_px, int w, int dmax,
                  const float *wt, const float *bias, int split, float *out);
-/* one 3x3x3 32->32 conv3d (+bias, optional LeakyReLU): in [32][d][h][w] -> out [32][d][h][w]; lrelu bits as above */
+/* one 3x3x3 32->32 conv3d (+bias, optional LeakyReLU): in [32][d][h][w] -> out [32][d][h][w]; lrelu bits as above,
+ * bit 3 (with bits 1 and 2): the aggregation kernel of the zero-bordered volumes (k_agg_x3s_dma) */
 int sn_dbg_conv3d(sn_handle *h, const float *in, int d, int h_px, int w, const float *wt,
                   const float *bias, int lrelu, float *out);
 /* one 32->32 3x3 conv (dilation 1/2/4/8) through the fp16 refinement-tower kernel: in / residual / out are

@@ -322,7 +322,7 @@ def test_lowres_split_conv3x3(small_engine, oracle, h, w):
     assert rel_err(got2, ref2) < 4e-6
 
 
-@pytest.mark.parametrize("d,h,w", [(3, 4, 6), (12, 45, 80), (16, 24, 78)])
+@pytest.mark.parametrize("d,h,w", [(3, 4, 6), (12, 45, 80), (16, 24, 78), (1, 8, 16), (6, 23, 40), (12, 90, 160)])
 def test_lowres_split_conv3d(small_engine, oracle, d, h, w):
     rng = np.random.default_rng(d + h + w)
     x = rng.standard_normal((32, d, h, w)).astype(np.float32)
@@ -331,6 +331,13 @@ def test_lowres_split_conv3d(small_engine, oracle, d, h, w):
     ref = oracle.conv3d(x, wt, b)
     got = small_engine.dbg_conv3d(x, wt, b, x3=True, slots=True)
     assert rel_err(got, ref) < 4e-6
+    # the same layer on zero-bordered volumes (LDS-DMA staging, double-buffered tile, deferred epilogue): the same MFMAs
+    # in the same order, so the same bits — with and without the activation
+    got_dma = small_engine.dbg_conv3d(x, wt, b, x3=True, slots=True, dma=True)
+    assert np.array_equal(got_dma, got)
+    a = small_engine.dbg_conv3d(x, wt, b, lrelu=True, x3=True, slots=True)
+    a_dma = small_engine.dbg_conv3d(x, wt, b, lrelu=True, x3=True, slots=True, dma=True)
+    assert np.array_equal(a_dma, a)
 
 
 @pytest.mark.parametrize("h,w", [(90, 160), (46, 82), (360, 640), (64, 96)])
