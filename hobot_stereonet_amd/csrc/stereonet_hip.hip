@@ -903,7 +903,8 @@ int alloc_ws(sn_handle* h, Workspace* ws, int nb, int rb, int ns) {
   if (h->precision != SN_PREC_FP32 && agg_dma_enabled()) {
     const VolPad g = vol_pad(h->Dl, h->hl, h->wl);
     const size_t bytes = g.planes(pb) * g.plane_slots() * sizeof(uint4);
-    for (int k = 0; k < 2; ++k) {
+    // the kernel addresses the volume with 32-bit byte offsets; a piece that large keeps the plain volumes
+    for (int k = 0; k < 2 && bytes < ((size_t)1 << 32); ++k) {
       HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&ws->volp[k]), bytes));
       HIP_TRY(h, hipMemset(ws->volp[k], 0, bytes));       // the borders stay zero: kernels write image pixels only
     }
