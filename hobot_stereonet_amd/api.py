@@ -271,7 +271,8 @@ class StereoNetHIP:
                 "bytes_per_launch": by.value}
 
     # -- parity hooks --------------------------------------------------------------------------------
-    def dbg_conv2d(self, x, wt, bias, k, stride=1, dil=1, lrelu=False, residual=None, x3=False, slots=False, tower32=False):
+    def dbg_conv2d(self, x, wt, bias, k, stride=1, dil=1, lrelu=False, residual=None, x3=False, slots=False, tower32=False, dma=False):
+        """dma (5x5 stride 2 with x3 and slots): k_down_x3s_dma on zero-bordered tensors; the hook also checks the borders"""
         x = np.ascontiguousarray(x, np.float32)
         wt = np.ascontiguousarray(wt, np.float32)
         bias = np.ascontiguousarray(bias, np.float32)
@@ -280,7 +281,7 @@ class StereoNetHIP:
         out = np.empty((32, ho, wo), np.float32)
         res = np.ascontiguousarray(residual, np.float32) if residual is not None else None
         self._check(self._lib.sn_dbg_conv2d(self._h, x.ctypes.data, cin, h, w, wt.ctypes.data, bias.ctypes.data, k,
-                                            stride, dil, int(lrelu) | (2 if x3 else 0) | (4 if slots else 0) | (8 if tower32 else 0), _np_ptr(res),
+                                            stride, dil, int(lrelu) | (2 if x3 else 0) | (4 if slots else 0) | (8 if tower32 else 0) | (16 if dma else 0), _np_ptr(res),
                                             out.ctypes.data),
                     "sn_dbg_conv2d")
         return out

@@ -315,4 +315,203 @@ __global__ __launch_bounds__(256, 1) void k_agg_x3s_dma(ConvArgs a, const uint4*
   SN_AGG_STAMP_WG(1);
 }
 
+// ------------------------------------------------------------------------------------------
+// The 5x5 stride-2 down-convs 1..3 of the fp16 modes (k_conv_x3s<5, 2, 32, 4, 32, 32, ...>) in the same style: the input
+// is a zero-bordered split-slot tensor (two zero pixels around the image, the grid rounded up to whole tiles), staging
+// is LDS-DMA into a double-buffered halo tile, the epilogue is deferred.  The 4 x 32 tile of k_conv_x3s needs 101 KB of
+// LDS and cannot be double buffered, so a round here is a 4 x 16 tile (55 KB: two 2 x 16 segments, one per wave pair
+// member): wave (khalf, pset) accumulates K half `khalf` of segment `pset` — 25 K-steps x 3 MFMAs, B fragments three
+// K-steps ahead — and the two members of a pair take turns finishing the segment (round parity), so every wave ships
+// one partial and finishes one segment per two rounds.  K order and the three MFMAs per K-step are those of k_conv_x3s:
+// the same bits.
+// ------------------------------------------------------------------------------------------
+struct SlotGeom {      // split-slot tensor [img][4 blocks][hi | lo][PH][PW]; pixel (y, x) at row y + py, column x + px
+  int PH, PW, py, px;
+};
+
+struct DownDma {
+  static constexpr int TR = 4, TC = 16, ROWS_IN = 11, COLS_IN = 35, HALF = 20, PITCH = 40, PLANE = ROWS_IN * PITCH;
+  static constexpr int NCB = 4, HCB = 2, NK = 25;
+  static constexpr int NSL = 2 * NCB * PLANE;                   // LDS slots of a halo tile (parity-split columns): 3520
+  static constexpr int NINST = (NSL + 63) / 64;                 // 55
+  static constexpr int KW = (NINST + 3) / 4;                    // DMA instructions per wave: 14
+  static constexpr int BUF = KW * 4 * 64;
+  static constexpr int RED_FLOATS = 4 * 16 * 64;
+  static constexpr size_t LDS_BYTES = (size_t)2 * BUF * 16 + (size_t)RED_FLOATS * 4 + 32 * 4 + 16;
+  // padded input grid for an Ho x Wo output: two zero rows above the image; EIGHT zero columns to its left (two are read)
+  // and a row pitch that is a multiple of 16 slots, so that the producer's 512-byte runs stay 128-byte aligned — with a
+  // two-column border and an odd pitch k_down0_f16, which is bound by its 59 MB per pair of stores, took 25 % longer
+  static constexpr int PADY = 2, PADX = 8;
+  __host__ __device__ static int ph(int Ho) { return (Ho + TR - 1) / TR * (2 * TR) + 3; }
+  __host__ __device__ static int pw(int Wo) { return (Wo + TC - 1) / TC * (2 * TC) + 16; }
+  static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
+  static_assert((2 * PITCH) % 16 == 0, "the two rows of a segment land on disjoint banks");
+};
+
+__global__ __launch_bounds__(256, 1) void k_down_x3s_dma(ConvArgs a, const uint4* __restrict__ vin, SlotGeom gi, SlotGeom go) {
+  using T = DownDma;
+  constexpr int BUF = T::BUF, KW = T::KW;
+  extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
+  float* s_red = reinterpret_cast<float*>(smem4 + 2 * BUF);
+  float* s_bias = s_red + T::RED_FLOATS;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int khalf = wave >> 1, pset = wave & 1;
+  const int gh = lane >> 5, j = lane & 31;
+
+  half8 wh[T::NK], wl[T::NK];
+  {
+    const uint4* wsrc = reinterpret_cast<const uint4*>(a.wpk) + (size_t)khalf * T::NK * 2 * 64 + lane;
+#pragma unroll
+    for (int k = 0; k < T::NK; ++k) {
+      const uint4 x = wsrc[(2 * k) * 64], y = wsrc[(2 * k + 1) * 64];
+      wh[k] = *reinterpret_cast<const half8*>(&x);
+      wl[k] = *reinterpret_cast<const half8*>(&y);
+    }
+#pragma unroll
+    for (int k = 0; k < T::NK; ++k) asm volatile("" : "+a"(wh[k]), "+a"(wl[k]));
+  }
+  const int pr = j / 16, pc = j % 16;
+  const int srow = pset * 2 + pr;                      // output row of the tile this lane computes
+  const int lane_base = (khalf * T::HCB + gh) * T::PLANE + 2 * srow * T::PITCH + pc;
+  if (tid < kC) s_bias[tid] = a.bias[tid];
+
+  const unsigned iphw = (unsigned)(gi.PH * gi.PW), ophw = (unsigned)(go.PH * go.PW);
+  unsigned srel[KW];
+#pragma unroll
+  for (int e = 0; e < KW; ++e) {
+    const int L = (4 * e + wave) * 64 + lane;
+    const int part = L / (T::NCB * T::PLANE);
+    const int rem = L - part * (T::NCB * T::PLANE);
+    const int vb = rem / T::PLANE;
+    const int rc = rem - vb * T::PLANE;
+    const int r = rc / T::PITCH, di = rc - r * T::PITCH;
+    const int cc = di < T::HALF ? 2 * di : 2 * (di - T::HALF) + 1;       // LDS keeps even and odd columns apart
+    srel[e] = (L < T::NSL && cc < T::COLS_IN) ? (unsigned)(((vb * 2 + part) * (int)iphw + r * gi.PW + cc) * 16) : 0u;
+  }
+  const FastDiv div_tx((unsigned)a.tiles_x), div_ty((unsigned)a.tiles_y);
+  auto tile_off = [&](int tile, int& img, int& ty, int& tx) {
+    unsigned txu, tyu;
+    const unsigned t2 = div_tx.divmod((unsigned)tile, txu);
+    img = (int)div_ty.divmod(t2, tyu);
+    ty = (int)tyu;
+    tx = (int)txu;
+    return (unsigned)__builtin_amdgcn_readfirstlane(
+        (int)(((unsigned)img * 8u * iphw + (unsigned)(ty * 2 * T::TR * gi.PW + tx * 2 * T::TC + (T::PADX - 2))) * 16u));
+  };
+  const unsigned lds0 = lds_addr(smem4);
+  auto dma = [&](int e, int buf, unsigned toff) {
+    glds16(lds0 + (unsigned)(buf * BUF * 16) + (unsigned)((4 * e + wave) * 1024), srel[e] + toff, vin);
+  };
+
+  const int total = a.tiles_x * a.tiles_y * a.nimg;
+  const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, nlb = gridDim.x >> 3;
+  const int t_end = (int)((long)(xcd + 1) * total / 8);
+  int tile = (int)((long)xcd * total / 8) + lb;
+  if (tile >= t_end) return;
+  int c_img, c_ty, c_tx;
+  unsigned toff = tile_off(tile, c_img, c_ty, c_tx);
+#pragma unroll
+  for (int e = 0; e < KW; ++e) dma(e, 0, toff);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const float slope = a.lrelu ? kSlope : 1.0f;
+  float fin[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) fin[r] = 0.f;
+  bool d_in = false;
+  int pending = 0;
+  char* d_base = reinterpret_cast<char*>(a.out);
+  unsigned d_off = 0;
+  auto flush = [&](int q) {
+    half4 hh, hl;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = fin[4 * q + e];
+      v = fmaxf(v, v * slope);
+      const _Float16 hi = (_Float16)v;
+      hh[e] = hi;
+      hl[e] = (_Float16)((v - (float)hi) * kSplitScale);
+    }
+    if (d_in) {
+      char* oq = d_base + (size_t)(2 * q) * ophw * 16;
+      __builtin_nontemporal_store(hh, reinterpret_cast<half4*>(oq + d_off));
+      __builtin_nontemporal_store(hl, reinterpret_cast<half4*>(oq + (size_t)ophw * 16 + d_off));
+    }
+  };
+  auto koff_of = [&](int k) {
+    const int ky = k / 5, kx = k - ky * 5;
+    return ky * T::PITCH + (kx & 1) * T::HALF + (kx >> 1);
+  };
+
+  int cur = 0;
+  for (int it = 0; tile < t_end; tile += nlb, ++it) {
+    const int nxt = tile + nlb;
+    const int more = __builtin_amdgcn_readfirstlane(nxt < t_end ? 1 : 0);
+    int n_img = c_img, n_ty = c_ty, n_tx = c_tx;
+    const unsigned ntoff = more ? tile_off(nxt, n_img, n_ty, n_tx) : toff;
+    const uint4* s_xh = smem4 + cur * BUF + lane_base;
+    const uint4* s_xl = s_xh + T::NCB * T::PLANE;
+
+    f32x16 acc0, acc1, zero;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+    constexpr int PD = 3;                 // B fragments in flight: one wave per SIMD, nobody else hides the LDS latency
+    uint4 bh[PD + 1], bl[PD + 1];
+#pragma unroll
+    for (int d = 0; d < PD; ++d) {
+      bh[d] = s_xh[koff_of(d)];
+      bl[d] = s_xl[koff_of(d)];
+    }
+#pragma unroll
+    for (int k = 0; k < T::NK; ++k) {
+      if (k + PD < T::NK) {
+        bh[(k + PD) % (PD + 1)] = s_xh[koff_of(k + PD)];
+        bl[(k + PD) % (PD + 1)] = s_xl[koff_of(k + PD)];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const half8 xh = *reinterpret_cast<const half8*>(&bh[k % (PD + 1)]);
+      const half8 xl = *reinterpret_cast<const half8*>(&bl[k % (PD + 1)]);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[k], xh, k == 0 ? zero : acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[k], xh, k == 0 ? zero : acc1, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[k], xl, acc1, 0, 0, 0);
+      if (k < KW) dma(k, cur ^ 1, ntoff);
+      if (k >= 2 && k < 6 && pending) flush(k - 2);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    pending = 0;
+    const int fin_role = ((it & 1) == khalf) ? 1 : 0;        // wave-uniform: this round's finisher of the pair
+    if (!fin_role) {
+      float* dst = s_red + (size_t)wave * 16 * 64 + lane;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[r * 64] = acc0[r] + acc1[r] * kSplitInv;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next tile has landed
+    lds_barrier();                      // partials visible; every wave is done with buffer `cur`
+    if (fin_role) {
+      const float* src = s_red + (size_t)(wave ^ 2) * 16 * 64 + lane;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) fin[r] = acc0[r] + acc1[r] * kSplitInv + src[r * 64] + s_bias[(r & 3) + 8 * (r >> 2) + 4 * gh];
+      const int e_y = c_ty * T::TR + srow;
+      const int e_x = c_tx * T::TC + pc;
+      d_in = e_y < a.Ho && e_x < a.Wo;
+      d_base = reinterpret_cast<char*>(a.out) + (size_t)c_img * 8 * ophw * 16;
+      d_off = ((unsigned)(e_y + go.py) * (unsigned)go.PW + (unsigned)(e_x + go.px)) * 16u + gh * 8u;
+      pending = 1;
+    }
+    lds_barrier();                      // partial buffer free
+    cur ^= 1;
+    toff = ntoff;
+    c_img = n_img;
+    c_ty = n_ty;
+    c_tx = n_tx;
+  }
+  if (pending) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) flush(q);
+  }
+}
+
 }  // namespace sn

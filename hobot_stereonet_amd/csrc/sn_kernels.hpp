@@ -830,7 +830,8 @@ __global__ __launch_bounds__(256, 2) void k_down0_f16(const int8_t* __restrict__
                                                    const uint4* __restrict__ wfrag,   // [8][hi|lo][64]
                                                    const float* __restrict__ bias, float* __restrict__ out, int Ho,
                                                    int Wo, int tiles_x, int tiles_y, int nimg, int lrelu,
-                                                   int al4) {   // W % 4 == 0 and in6 4-byte aligned: dword loads
+                                                   int al4,     // W % 4 == 0 and in6 4-byte aligned: dword loads
+                                                   int oPH, int oPW, int opy, int opx) {   // output slot grid and image origin (plain: Ho, Wo, 0, 0)
   using T = Down0Tile<TC>;
   extern __shared__ __attribute__((aligned(16))) _Float16 s_x[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -916,9 +917,9 @@ __global__ __launch_bounds__(256, 2) void k_down0_f16(const int8_t* __restrict__
 #pragma unroll
   for (int s = 0; s < T::SPW; ++s) {
     const int seg = wave * T::SPW + s;
-    io_voff[s] = ((unsigned)(seg / T::CSEG) * (unsigned)Wo + (unsigned)((seg % T::CSEG) * 32 + j)) * 16u + g * 8u;
+    io_voff[s] = ((unsigned)(seg / T::CSEG) * (unsigned)oPW + (unsigned)((seg % T::CSEG) * 32 + j)) * 16u + g * 8u;
   }
-  const size_t plane_b = (size_t)Ho * Wo * 16;                 // bytes of one (block, part) plane
+  const size_t plane_b = (size_t)oPH * oPW * 16;               // bytes of one (block, part) plane
   const float slope = lrelu ? kSlope : 1.0f;                  // max(v, v) = v: one code path
   f32x16 zero;
 #pragma unroll
@@ -953,7 +954,7 @@ __global__ __launch_bounds__(256, 2) void k_down0_f16(const int8_t* __restrict__
       const int y0 = ty * T::TR, x0 = tx * TC;
       const bool interior = y0 + T::TR <= Ho && x0 + TC <= Wo;             // wave-uniform
       // split-slot tensor for the next down-conv (see SlotIn / low_slot_index): [img][4 blocks][hi | lo][Ho][Wo]
-      char* const tbase = reinterpret_cast<char*>(out) + (size_t)img * 8 * plane_b + ((size_t)y0 * Wo + x0) * 16;
+      char* const tbase = reinterpret_cast<char*>(out) + (size_t)img * 8 * plane_b + ((size_t)(y0 + opy) * oPW + x0 + opx) * 16;
 #pragma unroll
       for (int s = 0; s < T::SPW; ++s) {
         bool ok = true;

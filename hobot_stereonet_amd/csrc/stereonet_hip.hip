@@ -72,7 +72,8 @@ struct Workspace {          // activations for up to `nb` pairs
   float* low[3] = {nullptr, nullptr, nullptr};
   float* feat = nullptr;
   float* vol[2] = {nullptr, nullptr};
-  uint4* volp[2] = {nullptr, nullptr};   // zero-bordered split-slot volumes of the aggregation layers (fp16 modes, VolPad)
+  uint4* volp[2] = {nullptr, nullptr};
+  uint4* downp[3] = {nullptr, nullptr, nullptr};   // zero-bordered inputs of down-convs 1..3 (fp16 modes, DownDma)   // zero-bordered split-slot volumes of the aggregation layers (fp16 modes, VolPad)
   float* cost = nullptr;     // [nb][Dl][hl][wl] (debug / parity)
   float* disp_low = nullptr;
   int ns = 1;                 // tower streams this workspace serves: one (x, t) activation pair per stream
@@ -347,7 +348,7 @@ hipError_t launch_refin_f16(hipStream_t st, const Down0F16& L, const float* bias
 }
 
 hipError_t launch_down0_f16(hipStream_t st, const Down0F16& L, const float* bias, const int8_t* in6, int H, int W,
-                            int nimg, int Ho, int Wo, float* out, int num_cu) {
+                            int nimg, int Ho, int Wo, float* out, int num_cu, const SlotGeom* og = nullptr) {
   constexpr int TC = 32;
   using T = Down0Tile<TC>;
   const int tiles_x = (Wo + TC - 1) / TC, tiles_y = (Ho + T::TR - 1) / T::TR;
@@ -356,7 +357,7 @@ hipError_t launch_down0_f16(hipStream_t st, const Down0F16& L, const float* bias
   if (blocks > total) blocks = total;
   const int al4 = (W % 4 == 0) && (reinterpret_cast<uintptr_t>(in6) % 4 == 0);
   hipLaunchKernelGGL((k_down0_f16<TC>), dim3(blocks), dim3(256), T::LDS_BYTES, st, in6, H, W, L.wfrag, bias, out, Ho, Wo,
-                     tiles_x, tiles_y, nimg, 0, al4);
+                     tiles_x, tiles_y, nimg, 0, al4, og ? og->PH : Ho, og ? og->PW : Wo, og ? og->py : 0, og ? og->px : 0);
   return hipGetLastError();
 }
 
@@ -435,6 +436,45 @@ hipError_t launch_agg_dma(hipStream_t st, const ConvLayer& L, const uint4* vin, 
   if (blocks > (total + 7) / 8 * 8) blocks = (total + 7) / 8 * 8;
   blocks = (blocks + 7) / 8 * 8;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), AggDma::LDS_BYTES, st, a, vin, g);
+  return hipGetLastError();
+}
+
+// SN_DOWN_DMA=0: down-convs 1..3 on the plain split-slot tensors (k_conv_x3s) instead of the zero-bordered ones
+bool down_dma_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("SN_DOWN_DMA");
+    return !(e && *e == '0');
+  }();
+  return on;
+}
+
+// zero-bordered input grid of a 5x5 stride-2 down-conv with an Ho x Wo output
+SlotGeom down_in_geom(int Ho, int Wo) { return SlotGeom{DownDma::ph(Ho), DownDma::pw(Wo), DownDma::PADY, DownDma::PADX}; }
+
+// 5x5 stride-2 32->32 down-conv on a zero-bordered split-slot input (sn_agg_dma.hpp); go = the output tensor's grid
+hipError_t launch_down_dma(hipStream_t st, const ConvLayer& L, const uint4* vin, int nimg, int Ho, int Wo, void* out,
+                           const SlotGeom& go, bool lrelu, int num_cu) {
+  ConvArgs a{};
+  a.wpk = reinterpret_cast<const float*>(L.wx3);
+  a.bias = L.bias;
+  a.out = reinterpret_cast<float*>(out);
+  a.res = nullptr;
+  a.nimg = nimg;
+  a.cin_pad = L.cin_pad;
+  a.Ho = Ho;
+  a.Wo = Wo;
+  a.dil = 1;
+  a.pad = 2;
+  a.lrelu = lrelu ? 1 : 0;
+  a.tiles_x = (Wo + DownDma::TC - 1) / DownDma::TC;
+  a.tiles_y = (Ho + DownDma::TR - 1) / DownDma::TR;
+  hipError_t e = ensure_lds_attr(k_down_x3s_dma, (int)DownDma::LDS_BYTES);
+  if (e != hipSuccess) return e;
+  const int total = a.tiles_x * a.tiles_y * nimg;
+  int blocks = num_cu;
+  if (blocks > (total + 7) / 8 * 8) blocks = (total + 7) / 8 * 8;
+  blocks = (blocks + 7) / 8 * 8;
+  hipLaunchKernelGGL(k_down_x3s_dma, dim3(blocks), dim3(256), DownDma::LDS_BYTES, st, a, vin, down_in_geom(Ho, Wo), go);
   return hipGetLastError();
 }
 
@@ -900,6 +940,19 @@ int alloc_ws(sn_handle* h, Workspace* ws, int nb, int rb, int ns) {
   for (int k = 0; k < 3; ++k) HIP_TRY(h, dalloc(&ws->low[k], (size_t)2 * pb * kC * hw));
   HIP_TRY(h, dalloc(&ws->feat, (size_t)2 * pb * kC * hw));
   for (int k = 0; k < 2; ++k) HIP_TRY(h, dalloc(&ws->vol[k], (size_t)pb * h->Dl * kC * hw));
+  if (h->precision != SN_PREC_FP32 && down_dma_enabled()) {
+    size_t bytes[3];
+    bool fits = true;
+    for (int k = 0; k < 3; ++k) {      // input of down-conv k + 1: output grid (Hp, Wp) >> (k + 2)
+      const SlotGeom g = down_in_geom(h->Hp >> (k + 2), h->Wp >> (k + 2));
+      bytes[k] = (size_t)2 * pb * 8 * g.PH * g.PW * sizeof(uint4);
+      fits = fits && bytes[k] < ((size_t)1 << 32);        // 32-bit byte offsets inside the kernel
+    }
+    for (int k = 0; k < 3 && fits; ++k) {
+      HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&ws->downp[k]), bytes[k]));
+      HIP_TRY(h, hipMemset(ws->downp[k], 0, bytes[k]));   // the borders stay zero: kernels write image pixels only
+    }
+  }
   if (h->precision != SN_PREC_FP32 && agg_dma_enabled()) {
     const VolPad g = vol_pad(h->Dl, h->hl, h->wl);
     const size_t bytes = g.planes(pb) * g.plane_slots() * sizeof(uint4);
@@ -959,6 +1012,7 @@ void free_ws(Workspace* ws) {
   hipFree(ws->feat);
   for (auto p : ws->vol) hipFree(p);
   for (auto p : ws->volp) hipFree(p);
+  for (auto p : ws->downp) hipFree(p);
   hipFree(ws->cost);
   hipFree(ws->disp_low);
   for (auto p : ws->ref) hipFree(p);
@@ -989,6 +1043,18 @@ int lowres_slots(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, con
   const int8_t* in = in6 + (size_t)p0 * 6 * HW;
   const int ncu = h->num_cu, ni = 2 * m;
   auto U4 = [](float* p) { return reinterpret_cast<const uint4*>(p); };
+  if (ws.downp[0] != nullptr) {       // zero-bordered tensors between the down-convs, LDS-DMA kernel
+    SlotGeom gin[3];
+    for (int i = 0; i < 3; ++i) gin[i] = down_in_geom(Hp >> (i + 2), Wp >> (i + 2));
+    HIP_TRY(h, launch_down0_f16(st, h->down0, h->down[0].bias, in, h->H, h->W, ni, Hp / 2, Wp / 2,
+                                reinterpret_cast<float*>(ws.downp[0]), ncu, &gin[0]));
+    for (int i = 0; i < 3; ++i) {
+      const int Ho = Hp >> (i + 2), Wo = Wp >> (i + 2);
+      const SlotGeom plain{Ho, Wo, 0, 0};
+      HIP_TRY(h, launch_down_dma(st, h->down[i + 1], ws.downp[i], ni, Ho, Wo, i < 2 ? (void*)ws.downp[i + 1] : (void*)ws.low[0],
+                                 i < 2 ? gin[i + 1] : plain, false, ncu));
+    }
+  } else {
   HIP_TRY(h, launch_down0_f16(st, h->down0, h->down[0].bias, in, h->H, h->W, ni, Hp / 2, Wp / 2, ws.down[0], ncu));
   {
     float* src[3] = {ws.down[0], ws.down[1], ws.down[2]};
@@ -999,6 +1065,7 @@ int lowres_slots(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, con
       HIP_TRY(h, (launch_conv_x3s<5, 2, 32, 4, 32, 32, 1, true, SlotIn>(st, h->down[i + 1], ld, ni, Hi / 2, Wi / 2, dst[i],
                                                                        nullptr, false, ncu)));
     }
+  }
   }
   float* x = ws.low[0];
   float* t = ws.low[1];
@@ -2109,8 +2176,10 @@ int sn_dbg_conv2d(sn_handle* h, const float* in, int cin, int h_px, int w, const
   if (stride == 2 && ((h_px & 1) || (w & 1))) return SN_ERR_ARG;
   const bool x3 = (lrelu & 2) != 0, slots = (lrelu & 4) != 0;
   const bool tower32 = (lrelu & 8) != 0;     // bit 3: the fp32 tower kernel (k_ref_conv_f32) instead of the generic one
+  const bool dma = (lrelu & 16) != 0;        // bit 4 (5x5 stride 2 on slots): k_down_x3s_dma on zero-bordered tensors
   lrelu &= 1;
   if (x3 != slots || (x3 && !(cin == kC && dil == 1))) return SN_ERR_ARG;     // the split-operand kernel reads slots
+  if (dma && !(slots && k == 5 && !residual)) return SN_ERR_ARG;
   if (slots) {          // split-slot tensors in and out through the weights-stationary kernel (fp16 modes' low-res path)
     ConvLayer Ls;
     HostLayer hls{wt, bias, kC, cin, taps};
@@ -2128,6 +2197,42 @@ int sn_dbg_conv2d(sn_handle* h, const float* in, int cin, int h_px, int w, const
       host_to_slots(residual, 1, Ho, Wo, hres);
       HIP_TRY(h, hipMemcpy(dout, hres.data(), hres.size() * 2, hipMemcpyHostToDevice));
       dres = reinterpret_cast<const float*>(dout);
+    }
+    if (dma) {      // zero-bordered input (two pixels), an output grid with a border of its own (3 pixels of slack)
+      const SlotGeom gi = down_in_geom(Ho, Wo), go{Ho + 5, Wo + 7, 2, 3};
+      const size_t iphw = (size_t)gi.PH * gi.PW, ophw = (size_t)go.PH * go.PW;
+      std::vector<_Float16> pin(8 * iphw * 8, (_Float16)0.f), pout(8 * ophw * 8);
+      for (int img = 0; img < 8; ++img)      // (block, part) images
+        for (int y = 0; y < h_px; ++y)
+          memcpy(&pin[((size_t)img * iphw + (size_t)(y + gi.py) * gi.PW + gi.px) * 8], &hin[((size_t)img * h_px + y) * w * 8], (size_t)w * 16);
+      uint4 *pdin = nullptr, *pdout = nullptr;
+      HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&pdin), pin.size() * 2));
+      HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&pdout), pout.size() * 2));
+      HIP_TRY(h, hipMemcpy(pdin, pin.data(), pin.size() * 2, hipMemcpyHostToDevice));
+      HIP_TRY(h, hipMemset(pdout, 0, pout.size() * 2));
+      HIP_TRY(h, launch_down_dma(h->stream, Ls, pdin, 1, Ho, Wo, pdout, go, lrelu != 0, h->num_cu));
+      HIP_TRY(h, hipStreamSynchronize(h->stream));
+      HIP_TRY(h, hipMemcpy(pout.data(), pdout, pout.size() * 2, hipMemcpyDeviceToHost));
+      hipFree(pdin);
+      hipFree(pdout);
+      for (int img = 0; img < 8; ++img)
+        for (int y = 0; y < Ho; ++y)
+          memcpy(&hout[((size_t)img * Ho + y) * Wo * 8], &pout[((size_t)img * ophw + (size_t)(y + go.py) * go.PW + go.px) * 8], (size_t)Wo * 16);
+      for (size_t i = 0; i < pout.size(); ++i) {
+        const size_t sl = i / 8, y = (sl % ophw) / go.PW, x = sl % go.PW;
+        const bool inside = y >= (size_t)go.py && y < (size_t)Ho + go.py && x >= (size_t)go.px && x < (size_t)Wo + go.px;
+        if (!inside && (float)pout[i] != 0.f) {
+          set_err(h, "k_down_x3s_dma wrote outside the image");
+          return SN_ERR_DEVICE;
+        }
+      }
+      host_from_slots(hout, 1, Ho, Wo, out);
+      hipFree(din);
+      hipFree(dout);
+      hipFree(Ls.wx3);
+      hipFree(Ls.wpk);
+      hipFree(Ls.bias);
+      return SN_OK;
     }
     SlotIn ls{din, 0, h_px, w};
     hipError_t e2 = k == 5 ? launch_conv_x3s<5, 2, 32, 4, 32, 32, 1, true, SlotIn>(h->stream, Ls, ls, 1, Ho, Wo, reinterpret_cast<float*>(dout), dres, lrelu != 0, h->num_cu)

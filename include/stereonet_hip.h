@@ -210,7 +210,8 @@ int sn_get_dominant_kernel(sn_handle *h, char *name, size_t name_cap, int *launc
  * lrelu bit 0 = LeakyReLU, bit 1 = use the split-operand fp16 kernel of the fp16 modes (cin 32; 3x3 stride 1 or
  * 5x5 stride 2), bit 2 (with bit 1) = run it on split-slot tensors (hi/lo fp16, the fp16 modes' low-resolution
  * activation format) through the weights-stationary kernel; the hook converts to and from that layout; bit 3 = the
- * fp32 tower kernel k_ref_conv_f32 (cin 32, 3x3, w % 4 == 0) instead of the generic fp32 kernel. */
+ * fp32 tower kernel k_ref_conv_f32 (cin 32, 3x3, w % 4 == 0) instead of the generic fp32 kernel; bit 4 (with bits 1
+ * and 2, 5x5 stride 2, no residual) = the down-conv kernel of the zero-bordered tensors (k_down_x3s_dma). */
 int sn_dbg_conv2d(sn_handle *h, const float *in, int cin, int h_px, int w, const float *wt,
                   const float *bias, int k, int stride, int dil, int lrelu, const float *residual,
                   float *out);

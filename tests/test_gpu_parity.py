@@ -340,7 +340,7 @@ def test_lowres_split_conv3d(small_engine, oracle, d, h, w):
     assert np.array_equal(a_dma, a)
 
 
-@pytest.mark.parametrize("h,w", [(90, 160), (46, 82), (360, 640), (64, 96)])
+@pytest.mark.parametrize("h,w", [(90, 160), (46, 82), (360, 640), (64, 96), (8, 32), (2, 2), (30, 70)])
 def test_lowres_split_conv5x5_stride2(small_engine, oracle, h, w):
     rng = np.random.default_rng(h * 3 + w)
     x = rng.standard_normal((32, h, w)).astype(np.float32)
@@ -350,3 +350,10 @@ def test_lowres_split_conv5x5_stride2(small_engine, oracle, h, w):
     got = small_engine.dbg_conv2d(x, wt, b, 5, 2, 1, x3=True, slots=True)
     assert got.shape == ref.shape
     assert rel_err(got, ref) < 4e-6
+    # the same layer on zero-bordered tensors (LDS-DMA staging, 4 x 16 double-buffered tiles, deferred epilogue): the same
+    # K order and MFMAs per output, so the same bits
+    got_dma = small_engine.dbg_conv2d(x, wt, b, 5, 2, 1, x3=True, slots=True, dma=True)
+    assert np.array_equal(got_dma, got)
+    a = small_engine.dbg_conv2d(x, wt, b, 5, 2, 1, lrelu=True, x3=True, slots=True)
+    a_dma = small_engine.dbg_conv2d(x, wt, b, 5, 2, 1, lrelu=True, x3=True, slots=True, dma=True)
+    assert np.array_equal(a_dma, a)
