@@ -447,24 +447,29 @@ __global__ __launch_bounds__(256, 1) void k_down_x3s_dma(ConvArgs a, const uint4
   };
 
   int cur = 0;
+  constexpr int PD = 3;                   // B fragments in flight: one wave per SIMD, nobody else hides the LDS latency
+  uint4 bh[PD + 1], bl[PD + 1];
+  auto prefetch = [&](int buf) {          // the first PD fragments of a tile: issued as soon as the tile has landed
+    const uint4* xh_ = smem4 + buf * BUF + lane_base;
+    const uint4* xl_ = xh_ + T::NCB * T::PLANE;
+#pragma unroll
+    for (int d = 0; d < PD; ++d) {
+      bh[d] = xh_[koff_of(d)];
+      bl[d] = xl_[koff_of(d)];
+    }
+  };
+  prefetch(0);
   for (int it = 0; tile < t_end; tile += nlb, ++it) {
     const int nxt = tile + nlb;
     const int more = __builtin_amdgcn_readfirstlane(nxt < t_end ? 1 : 0);
     int n_img = c_img, n_ty = c_ty, n_tx = c_tx;
-    const unsigned ntoff = more ? tile_off(nxt, n_img, n_ty, n_tx) : toff;
+    unsigned ntoff = toff;
     const uint4* s_xh = smem4 + cur * BUF + lane_base;
     const uint4* s_xl = s_xh + T::NCB * T::PLANE;
 
     f32x16 acc0, acc1, zero;
 #pragma unroll
     for (int r = 0; r < 16; ++r) zero[r] = 0.f;
-    constexpr int PD = 3;                 // B fragments in flight: one wave per SIMD, nobody else hides the LDS latency
-    uint4 bh[PD + 1], bl[PD + 1];
-#pragma unroll
-    for (int d = 0; d < PD; ++d) {
-      bh[d] = s_xh[koff_of(d)];
-      bl[d] = s_xl[koff_of(d)];
-    }
 #pragma unroll
     for (int k = 0; k < T::NK; ++k) {
       if (k + PD < T::NK) {
@@ -477,7 +482,9 @@ __global__ __launch_bounds__(256, 1) void k_down_x3s_dma(ConvArgs a, const uint4
       acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[k], xh, k == 0 ? zero : acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[k], xh, k == 0 ? zero : acc1, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[k], xl, acc1, 0, 0, 0);
-      if (k < KW) dma(k, cur ^ 1, ntoff);
+      // the next tile's coordinates are worked out behind the first MFMAs, its DMA starts one K-step later
+      if (k == 0 && more) ntoff = tile_off(nxt, n_img, n_ty, n_tx);
+      if (k >= 1 && k <= KW) dma(k - 1, cur ^ 1, ntoff);
       if (k >= 2 && k < 6 && pending) flush(k - 2);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -489,7 +496,11 @@ __global__ __launch_bounds__(256, 1) void k_down_x3s_dma(ConvArgs a, const uint4
       for (int r = 0; r < 16; ++r) dst[r * 64] = acc0[r] + acc1[r] * kSplitInv;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next tile has landed
-    lds_barrier();                      // partials visible; every wave is done with buffer `cur`
+    // ONE barrier per round: partials visible, every wave done with buffer `cur`.  The partial buffer needs no second
+    // one: a wave writes its region every other round only (the roles alternate), and the barrier of the round in
+    // between orders its partner's read before that write.
+    lds_barrier();
+    prefetch(cur ^ 1);
     if (fin_role) {
       const float* src = s_red + (size_t)(wave ^ 2) * 16 * 64 + lane;
 #pragma unroll
@@ -501,7 +512,6 @@ __global__ __launch_bounds__(256, 1) void k_down_x3s_dma(ConvArgs a, const uint4
       d_off = ((unsigned)(e_y + go.py) * (unsigned)go.PW + (unsigned)(e_x + go.px)) * 16u + gh * 8u;
       pending = 1;
     }
-    lds_barrier();                      // partial buffer free
     cur ^= 1;
     toff = ntoff;
     c_img = n_img;
