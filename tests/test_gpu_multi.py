@@ -172,8 +172,8 @@ np.save(sys.argv[3], disp)
                                        ({"SN_FUSE": "0", "SN_HEAD_FUSE": "0"}, True), ({"SN_STREAM_DIL": "2", "SN_HEAD_FUSE": "0", "SN_STREAM_LAST": "0"}, True),
                                        # ... except through the head: fused with the last conv it sums in another order
                                        ({"SN_FUSE": "0"}, False), ({"SN_STREAM_LAST": "0"}, False), ({"SN_STREAM_WGS": "100"}, True),
-                                       # aggregation layers on the plain volumes (k_conv_x3s) instead of the zero-bordered ones
-                                       ({"SN_AGG_DMA": "0"}, True)])
+                                       # aggregation layers / down-convs on the plain tensors (k_conv_x3s) instead of the zero-bordered ones
+                                       ({"SN_AGG_DMA": "0"}, True), ({"SN_DOWN_DMA": "0"}, True), ({"SN_AGG_DMA": "0", "SN_DOWN_DMA": "0"}, True)])
 def test_diagnostic_switches_run_the_same_network(model_factory, oracle, weights_blob, tmp_path, env, exact):
     """The library's diagnostic environment switches select other schedules / kernel pairings of the
     SAME arithmetic: stream layout switches must be bit-identical to the default, kernel pairings within the EPE bar."""
