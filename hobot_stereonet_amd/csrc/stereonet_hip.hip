@@ -935,23 +935,23 @@ int alloc_ws(sn_handle* h, Workspace* ws, int nb, int rb, int ns) {
   const int pb = ws->pb;
   const size_t HW = (size_t)h->H * h->W, HWp = (size_t)h->Hp * h->Wp, hw = (size_t)h->hl * h->wl;
   HIP_TRY(h, dalloc(&ws->in6, (size_t)nb * 6 * HW));
-  for (int k = 0; k < 3; ++k)
+  // fp16 modes keep the tensors between the down-convs in the zero-bordered layout (downp[], below) unless SN_DOWN_DMA=0
+  // or a tensor would not fit 32-bit byte offsets; the plain ones are then not allocated at all (0.9 GB per 16-pair piece)
+  bool padded_down = h->precision != SN_PREC_FP32 && down_dma_enabled();
+  size_t downp_bytes[3] = {0, 0, 0};
+  for (int k = 0; k < 3 && padded_down; ++k) {      // input of down-conv k + 1: output grid (Hp, Wp) >> (k + 2)
+    const SlotGeom g = down_in_geom(h->Hp >> (k + 2), h->Wp >> (k + 2));
+    downp_bytes[k] = (size_t)2 * pb * 8 * g.PH * g.PW * sizeof(uint4);
+    padded_down = downp_bytes[k] < ((size_t)1 << 32);
+  }
+  for (int k = 0; k < 3 && !padded_down; ++k)
     HIP_TRY(h, dalloc(&ws->down[k], (size_t)2 * pb * kC * (HWp >> (2 * (k + 1)))));
   for (int k = 0; k < 3; ++k) HIP_TRY(h, dalloc(&ws->low[k], (size_t)2 * pb * kC * hw));
   HIP_TRY(h, dalloc(&ws->feat, (size_t)2 * pb * kC * hw));
   for (int k = 0; k < 2; ++k) HIP_TRY(h, dalloc(&ws->vol[k], (size_t)pb * h->Dl * kC * hw));
-  if (h->precision != SN_PREC_FP32 && down_dma_enabled()) {
-    size_t bytes[3];
-    bool fits = true;
-    for (int k = 0; k < 3; ++k) {      // input of down-conv k + 1: output grid (Hp, Wp) >> (k + 2)
-      const SlotGeom g = down_in_geom(h->Hp >> (k + 2), h->Wp >> (k + 2));
-      bytes[k] = (size_t)2 * pb * 8 * g.PH * g.PW * sizeof(uint4);
-      fits = fits && bytes[k] < ((size_t)1 << 32);        // 32-bit byte offsets inside the kernel
-    }
-    for (int k = 0; k < 3 && fits; ++k) {
-      HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&ws->downp[k]), bytes[k]));
-      HIP_TRY(h, hipMemset(ws->downp[k], 0, bytes[k]));   // the borders stay zero: kernels write image pixels only
-    }
+  for (int k = 0; k < 3 && padded_down; ++k) {
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&ws->downp[k]), downp_bytes[k]));
+    HIP_TRY(h, hipMemset(ws->downp[k], 0, downp_bytes[k]));   // the borders stay zero: kernels write image pixels only
   }
   if (h->precision != SN_PREC_FP32 && agg_dma_enabled()) {
     const VolPad g = vol_pad(h->Dl, h->hl, h->wl);
