@@ -350,7 +350,7 @@ class StereoNetHIP:
         return out
 
     def dbg_ref_block_f16(self, x, w1, b1, w2, b2, dil=1, fused=0):
-        """fused: 0 = two conv launches, 1 = tile-fused kernel (dilation 1 only), 2 = row-streaming fused kernel (dilation 1, 2)"""
+        """fused: 0 = two conv launches, 2 = row-streaming fused kernel (every dilation: 1, 2, 4, 8)"""
         dil = dil | (fused << 8)
         a = [np.ascontiguousarray(v, np.float32) for v in (x, w1, b1, w2, b2)]
         _, h, w = a[0].shape

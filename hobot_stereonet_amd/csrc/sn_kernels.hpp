@@ -1855,262 +1855,6 @@ __global__ __launch_bounds__(256, 2) void k_ref_conv_head_f16(const uint4* __res
 }
 
 // ------------------------------------------------------------------------------------------
-// Fused residual block, third form: sized so that TWO workgroups fit on a CU (this round's measurements: one
-// workgroup per CU is what held the first two fused kernels and the dilated v2 variants back).
-//   output tile 6 x 62, t on 8 x 64 (16 segments = 4 per wave), x on 10 x 66; ONE x tile in LDS (both channel
-//   halves, 43 KB) + the t tile (34 KB) = 77 KB; weights of both convs in registers (144), biases in LDS.
-//   The x tile is dead after stage 1 (the residual is re-read from global memory, L2-hot, as 8-byte loads issued
-//   BEFORE the next DMA group so the counted vmcnt retires them without draining it), so the next tile's x streams
-//   in during stage 2; the second resident workgroup covers what is left of the DMA latency.
-// VMEM order per tile and wave: [12 residual loads][2*KW DMA][12 stores]; tile start waits vmcnt(12).
-// ------------------------------------------------------------------------------------------
-struct FusedHTile {
-  static constexpr int TH = 6, TWO = 62;
-  static constexpr int RT = TH + 2, CT = 64;
-  static constexpr int RX = TH + 4, CX = 66;
-  static constexpr int PX = RX * CX, PT = RT * CT;
-  static constexpr int XHALF = 2 * PX;
-  static constexpr int NINST = (XHALF + 63) / 64;
-  static constexpr int KW = (NINST + 3) / 4;
-  static constexpr int XBUF = NINST * 64;
-  static constexpr int TBUF = 4 * PT + 64;
-  static constexpr int LDS_BYTES = (2 * XBUF + TBUF) * 16 + 64 * 4;      // + both bias vectors
-  static constexpr int S1 = RT * 2 / 4, S2 = TH * 2 / 4;
-  static constexpr int NSTORE = 4 * S2;
-  static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
-};
-
-__global__ __launch_bounds__(256, 2) void k_ref_block_f16_h(const uint4* __restrict__ xin, uint4* __restrict__ yout,
-                                                            const uint4* __restrict__ wfrag1, const float* __restrict__ bias1,
-                                                            const uint4* __restrict__ wfrag2, const float* __restrict__ bias2,
-                                                            RefGeom g, int nimg, uint4* /*zero_slot*/) {
-  using T = FusedHTile;
-  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
-  uint4* xbuf = lds;                       // [kk][XBUF]
-  uint4* tbuf = lds + 2 * T::XBUF;         // t tile [4 blocks][RT][CT]
-  float* s_b = reinterpret_cast<float*>(tbuf + T::TBUF);     // bias1[32], bias2[32]
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int j = lane & 31, gh = lane >> 5;
-
-  half8 w1[18], w2[18];
-#pragma unroll
-  for (int i = 0; i < 18; ++i) {
-    const uint4 a = wfrag1[i * 64 + lane], b = wfrag2[i * 64 + lane];
-    w1[i] = *reinterpret_cast<const half8*>(&a);
-    w2[i] = *reinterpret_cast<const half8*>(&b);
-  }
-  if (tid < 32) s_b[tid] = bias1[tid];
-  else if (tid < 64) s_b[tid] = bias2[tid - 32];
-#pragma unroll
-  for (int i = 0; i < 18; ++i) {
-    asm volatile("" : "+v"(w1[i]));
-    asm volatile("" : "+v"(w2[i]));
-  }
-
-  const int per_img = g.tiles_x * g.tiles_y;
-  const int total = per_img * nimg;
-  const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, nlb = gridDim.x >> 3;
-  const int t_begin = (int)((long)xcd * total / 8), t_end = (int)((long)(xcd + 1) * total / 8);
-  const int t0 = t_begin + lb;
-  if (t0 >= t_end) return;
-  const int ntiles = (t_end - t0 + nlb - 1) / nlb;
-
-  auto tile_xy = [&](int ti, int& img, int& y0, int& x0) {
-    const int t = t0 + ti * nlb;
-    img = t / per_img;
-    const int rem = t - img * per_img;
-    const int ty = rem / g.tiles_x;
-    y0 = ty * T::TH;
-    x0 = (rem - ty * g.tiles_x) * T::TWO;
-  };
-  // fixed per-lane slot offsets of the DMA instructions of this wave (relative to the tile's x origin)
-  unsigned dma_off[T::KW];
-#pragma unroll
-  for (int k = 0; k < T::KW; ++k) {
-    int i = wave + 4 * k;
-    i = i < T::NINST ? i : T::NINST - 1;
-    int s = i * 64 + lane;
-    s = s < T::XHALF ? s : T::XHALF - 1;
-    const int pc = s / T::PX;
-    const int rem = s - pc * T::PX;
-    const int r = rem / T::CX;
-    const int c = rem - r * T::CX;
-    dma_off[k] = ((unsigned)pc * g.Hs + r) * g.Ws + c;
-  }
-  // Addressing as in k_ref_conv_f16_v2: every global address is a uniform 32-bit byte offset of the tile (SGPRs,
-  // once per tile) plus a per-lane 32-bit byte offset that never changes (computed here once).  The phase timing
-  // of the first version of this kernel showed 5 k cycles of address arithmetic in stage 2 and 4 k in its epilogue
-  // against 5.3 k cycles of MFMAs per tile.
-  const unsigned plane_b = (unsigned)g.Hs * (unsigned)g.Ws * 16u;
-  auto tile_base = [&](int img, int y, int x) -> unsigned {
-    return (((unsigned)img * 4u * (unsigned)g.Hs + (unsigned)(y + kRefPad)) * (unsigned)g.Ws + (unsigned)(x + kRefPad)) * 16u;
-  };
-#pragma unroll
-  for (int k = 0; k < T::KW; ++k) dma_off[k] *= 16u;                           // bytes
-  unsigned t_off[T::S1];            // stage 1: LDS byte offset of this lane's t pixel (block 0, + gh * 8)
-#pragma unroll
-  for (int s = 0; s < T::S1; ++s) {
-    const int seg = wave * T::S1 + s;
-    t_off[s] = (unsigned)((seg >> 1) * T::CT + (seg & 1) * 32 + j) * 16u + gh * 8u;
-  }
-  // stage 2: output = residual byte offsets relative to the tile base (the two lanes per row that fall into the
-  // next tile's first columns read a valid slot there and simply do not store)
-  unsigned o_off[T::S2];
-  unsigned o_ok = 0;                     // bit s: this lane's column of segment s is one of the 62 real ones
-#pragma unroll
-  for (int s = 0; s < T::S2; ++s) {
-    const int seg = wave * T::S2 + s;
-    const int orow = seg >> 1, ocol = (seg & 1) * 32 + j;
-    o_off[s] = ((unsigned)orow * (unsigned)g.Ws + (unsigned)ocol) * 16u + gh * 8u;
-    o_ok |= ocol < T::TWO ? (1u << s) : 0u;
-  }
-  auto issue_x = [&](int img, int y0, int x0) {             // both channel halves of tile (img, y0, x0)
-    const unsigned origin = tile_base(img, y0 - 2, x0 - 2);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const char* src = reinterpret_cast<const char*>(xin) + (origin + 2u * kk * plane_b);
-      uint4* dst = xbuf + kk * T::XBUF;
-#pragma unroll
-      for (int k = 0; k < T::KW; ++k) {
-        int i = wave + 4 * k;
-        i = i < T::NINST ? i : T::NINST - 1;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + dma_off[k]),
-                                         (__attribute__((address_space(3))) void*)(dst + i * 64), 16, 0, 0);
-      }
-    }
-  };
-
-  wait_vmcnt<0>();
-  bool prev_full = false;
-  int img, y0, x0, nimg_ = 0, ny0 = 0, nx0 = 0;
-  tile_xy(0, img, y0, x0);
-  issue_x(img, y0, x0);
-
-  for (int ti = 0; ti < ntiles; ++ti) {
-    if (ti + 1 < ntiles) tile_xy(ti + 1, nimg_, ny0, nx0);      // one coordinate decode per tile
-    if (ti == 0 || !prev_full) wait_vmcnt<0>();
-    else wait_vmcnt<T::NSTORE>();      // younger than this tile's x: the previous tile's NSTORE (exec-masked) stores
-    block_barrier();                   // x tile visible; everyone is past the previous tile's stage 2 (t buffer free)
-    const uint4* xa = xbuf;
-    const uint4* xb = xbuf + T::XBUF;
-
-    // ---- stage 1: t = lrelu(conv1(x) + b1) on 8 x 64 ----
-    {
-      f32x16 acc[T::S1];
-#pragma unroll
-      for (int s = 0; s < T::S1; ++s)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[s][r] = s_b[(r & 3) + 8 * (r >> 2) + 4 * gh];
-      const int seg0 = wave * T::S1;
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const uint4* base = (kk ? xb : xa) + gh * T::PX + j;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-          const int ky = tap / 3, kx = tap - ky * 3;
-#pragma unroll
-          for (int s = 0; s < T::S1; ++s) {
-            const int seg = seg0 + s;
-            const int off = ((seg >> 1) + ky) * T::CX + (seg & 1) * 32 + kx;
-            const half8 v = *reinterpret_cast<const half8*>(base + off);
-            acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[tap * 2 + kk], v, acc[s], 0, 0, 0);
-          }
-        }
-      }
-      // t positions outside the image are conv2's zero padding; tiles whose whole t region lies inside skip the test
-      const bool t_interior = y0 >= 1 && y0 - 1 + T::RT <= g.H && x0 >= 1 && x0 - 1 + T::CT <= g.W;      // uniform
-#pragma unroll
-      for (int s = 0; s < T::S1; ++s) {
-        bool inside = true;
-        if (!t_interior) {
-          const int seg = seg0 + s;
-          const int gy = y0 - 1 + (seg >> 1), gx = x0 - 1 + (seg & 1) * 32 + j;
-          inside = (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          half4 hv;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float u = lrelu_fast(acc[s][4 * q + e]);
-            hv[e] = inside ? (_Float16)u : (_Float16)0.f;
-          }
-          *reinterpret_cast<half4*>(reinterpret_cast<char*>(tbuf + q * T::PT) + t_off[s]) = hv;
-        }
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    block_barrier();                   // t tile complete; the x tile is dead from here on
-
-    // ---- stage 2: y = lrelu(x + conv2(t) + b2) on 6 x 62 ----
-    {
-      const int seg0 = wave * T::S2;
-      // residual x at the output pixels: 8-byte global loads (L2-hot), issued before the next DMA group
-      const unsigned tb = tile_base(img, y0, x0);
-      uint2 rres[T::NSTORE];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const char* rq = reinterpret_cast<const char*>(xin) + (tb + (unsigned)q * plane_b);        // uniform
-#pragma unroll
-        for (int s = 0; s < T::S2; ++s) {
-          const char* rp = rq + o_off[s];
-          asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rres[s * 4 + q]) : "v"(rp) : "memory");
-        }
-      }
-      if (ti + 1 < ntiles) issue_x(nimg_, ny0, nx0);
-
-      f32x16 acc[T::S2];
-#pragma unroll
-      for (int s = 0; s < T::S2; ++s)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[s][r] = s_b[32 + (r & 3) + 8 * (r >> 2) + 4 * gh];
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const uint4* base = tbuf + (2 * kk + gh) * T::PT + j;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-          const int ky = tap / 3, kx = tap - ky * 3;
-#pragma unroll
-          for (int s = 0; s < T::S2; ++s) {
-            const int seg = seg0 + s;
-            const int off = ((seg >> 1) + ky) * T::CT + (seg & 1) * 32 + kx;
-            const half8 v = *reinterpret_cast<const half8*>(base + off);
-            acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2[tap * 2 + kk], v, acc[s], 0, 0, 0);
-          }
-        }
-      }
-      if (ti + 1 < ntiles) wait_vmcnt<2 * T::KW>(); else wait_vmcnt<0>();      // the residual loads are older than the DMA
-#pragma unroll
-      for (int i = 0; i < T::NSTORE; ++i) asm volatile("" : "+v"(rres[i]));
-      const bool interior = y0 + T::TH <= g.H && x0 + T::TWO <= g.W;            // uniform
-#pragma unroll
-      for (int s = 0; s < T::S2; ++s) {
-        bool ok = (o_ok >> s) & 1u;
-        if (!interior) {
-          const int seg = seg0 + s;
-          const int y = y0 + (seg >> 1), x = x0 + (seg & 1) * 32 + j;
-          ok = ok && y < g.H && x < g.W;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const half4 rv = *reinterpret_cast<const half4*>(&rres[s * 4 + q]);
-          half4 hv;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) hv[e] = (_Float16)lrelu_fast(acc[s][4 * q + e] + (float)rv[e]);
-          // (pixels outside the image stay zero: the border of y is never written)
-          if (ok) *reinterpret_cast<half4*>(reinterpret_cast<char*>(yout) + (tb + (unsigned)q * plane_b) + o_off[s]) = hv;
-        }
-      }
-      prev_full = interior;      // an edge tile may skip whole store instructions: the next wait must not count them
-    }
-    img = nimg_;
-    y0 = ny0;
-    x0 = nx0;
-  }
-}
-
-// ------------------------------------------------------------------------------------------
 // SN_PREC_F16X3: the v2 tower kernel on split operands.  Every activation / weight is a pair of fp16 numbers
 // (hi = fp16(v), lo = fp16((v - hi) * 2^11)), i.e. 22 significant bits, and a product is evaluated with three
 // fp16 MFMAs:  x*w ~= xhi*whi + (xhi*wlo + xlo*whi) * 2^-11   (the dropped xlo*wlo term is 2^-22 relative).

@@ -28,11 +28,12 @@
 
 namespace {
 
-// ---- RCCL through dlopen: only the six entry points of the grouped send / recv exchange ----------------------
+// ---- RCCL through dlopen: only the entry points of the grouped send / recv exchange (+ ncclCommAbort) ----------------------
 struct Rccl {
   void* lib = nullptr;
   int (*CommInitAll)(void** comms, int ndev, const int* devlist) = nullptr;
   int (*CommDestroy)(void* comm) = nullptr;
+  int (*CommAbort)(void* comm) = nullptr;      // optional: frees a communicator whose exchange can no longer complete
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
   int (*Send)(const void* buf, size_t count, int dtype, int peer, void* comm, hipStream_t st) = nullptr;
@@ -46,6 +47,7 @@ struct Rccl {
     auto sym = [&](const char* n) { return dlsym(lib, n); };
     CommInitAll = reinterpret_cast<decltype(CommInitAll)>(sym("ncclCommInitAll"));
     CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+    CommAbort = reinterpret_cast<decltype(CommAbort)>(sym("ncclCommAbort"));
     GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
     GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
     Send = reinterpret_cast<decltype(Send)>(sym("ncclSend"));
@@ -351,6 +353,14 @@ int sn_mgpu_infer_batch(sn_mgpu* m, int n, const int8_t* in, int32_t* out_i32, f
     return SN_ERR_ARG;
   }
   const size_t HW = (size_t)m->W * m->H;
+  // the host form runs on the engines' own streams and shares their workspaces with device-resident batches that are
+  // still in flight on the compute streams: refuse to overlap them (wait for the tickets first)
+  std::lock_guard<std::mutex> api(m->api_mu);
+  for (int i = 0; i < SN_MGPU_SLOTS; ++i)
+    if (m->ring.slot_ticket[i] != 0) {
+      m->err = "sn_mgpu_infer_batch: device-resident batches are in flight (sn_mgpu_wait for their tickets first)";
+      return SN_ERR_BUSY;
+    }
   return run_all(m, [&](int k) -> int {
     int first = 0, cnt = 0;
     sn_mgpu_shard(n, m->ndev, k, &first, &cnt);
@@ -394,10 +404,19 @@ int sn_mgpu_submit_device(sn_mgpu* m, int n, const int8_t* const* in_per_device,
     if (my == SN_OK && hipEventRecord(w->ev_compute[slot], w->cs) != hipSuccess) my = SN_ERR_DEVICE;
     // every rank learns whether ALL shards are on their way before any of them enters the exchange
     const int all = m->ndev > 1 ? m->agree.arrive_and_wait(my) : my;
-    if (all != SN_OK) return my != SN_OK ? my : all;
-    if (hipStreamWaitEvent(w->st, w->ev_compute[slot], 0) != hipSuccess) return SN_ERR_DEVICE;
+    if (all != SN_OK) {
+      (void)hipEventRecord(w->ev_done[slot], w->st);
+      return my != SN_OK ? my : all;
+    }
+    // (a failure here is reported through the second agreement below when RCCL carries the gather: this rank still
+    // enters the group so that nobody is left with an unmatched half)
+    const bool waited = hipStreamWaitEvent(w->st, w->ev_compute[slot], 0) == hipSuccess;
+    if (!waited && m->gather != 2) {
+      (void)hipEventRecord(w->ev_done[slot], w->st);
+      return SN_ERR_DEVICE;
+    }
     if (m->gather == 2) {     // one grouped exchange: root posts a recv per peer, every peer one send per map kind
-      bool ok = m->rccl.GroupStart() == 0;
+      bool ok = waited && m->rccl.GroupStart() == 0;
       for (int kind = 0; kind < 2 && ok; ++kind) {
         char* root_buf = reinterpret_cast<char*>(kind == 0 ? (void*)out_i32_root : (void*)out_disp_root);
         const void* mine = kind == 0 ? (const void*)raw : (const void*)disp;
@@ -413,12 +432,32 @@ int sn_mgpu_submit_device(sn_mgpu* m, int n, const int8_t* const* in_per_device,
         }
       }
       ok = (m->rccl.GroupEnd() == 0) && ok;
-      if (!ok) return SN_ERR_DEVICE;
+      // second agreement, AFTER the exchange is enqueued: a rank that failed inside the group leaves its peers with an
+      // unmatched send / recv on their exchange streams, which a later hipStreamSynchronize would wait on forever.  If any
+      // rank failed, every rank aborts its communicator (that releases the enqueued half) and peer copies carry the
+      // gather from then on.
+      const int mine2 = ok ? SN_OK : SN_ERR_DEVICE;
+      const int all2 = m->ndev > 1 ? m->agree.arrive_and_wait(mine2) : mine2;
+      if (all2 != SN_OK) {
+        if (w->comm) {
+          if (m->rccl.CommAbort) m->rccl.CommAbort(w->comm);
+          else m->rccl.CommDestroy(w->comm);
+          w->comm = nullptr;
+        }
+        if (k == 0) m->gather = 1;
+        (void)hipEventRecord(w->ev_done[slot], w->st);        // the slot's event is always recorded
+        return mine2 != SN_OK ? mine2 : all2;
+      }
     } else if (k > 0 && cnt > 0) {       // peer copies: every non-root device pushes its maps over its own link
+      bool ok = true;
       if (raw && hipMemcpyPeerAsync(out_i32_root + (size_t)first * HW, root, raw, w->dev, (size_t)cnt * HW * 4, w->st) != hipSuccess)
+        ok = false;
+      if (ok && disp && hipMemcpyPeerAsync(out_disp_root + (size_t)first * HW, root, disp, w->dev, (size_t)cnt * HW * 4, w->st) != hipSuccess)
+        ok = false;
+      if (!ok) {
+        (void)hipEventRecord(w->ev_done[slot], w->st);
         return SN_ERR_DEVICE;
-      if (disp && hipMemcpyPeerAsync(out_disp_root + (size_t)first * HW, root, disp, w->dev, (size_t)cnt * HW * 4, w->st) != hipSuccess)
-        return SN_ERR_DEVICE;
+      }
     }
     return hipEventRecord(w->ev_done[slot], w->st) == hipSuccess ? SN_OK : SN_ERR_DEVICE;
   });
@@ -438,16 +477,29 @@ int sn_mgpu_submit_device(sn_mgpu* m, int n, const int8_t* const* in_per_device,
 
 int sn_mgpu_wait(sn_mgpu* m, uint64_t ticket) {
   if (!m) return SN_ERR_ARG;
-  std::lock_guard<std::mutex> api(m->api_mu);
+  // Blocks on the events WITHOUT the API lock (a submit from another thread must not stall for a whole batch); the slot
+  // is released only afterwards, so a concurrent submit cannot reuse its staging buffers while the gather still runs.
+  // The events are waited for from this thread: the worker threads stay free for that submit.
   int slot = 0;
-  const int rc = sn_mgpu_ring_wait(&m->ring, ticket, &slot);
-  if (rc != SN_OK) {
-    m->err = "sn_mgpu_wait: unknown or already-consumed ticket";
-    return rc;
+  {
+    std::lock_guard<std::mutex> api(m->api_mu);
+    slot = (int)(ticket % SN_MGPU_SLOTS);
+    if (ticket == 0 || m->ring.slot_ticket[slot] != ticket) {
+      m->err = "sn_mgpu_wait: unknown or already-consumed ticket";
+      return SN_ERR_TICKET;
+    }
   }
-  return run_all(m, [&](int k) -> int {
-    return hipEventSynchronize(m->w[k]->ev_done[slot]) == hipSuccess ? SN_OK : SN_ERR_DEVICE;
-  });
+  int rc = SN_OK;
+  for (int k = 0; k < m->ndev; ++k)
+    if (hipEventSynchronize(m->w[k]->ev_done[slot]) != hipSuccess && rc == SN_OK) rc = SN_ERR_DEVICE;
+  std::lock_guard<std::mutex> api(m->api_mu);
+  int s2 = 0;
+  const int r2 = sn_mgpu_ring_wait(&m->ring, ticket, &s2);       // fails if another thread consumed the same ticket meanwhile
+  if (r2 != SN_OK) {
+    m->err = "sn_mgpu_wait: unknown or already-consumed ticket";
+    return r2;
+  }
+  return rc;
 }
 
 int sn_mgpu_infer_batch_device(sn_mgpu* m, int n, const int8_t* const* in_per_device, int32_t* out_i32_root,

@@ -81,6 +81,9 @@ struct StreamTile {
   static constexpr int XRING = NXS * XGP;
   static constexpr int TRING = NTS * TGP + 64;             // conv2's kx taps of the junk columns run past the last row
   static constexpr int LDS_BYTES = (XRING + TRING) * 16 + 2 * 2 * 16 * 4;      // + bias tables [conv][k-half][16]
+  // image rows a DMA group may touch outside [0, H): a unit's slot 0 starts R sub-rows above its first output row
+  // (row -R DIL at v0 = 0) and its last group ends at sub-row hsub + R, i.e. image row <= H + (R + 2) DIL - 2
+  static constexpr int ROWS_ABOVE = R * DIL, ROWS_BELOW = (R + 2) * DIL - 1;
   static_assert(SPW == 1 || SPW == 2, "segments per wave");
   static_assert(CSEG % SPW == 0, "a wave's segments lie in one row");
   static_assert(PF == 2, "prefetch distance the counted waits are written for");

@@ -6,6 +6,8 @@
 // there is no gfx950 device every entry point fails with SN_ERR_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -39,6 +41,18 @@ constexpr int kMaxTowerStreams = 2;
       return SN_ERR_DEVICE;                                                           \
     }                                                                                 \
   } while (0)
+
+// Device buffers of a parity hook (sn_dbg_*): freed on EVERY return path, error paths included.
+struct DevScope {
+  std::vector<void*> ptrs;
+  void track(const void* p) {
+    void* q = const_cast<void*>(p);
+    if (q && std::find(ptrs.begin(), ptrs.end(), q) == ptrs.end()) ptrs.push_back(q);
+  }
+  ~DevScope() {
+    for (void* q : ptrs) (void)hipFree(q);
+  }
+};
 
 struct ConvLayer {
   uint4* wx3 = nullptr;    // device, split fp16 A-fragments [cin_pad/16][9][hi|lo][64 lanes] (fp16 modes, 3x3 layers)
@@ -137,7 +151,7 @@ struct sn_handle {
   bool overlap = true;
   int tower_streams = kMaxTowerStreams;
   bool stream_last = true;   // the last block streamed too + separate head launch (SN_STREAM_LAST=0: conv + fused conv/head)
-  int fuse_mode = 4;         // SN_FUSE: 4 = streaming fused blocks (default), 3 = tile-fused dilation-1 blocks, 0 = two launches per block
+  int fuse_mode = 4;         // SN_FUSE: 4 = streaming fused blocks (default), 0 = two launches per block
   bool head_fuse = true;     // last tower conv + head in one kernel (fp16 mode; SN_HEAD_FUSE=0 separates them)
   unsigned* dump = nullptr;  // 2 KB device scratch: where lanes without an output pixel store (fused head)
   bool use_graphs = true;    // hipGraph replay for the async single-pair path (SN_NO_GRAPH disables)
@@ -617,17 +631,30 @@ RefGeom make_ref_geom(int Hp, int Wp) {
 }
 
 size_t ref16_slots(const RefGeom& g, int nimg) { return (size_t)nimg * 4 * g.Hs * g.Ws; }
-// Slots behind a tensor that kernels may over-read (never written, zero): the fused blocks fetch whole x tiles / row
-// groups past the last padded row of the last image (tile-fused kernel: < 4096 slots; streaming kernel: up to
-// (R + 2) * DIL + DIL - 1 rows of Ws slots below the image, of which 8 are the tensor's own border).
+// The streaming block kernels the pipeline instantiates (ref_block_stream below): ONE list, from which the zero rows
+// around a tensor are derived.
+using StreamTile1 = StreamTile<1, 64, 4, 6, 4>;
+using StreamTile2 = StreamTile<2, 64, 4, 6, 4>;
+using StreamTile4 = StreamTile<4, 128, 2, 6, 4>;
+using StreamTile8 = StreamTile<8, 128, 2, 6, 4>;
+constexpr int cmax4(int a, int b, int c, int d) { return (a > b ? a : b) > (c > d ? c : d) ? (a > b ? a : b) : (c > d ? c : d); }
+constexpr int kStreamRowsAbove = cmax4(StreamTile1::ROWS_ABOVE, StreamTile2::ROWS_ABOVE, StreamTile4::ROWS_ABOVE, StreamTile8::ROWS_ABOVE);
+constexpr int kStreamRowsBelow = cmax4(StreamTile1::ROWS_BELOW, StreamTile2::ROWS_BELOW, StreamTile4::ROWS_BELOW, StreamTile8::ROWS_BELOW);
+// Slots behind a tensor that kernels may over-read (never written, zero).  Streaming kernel: a DMA group reaches up to
+// ROWS_BELOW image rows below the last image row, of which the tensor itself holds Hs - kRefPad - H >= kRefPad; a group
+// whose columns run past Ws wraps into the next row (+1).  The per-layer kernels over-read < 4096 slots.
+constexpr int kRefSlackRows = kStreamRowsBelow - kRefPad + 1;
+// Slots IN FRONT of a tensor (zero, never written): a strip's first group starts ROWS_ABOVE image rows above row 0
+// (16 at dilation 8) and up to 2 DIL columns left of column 0, where the tensor's own border is kRefPad rows / columns
+// (a column underrun wraps into the previous row: +1).  An fp16 activation tensor is allocated as
+// [front | tensor | slack] and handed around by the address of `tensor`.
+constexpr int kRefFrontRows = (kStreamRowsAbove > kRefPad ? kStreamRowsAbove - kRefPad : 0) + 1;
+static_assert(kRefSlackRows == 24 && kRefFrontRows == 9, "zero rows around the fp16 tower tensors follow the StreamTile list");
 size_t ref_slack(const RefGeom& g) {
-  const size_t rows = (size_t)24 * g.Ws;
+  const size_t rows = (size_t)kRefSlackRows * g.Ws;
   return rows > 4096 ? rows : 4096;
 }
-// Slots IN FRONT of a tensor (zero, never written): the streaming blocks of dilation 4 / 8 pre-load the two sub-rows above
-// a strip's first row, up to 2 * DIL = 16 image rows above row 0 where the tensor's own border is 8 rows.  An fp16
-// activation tensor is allocated as [front | tensor | slack] and handed around by the address of `tensor`.
-size_t ref_front(const RefGeom& g) { return (size_t)16 * g.Ws; }
+size_t ref_front(const RefGeom& g) { return (size_t)kRefFrontRows * g.Ws; }
 hipError_t alloc_ref16(const RefGeom& g, size_t tensor_and_slack_slots, uint4** raw, uint4** base) {
   const size_t front = ref_front(g), all = front + tensor_and_slack_slots;
   hipError_t e = dalloc(raw, all);
@@ -733,37 +760,13 @@ hipError_t launch_ref_f16_v2(hipStream_t st, const RefLayerF16& L, const RefGeom
   return hipGetLastError();
 }
 
-// Fused residual block (conv1 + conv2 + residual in one launch, t only in LDS); x and y must be different tensors.
-// 77 KB of LDS, two workgroups per CU.  Opt-in (SN_FUSE=3): 40 % of the HBM traffic of the two launches it replaces
-// at the same run time.
-hipError_t launch_ref_block_f16_h(hipStream_t st, const RefLayerF16& L1, const RefLayerF16& L2, const RefGeom& g,
-                                  int num_cu, const uint4* x, uint4* y, int nimg) {
-  using T = FusedHTile;
-  auto kern = k_ref_block_f16_h;
-  hipError_t e = ensure_lds_attr(kern, T::LDS_BYTES);
-  if (e != hipSuccess) return e;
-  RefGeom gt = g;
-  gt.tiles_x = (g.W + T::TWO - 1) / T::TWO;
-  gt.tiles_y = (g.H + T::TH - 1) / T::TH;
-  const int total = gt.tiles_x * gt.tiles_y * nimg;
-  const int band = (total + 7) / 8;
-  int cap = 2 * num_cu / 8;                // two workgroups per CU
-  if (cap < 1) cap = 1;
-  const int rounds = (band + cap - 1) / cap;
-  const int nlb = (band + rounds - 1) / rounds;
-  hipLaunchKernelGGL(kern, dim3(nlb * 8), dim3(256), T::LDS_BYTES, st, x, y, L1.wfrag, L1.bias, L2.wfrag, L2.bias, gt,
-                     nimg, y /* slot 0 = top-left pad corner, zero by construction */);
-  return hipGetLastError();
-}
-
-
 // Fused residual block, row-streaming form (sn_stream_block.hpp): one 512-thread workgroup per CU walks its share of
 // the flattened (image, row phase, strip, sub-row) sequence.  x and y must be different tensors.  dump: >= 1 KB scratch.
-template <int DIL, int TW, int R>
+template <class T>
 hipError_t launch_ref_block_stream(hipStream_t st, const RefLayerF16& L1, const RefLayerF16& L2, const RefGeom& g, int num_cu,
                                    const uint4* x, uint4* y, int nimg, unsigned* dump) {
-  using T = StreamTile<DIL, TW, R, 6, 4>;
-  auto kern = k_ref_block_stream_f16<DIL, TW, R, 6, 4>;
+  constexpr int DIL = T::DIL;
+  auto kern = k_ref_block_stream_f16<T::DIL, T::TW, T::R, T::NXS, T::NWR>;
   if (dump == nullptr) return hipErrorInvalidValue;
   hipError_t e = ensure_lds_attr(kern, T::LDS_BYTES);
   if (e != hipSuccess) return e;
@@ -787,10 +790,10 @@ hipError_t launch_ref_block_stream(hipStream_t st, const RefLayerF16& L1, const 
 hipError_t ref_block_stream(hipStream_t st, const RefLayerF16& L1, const RefLayerF16& L2, const RefGeom& g, int num_cu, int dil,
                             const uint4* x, uint4* y, int nimg, unsigned* dump) {
   switch (dil) {
-    case 1: return launch_ref_block_stream<1, 64, 4>(st, L1, L2, g, num_cu, x, y, nimg, dump);
-    case 2: return launch_ref_block_stream<2, 64, 4>(st, L1, L2, g, num_cu, x, y, nimg, dump);
-    case 4: return launch_ref_block_stream<4, 128, 2>(st, L1, L2, g, num_cu, x, y, nimg, dump);
-    case 8: return launch_ref_block_stream<8, 128, 2>(st, L1, L2, g, num_cu, x, y, nimg, dump);
+    case 1: return launch_ref_block_stream<StreamTile1>(st, L1, L2, g, num_cu, x, y, nimg, dump);
+    case 2: return launch_ref_block_stream<StreamTile2>(st, L1, L2, g, num_cu, x, y, nimg, dump);
+    case 4: return launch_ref_block_stream<StreamTile4>(st, L1, L2, g, num_cu, x, y, nimg, dump);
+    case 8: return launch_ref_block_stream<StreamTile8>(st, L1, L2, g, num_cu, x, y, nimg, dump);
     default: return hipErrorInvalidValue;
   }
 }
@@ -849,7 +852,7 @@ bool head_fuse_env() {   // SN_HEAD_FUSE=0: separate last conv + head launches (
 }
 
 // SN_FUSE: how the residual blocks of the fp16 tower run.  4 (default) = the row-streaming fused kernel for the
-// dilations it supports, 3 = the tile-fused kernel for dilation 1 (round 2, kept for A/B), 0 = two launches per block.
+// dilations it supports, 0 = two launches per block.
 int fuse_env() {
   static const int mode = getenv("SN_FUSE") != nullptr ? atoi(getenv("SN_FUSE")) : 4;
   return mode;
@@ -894,9 +897,6 @@ hipError_t ref_block_f16(hipStream_t st, const RefLayerF16& L1, const RefLayerF1
   bool fused = false;
   if (fuse_mode == 4 && stream_block_supports(dil)) {
     e = ref_block_stream(st, L1, L2, g, num_cu, dil, *cur, *oth, nimg, dump);
-    fused = true;
-  } else if (fuse_mode == 3 && dil == 1) {
-    e = launch_ref_block_f16_h(st, L1, L2, g, num_cu, *cur, *oth, nimg);
     fused = true;
   }
   if (fused) {
@@ -1229,9 +1229,8 @@ int refine_level(sn_handle* h, Workspace& ws, hipStream_t st, const Tower& T, fl
     flip();
     // fp16 mode: the last conv of the tower and the head run as one kernel (the tower's output tensor is never
     // written); needs the last block to be an unfused dilation-1 block
-    // (a streamed or tile-fused last block leaves its output in memory: the head then runs as its own launch)
-    const bool last_block_fused = (h->fuse_mode == 4 && stream_block_supports(kRefDil[kNRefRes - 1]) && h->stream_last) ||
-                                  (h->fuse_mode == 3 && kRefDil[kNRefRes - 1] == 1);
+    // (a streamed last block leaves its output in memory: the head then runs as its own launch)
+    const bool last_block_fused = h->fuse_mode == 4 && stream_block_supports(kRefDil[kNRefRes - 1]) && h->stream_last;
     const bool head_fused = !x3 && h->head_fuse && kRefDil[kNRefRes - 1] == 1 && !last_block_fused;
     for (int i = 0; i < kNRefRes; ++i) {
       if (x3) {
@@ -2141,20 +2140,22 @@ int sn_get_dominant_kernel(sn_handle* h, char* name, size_t cap, int* launches, 
       const bool last = i == kNRefRes - 1;
       if (stream_block_supports(kRefDil[i]) && (!last || h->stream_last || !h->head_fuse)) ++n;
     }
-    if (name && cap)
-      snprintf(name, cap, "%s", "k_ref_block_stream_f16<DIL> (fused residual block: two 3x3 C->C convs + residual, fp16 MFMA 32x32x16)");
-    if (launches) *launches = n;
-    if (flops) *flops = 2.0 * (2.0 * px * kC * kC * 9);           // two convolutions per launch
-    if (bytes) *bytes = px * kC * 2.0 * 2.0;                       // x read once + y written once; t never leaves LDS
-    return SN_OK;
+    if (n > 0) {     // (n == 0, e.g. SN_STREAM_DIL=0: nothing is streamed — the per-layer description below applies)
+      if (name && cap)
+        snprintf(name, cap, "%s", "k_ref_block_stream_f16<DIL> (fused residual block: two 3x3 C->C convs + residual, fp16 MFMA 32x32x16)");
+      if (launches) *launches = n;
+      if (flops) *flops = 2.0 * (2.0 * px * kC * kC * 9);           // two convolutions per launch
+      if (bytes) *bytes = px * kC * 2.0 * 2.0;                       // x read once + y written once; t never leaves LDS
+      return SN_OK;
+    }
   }
   if (name && cap)
     snprintf(name, cap, "%s",
              h->precision == SN_PREC_F16     ? "k_ref_conv_f16<DIL> (refinement 3x3 C->C, fp16 MFMA 32x32x16)"
              : h->precision == SN_PREC_F16X3 ? "k_ref_conv_f16x3<DIL> (refinement 3x3 C->C, 3x fp16 MFMA on hi/lo split operands)"
-                                             : "k_conv_c32_mfma<3,1,*> (refinement 3x3 C->C, fp32 MFMA 32x32x2)");
+                                             : "k_ref_conv_f32<DIL> (refinement 3x3 C->C, weights-stationary, fp32 MFMA 32x32x2)");
   // fp16 mode with the fused last layer: the timed span holds the 11 plain tower launches (6 without, 5 with residual)
-  const bool hf = f16 && h->head_fuse && !(h->fuse_mode == 3);
+  const bool hf = f16 && h->head_fuse;
   const int n_plain = kNRefRes, n_res = hf ? kNRefRes - 1 : kNRefRes;
   if (launches) *launches = n_plain + n_res;   // per refinement chunk
   if (flops) *flops = 2.0 * px * kC * kC * 9;
@@ -2167,6 +2168,7 @@ int sn_get_dominant_kernel(sn_handle* h, char* name, size_t cap, int* launches, 
 // ---- parity hooks ----------------------------------------------------------------------------------------
 int sn_dbg_conv2d(sn_handle* h, const float* in, int cin, int h_px, int w, const float* wt, const float* bias,
                   int k, int stride, int dil, int lrelu, const float* residual, float* out) {
+  DevScope ds;      // frees every tracked device buffer on every return path
   if (!h || !in || !wt || !bias || !out || cin <= 0 || cin > kC) return SN_ERR_ARG;
   if (!((k == 3 && stride == 1) || (k == 5 && stride == 2 && dil == 1))) return SN_ERR_ARG;
   int rc = check_device(h);
@@ -2184,13 +2186,17 @@ int sn_dbg_conv2d(sn_handle* h, const float* in, int cin, int h_px, int w, const
     ConvLayer Ls;
     HostLayer hls{wt, bias, kC, cin, taps};
     if ((rc = upload_conv2d(h, hls, 8, &Ls))) return rc;
+    ds.track(Ls.bias); ds.track(Ls.wpk); ds.track(Ls.wx3);
     if ((rc = upload_x3(h, kC, [&](int co, int c, int tap) { return wt[((size_t)co * kC + c) * taps + tap]; }, &Ls, taps)))
       return rc;
+    ds.track(Ls.bias); ds.track(Ls.wpk); ds.track(Ls.wx3);
     std::vector<_Float16> hin, hres, hout((size_t)8 * Ho * Wo * 8);
     host_to_slots(in, 1, h_px, w, hin);
     uint4 *din = nullptr, *dout = nullptr;
     HIP_TRY(h, dalloc(&din, hin.size() / 8));
+    ds.track(din);
     HIP_TRY(h, dalloc(&dout, hout.size() / 8));
+    ds.track(dout);
     HIP_TRY(h, hipMemcpy(din, hin.data(), hin.size() * 2, hipMemcpyHostToDevice));
     const float* dres = nullptr;
     if (residual) {
@@ -2207,14 +2213,14 @@ int sn_dbg_conv2d(sn_handle* h, const float* in, int cin, int h_px, int w, const
           memcpy(&pin[((size_t)img * iphw + (size_t)(y + gi.py) * gi.PW + gi.px) * 8], &hin[((size_t)img * h_px + y) * w * 8], (size_t)w * 16);
       uint4 *pdin = nullptr, *pdout = nullptr;
       HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&pdin), pin.size() * 2));
+      ds.track(pdin);
       HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&pdout), pout.size() * 2));
+      ds.track(pdout);
       HIP_TRY(h, hipMemcpy(pdin, pin.data(), pin.size() * 2, hipMemcpyHostToDevice));
       HIP_TRY(h, hipMemset(pdout, 0, pout.size() * 2));
       HIP_TRY(h, launch_down_dma(h->stream, Ls, pdin, 1, Ho, Wo, pdout, go, lrelu != 0, h->num_cu));
       HIP_TRY(h, hipStreamSynchronize(h->stream));
       HIP_TRY(h, hipMemcpy(pout.data(), pdout, pout.size() * 2, hipMemcpyDeviceToHost));
-      hipFree(pdin);
-      hipFree(pdout);
       for (int img = 0; img < 8; ++img)
         for (int y = 0; y < Ho; ++y)
           memcpy(&hout[((size_t)img * Ho + y) * Wo * 8], &pout[((size_t)img * ophw + (size_t)(y + go.py) * go.PW + go.px) * 8], (size_t)Wo * 16);
@@ -2227,11 +2233,6 @@ int sn_dbg_conv2d(sn_handle* h, const float* in, int cin, int h_px, int w, const
         }
       }
       host_from_slots(hout, 1, Ho, Wo, out);
-      hipFree(din);
-      hipFree(dout);
-      hipFree(Ls.wx3);
-      hipFree(Ls.wpk);
-      hipFree(Ls.bias);
       return SN_OK;
     }
     SlotIn ls{din, 0, h_px, w};
@@ -2241,20 +2242,18 @@ int sn_dbg_conv2d(sn_handle* h, const float* in, int cin, int h_px, int w, const
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemcpy(hout.data(), dout, hout.size() * 2, hipMemcpyDeviceToHost));
     host_from_slots(hout, 1, Ho, Wo, out);
-    hipFree(din);
-    hipFree(dout);
-    hipFree(Ls.wx3);
-    hipFree(Ls.wpk);
-    hipFree(Ls.bias);
     return SN_OK;
   }
   ConvLayer L;
   HostLayer hl{wt, bias, kC, cin, taps};
   if ((rc = upload_conv2d(h, hl, (k == 5 || cin <= 4) ? 4 : 8, &L))) return rc;
+  ds.track(L.bias); ds.track(L.wpk); ds.track(L.wx3);
   float *din = nullptr, *dout = nullptr;
   const size_t nin = (size_t)cin * h_px * w, nout = (size_t)kC * Ho * Wo;
   HIP_TRY(h, dalloc(&din, nin));
+  ds.track(din);
   HIP_TRY(h, dalloc(&dout, nout));
+  ds.track(dout);
   HIP_TRY(h, hipMemcpy(din, in, nin * 4, hipMemcpyHostToDevice));
   const float* dres = nullptr;
   if (residual) {   // in-place form, as the pipeline uses it
@@ -2278,16 +2277,12 @@ int sn_dbg_conv2d(sn_handle* h, const float* in, int cin, int h_px, int w, const
   HIP_TRY(h, e);
   HIP_TRY(h, hipStreamSynchronize(st));
   HIP_TRY(h, hipMemcpy(out, dout, nout * 4, hipMemcpyDeviceToHost));
-  hipFree(din);
-  hipFree(dout);
-  hipFree(L.wx3);
-  hipFree(L.wpk);
-  hipFree(L.bias);
   return SN_OK;
 }
 
 int sn_dbg_down0(sn_handle* h, const int8_t* in6, int h_px, int w, const float* wt, const float* bias, int tc,
                  float* out) {
+  DevScope ds;      // frees every tracked device buffer on every return path
   if (!h || !in6 || !wt || !bias || !out || h_px <= 0 || w <= 0 || tc != 32) return SN_ERR_ARG;
   int rc = check_device(h);
   if (rc) return rc;
@@ -2295,12 +2290,16 @@ int sn_dbg_down0(sn_handle* h, const int8_t* in6, int h_px, int w, const float* 
   Down0F16 L;
   HostLayer hl{wt, bias, kC, 3, 25};
   if ((rc = upload_down0_f16(h, hl, &L))) return rc;
+  ds.track(L.wfrag);
   int8_t* din = nullptr;
   float *dout = nullptr, *dbias = nullptr;
   const size_t nin = (size_t)6 * h_px * w, nout = (size_t)2 * kC * Ho * Wo;     // split slots: same bytes as fp32
   HIP_TRY(h, dalloc(&din, nin));
+  ds.track(din);
   HIP_TRY(h, dalloc(&dout, nout));
+  ds.track(dout);
   HIP_TRY(h, dalloc(&dbias, kC));
+  ds.track(dbias);
   HIP_TRY(h, hipMemcpy(din, in6, nin, hipMemcpyHostToDevice));
   HIP_TRY(h, hipMemcpy(dbias, bias, kC * 4, hipMemcpyHostToDevice));
   HIP_TRY(h, launch_down0_f16(h->stream, L, dbias, din, h_px, w, 2, Ho, Wo, dout, h->num_cu));   // the pipeline's kernel
@@ -2308,15 +2307,12 @@ int sn_dbg_down0(sn_handle* h, const int8_t* in6, int h_px, int w, const float* 
   std::vector<_Float16> hs(nout * 2);
   HIP_TRY(h, hipMemcpy(hs.data(), dout, nout * 4, hipMemcpyDeviceToHost));
   host_from_slots(hs, 2, Ho, Wo, out);
-  hipFree(din);
-  hipFree(dout);
-  hipFree(dbias);
-  hipFree(L.wfrag);
   return SN_OK;
 }
 
 int sn_dbg_refin(sn_handle* h, const float* disp_low, const int8_t* in6, int h_px, int w, int dmax, const float* wt,
                  const float* bias, int split, float* out) {
+  DevScope ds;      // frees every tracked device buffer on every return path
   if (!h || !disp_low || !in6 || !wt || !bias || !out || h_px <= 0 || w <= 0 || dmax <= 0) return SN_ERR_ARG;
   int rc = check_device(h);
   if (rc) return rc;
@@ -2326,13 +2322,18 @@ int sn_dbg_refin(sn_handle* h, const float* disp_low, const int8_t* in6, int h_p
   Down0F16 L;
   HostLayer hl_{wt, bias, kC, 4, 9};
   if ((rc = upload_refin_f16(h, hl_, &L))) return rc;
+  ds.track(L.wfrag);
   float *ddl = nullptr, *dbias = nullptr;
   int8_t* din = nullptr;
   uint4* dout = nullptr;
   HIP_TRY(h, dalloc(&ddl, (size_t)hl * wl));
+  ds.track(ddl);
   HIP_TRY(h, dalloc(&dbias, kC));
+  ds.track(dbias);
   HIP_TRY(h, dalloc(&din, (size_t)6 * h_px * w));
+  ds.track(din);
   HIP_TRY(h, dalloc(&dout, 2 * slots));
+  ds.track(dout);
   HIP_TRY(h, hipMemcpy(ddl, disp_low, (size_t)hl * wl * 4, hipMemcpyHostToDevice));
   HIP_TRY(h, hipMemcpy(dbias, bias, kC * 4, hipMemcpyHostToDevice));
   HIP_TRY(h, hipMemcpy(din, in6, (size_t)6 * h_px * w, hipMemcpyHostToDevice));
@@ -2360,16 +2361,12 @@ int sn_dbg_refin(sn_handle* h, const float* disp_low, const int8_t* in6, int h_p
             return SN_ERR_DEVICE;
           }
       }
-  hipFree(ddl);
-  hipFree(dbias);
-  hipFree(din);
-  hipFree(dout);
-  hipFree(L.wfrag);
   return SN_OK;
 }
 
 int sn_dbg_conv3d(sn_handle* h, const float* in, int d, int h_px, int w, const float* wt, const float* bias,
                   int lrelu, float* out) {
+  DevScope ds;      // frees every tracked device buffer on every return path
   if (!h || !in || !wt || !bias || !out || d <= 0) return SN_ERR_ARG;
   int rc = check_device(h);
   if (rc) return rc;
@@ -2379,6 +2376,7 @@ int sn_dbg_conv3d(sn_handle* h, const float* in, int d, int h_px, int w, const f
   ConvLayer L;
   HostLayer hl{wt, bias, kC, kC, 27};
   if ((rc = upload_conv3d(h, hl, &L))) return rc;
+  ds.track(L.bias); ds.track(L.wpk); ds.track(L.wx3);
   if (x3 && (rc = upload_x3(h, 96, [&](int co, int c, int tap) {
         return wt[(((size_t)co * kC + (c & 31)) * 3 + (c >> 5)) * 9 + tap];
       }, &L)))
@@ -2391,7 +2389,9 @@ int sn_dbg_conv3d(sn_handle* h, const float* in, int d, int h_px, int w, const f
       memcpy(&tmp[((size_t)z * kC + ci) * plane], &in[((size_t)ci * d + z) * plane], plane * 4);
   float *din = nullptr, *dout = nullptr;
   HIP_TRY(h, dalloc(&din, n));
+  ds.track(din);
   HIP_TRY(h, dalloc(&dout, n));
+  ds.track(dout);
   if (slots) {       // the volume as d split-slot images (same byte count as fp32)
     std::vector<_Float16> hs, ho(n * 2);
     host_to_slots(tmp.data(), d, h_px, w, hs);
@@ -2405,14 +2405,14 @@ int sn_dbg_conv3d(sn_handle* h, const float* in, int d, int h_px, int w, const f
                  (size_t)w * 16);
       uint4 *pdin = nullptr, *pdout = nullptr;
       HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&pdin), nsl * 16));
+      ds.track(pdin);
       HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&pdout), nsl * 16));
+      ds.track(pdout);
       HIP_TRY(h, hipMemcpy(pdin, pin.data(), nsl * 16, hipMemcpyHostToDevice));
       HIP_TRY(h, hipMemset(pdout, 0, nsl * 16));
       HIP_TRY(h, launch_agg_dma<true>(h->stream, L, pdin, g, 1, pdout, lrelu != 0, h->num_cu));
       HIP_TRY(h, hipStreamSynchronize(h->stream));
       HIP_TRY(h, hipMemcpy(pout.data(), pdout, nsl * 16, hipMemcpyDeviceToHost));
-      hipFree(pdin);
-      hipFree(pdout);
       for (size_t img = 0; img < (size_t)d * 8; ++img)
         for (int y = 0; y < h_px; ++y)
           memcpy(&ho[(img * plane + (size_t)y * w) * 8], &pout[(((img / 8 + 1) * 8 + img % 8) * phw + (size_t)(y + 1) * g.PW + 1) * 8],
@@ -2444,16 +2444,12 @@ int sn_dbg_conv3d(sn_handle* h, const float* in, int d, int h_px, int w, const f
   for (int co = 0; co < kC; ++co)
     for (int z = 0; z < d; ++z)
       memcpy(&out[((size_t)co * d + z) * plane], &tmp[((size_t)z * kC + co) * plane], plane * 4);
-  hipFree(din);
-  hipFree(dout);
-  hipFree(L.wx3);
-  hipFree(L.wpk);
-  hipFree(L.bias);
   return SN_OK;
 }
 
 int sn_dbg_ref_conv_f16(sn_handle* h, const float* in, int h_px, int w, const float* wt, const float* bias, int dil,
                         int lrelu, const float* residual, float* out) {
+  DevScope ds;      // frees every tracked device buffer on every return path
   if (!h || !in || !wt || !bias || !out || h_px <= 0 || w <= 0) return SN_ERR_ARG;
   if (dil != 1 && dil != 2 && dil != 4 && dil != 8) return SN_ERR_ARG;
   int rc = check_device(h);
@@ -2473,9 +2469,12 @@ int sn_dbg_ref_conv_f16(sn_handle* h, const float* in, int h_px, int w, const fl
   RefLayerF16 L;
   HostLayer hl{wt, bias, kC, kC, 9};
   if ((rc = upload_ref_f16(h, hl, &L))) return rc;
+  ds.track(L.bias); ds.track(L.wfrag);
   uint4 *din = nullptr, *dout = nullptr;
   HIP_TRY(h, dalloc(&din, slots));
+  ds.track(din);
   HIP_TRY(h, dalloc(&dout, slots));
+  ds.track(dout);
   HIP_TRY(h, hipMemcpy(din, hin.data(), slots * 16, hipMemcpyHostToDevice));
   const uint4* dres = nullptr;
   if (residual) {
@@ -2514,15 +2513,12 @@ int sn_dbg_ref_conv_f16(sn_handle* h, const float* in, int h_px, int w, const fl
             return SN_ERR_DEVICE;
           }
       }
-  hipFree(din);
-  hipFree(dout);
-  hipFree(L.wfrag);
-  hipFree(L.bias);
   return SN_OK;
 }
 
 int sn_dbg_ref_conv_f16x3(sn_handle* h, const float* in, int h_px, int w, const float* wt, const float* bias, int dil,
                           int lrelu, const float* residual, float* out) {
+  DevScope ds;      // frees every tracked device buffer on every return path
   if (!h || !in || !wt || !bias || !out || h_px <= 0 || w <= 0) return SN_ERR_ARG;
   if (dil != 1 && dil != 2 && dil != 4 && dil != 8) return SN_ERR_ARG;
   int rc = check_device(h);
@@ -2545,9 +2541,12 @@ int sn_dbg_ref_conv_f16x3(sn_handle* h, const float* in, int h_px, int w, const 
   split_to(in, hin);
   RefLayerF16 L;
   if ((rc = upload_ref_f16x3(h, HostLayer{wt, bias, kC, kC, 9}, &L))) return rc;
+  ds.track(L.bias); ds.track(L.wfrag);
   uint4 *din = nullptr, *dout = nullptr;
   HIP_TRY(h, dalloc(&din, slots));
+  ds.track(din);
   HIP_TRY(h, dalloc(&dout, slots));
+  ds.track(dout);
   HIP_TRY(h, hipMemcpy(din, hin.data(), slots * 16, hipMemcpyHostToDevice));
   const uint4* dres = nullptr;
   if (residual) {
@@ -2577,21 +2576,20 @@ int sn_dbg_ref_conv_f16x3(sn_handle* h, const float* in, int h_px, int w, const 
               return SN_ERR_DEVICE;
             }
         }
-  hipFree(din);
-  hipFree(dout);
-  hipFree(L.wfrag);
-  hipFree(L.bias);
   return SN_OK;
 }
 
 int sn_dbg_ref_block_f16(sn_handle* h, const float* in, int h_px, int w, const float* w1, const float* b1,
                          const float* w2, const float* b2, int dil, float* out) {
+  DevScope ds;      // frees every tracked device buffer on every return path
   if (!h || !in || !w1 || !b1 || !w2 || !b2 || !out || h_px <= 0 || w <= 0) return SN_ERR_ARG;
-  // tests: bits 8.. select the form: 0 = two launches, 1 = tile-fused kernel (dilation 1), 2 = row-streaming fused kernel
+  // tests: bits 8.. select the form: 0 = two launches, 2 = row-streaming fused kernel (1 was the tile-fused kernel of round 2)
   const int form = dil >> 8;
-  const int fuse_mode = form == 2 ? 4 : (form == 1 ? 3 : 0);
+  if (form != 0 && form != 2) return SN_ERR_ARG;
+  const int fuse_mode = form == 2 ? 4 : 0;
   dil &= 0xff;
   if (dil != 1 && dil != 2 && dil != 4 && dil != 8) return SN_ERR_ARG;
+  if (fuse_mode == 4 && !stream_block_supports(dil)) return SN_ERR_ARG;
   int rc = check_device(h);
   if (rc) return rc;
   const RefGeom g = make_ref_geom(h_px, w);
@@ -2603,10 +2601,14 @@ int sn_dbg_ref_block_f16(sn_handle* h, const float* in, int h_px, int w, const f
       for (int x = 0; x < w; ++x) hin[idx(c, y, x)] = (_Float16)in[((size_t)c * h_px + y) * w + x];
   RefLayerF16 L1, L2;
   if ((rc = upload_ref_f16(h, HostLayer{w1, b1, kC, kC, 9}, &L1))) return rc;
+  ds.track(L1.bias); ds.track(L1.wfrag);
   if ((rc = upload_ref_f16(h, HostLayer{w2, b2, kC, kC, 9}, &L2))) return rc;
+  ds.track(L2.bias); ds.track(L2.wfrag);
   uint4 *da = nullptr, *db = nullptr, *da_raw = nullptr, *db_raw = nullptr;
   HIP_TRY(h, alloc_ref16(g, slots + ref_slack(g), &da_raw, &da));
+  ds.track(da_raw);
   HIP_TRY(h, alloc_ref16(g, slots + ref_slack(g), &db_raw, &db));
+  ds.track(db_raw);
   HIP_TRY(h, hipMemcpy(da, hin.data(), slots * 16, hipMemcpyHostToDevice));
   uint4 *cur = da, *oth = db;
   if (!h->ws.tile_ctr) {
@@ -2614,8 +2616,6 @@ int sn_dbg_ref_block_f16(sn_handle* h, const float* in, int h_px, int w, const f
     return SN_ERR_ARG;
   }
   HIP_TRY(h, hipMemsetAsync(h->ws.tile_ctr, 0, kTileCtrBytes, h->stream));
-  // dilation 1 can go through the fused kernel here even when the pipeline does not use it
-  if (fuse_mode == 4 && !stream_block_supports(dil)) return SN_ERR_ARG;
   HIP_TRY(h, ref_block_f16(h->stream, L1, L2, g, h->num_cu, dil, &cur, &oth, 1, h->ws.tile_ctr, fuse_mode, h->dump));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   std::vector<_Float16> hout(slots * 8);
@@ -2633,12 +2633,6 @@ int sn_dbg_ref_block_f16(sn_handle* h, const float* in, int h_px, int w, const f
             return SN_ERR_DEVICE;
           }
       }
-  hipFree(da_raw);
-  hipFree(db_raw);
-  hipFree(L1.wfrag);
-  hipFree(L1.bias);
-  hipFree(L2.wfrag);
-  hipFree(L2.bias);
   return SN_OK;
 }
 

@@ -56,15 +56,32 @@ class AsyncGather:
     That form exists so that the whole multi-rank path — real engine, real maps — can run where RCCL cannot, e.g. two
     ranks on ONE GPU in the tests; it is not a throughput path."""
 
-    def __init__(self, local: torch.Tensor, dst: int = 0):
+    def __init__(self, local: torch.Tensor, dst: int = 0, bufs: Optional[List[torch.Tensor]] = None):
+        """bufs: rank `dst`'s receive list (world tensors shaped like `local`), allocated ONCE by a caller that gathers
+        every step (alloc_root_buffers) — world x 236 MB at the metric's shard size is not something to allocate per
+        step; None allocates a fresh list (one-shot callers)."""
         world, rank = dist.get_world_size(), dist.get_rank()
         self.device = local.device
         self.staged = local.is_cuda and dist.get_backend() == "gloo"
         send = local.contiguous()
         if self.staged:
             send = send.cpu()                 # waits for the producing stream
-        self.bufs = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+        if rank != dst:
+            self.bufs = None
+        elif bufs is not None and not self.staged:
+            if len(bufs) != world or any(b.shape != send.shape or b.dtype != send.dtype or b.device != send.device for b in bufs):
+                raise ValueError("preallocated gather buffers do not match the shard")
+            self.bufs = bufs
+        else:
+            self.bufs = [torch.empty_like(send) for _ in range(world)]
         self.work = dist.gather(send, self.bufs, dst=dst, async_op=True)
+
+    @staticmethod
+    def alloc_root_buffers(local: torch.Tensor, dst: int = 0) -> Optional[List[torch.Tensor]]:
+        """The receive list of one gather on rank `dst` (None on the other ranks)."""
+        if dist.get_rank() != dst:
+            return None
+        return [torch.empty_like(local) for _ in range(dist.get_world_size())]
 
     def wait(self):
         if self.work is not None:

@@ -60,3 +60,28 @@ def random_nv12(w: int, h: int, seed: int) -> np.ndarray:
     """Random w x h NV12 image (h*3/2 rows of w bytes)."""
     rng = np.random.default_rng(seed)
     return rng.integers(0, 256, (h * 3 // 2) * w, dtype=np.uint8)
+
+
+def sbs_nv12_from_planes(left: np.ndarray, right: np.ndarray) -> np.ndarray:
+    """Side-by-side NV12 frame (FeedImg's input, stereonet_node.cpp:700-738) from two planar 3 x h x w uint8 eyes:
+    2w x h luma rows [left | right] followed by h/2 rows of interleaved UV (chroma = top-left sample of each 2x2)."""
+    _, h, w = left.shape
+    assert w % 2 == 0 and h % 2 == 0
+    out = np.empty((h * 3 // 2, 2 * w), np.uint8)
+    for k, eye in enumerate((left, right)):
+        out[:h, k * w:(k + 1) * w] = eye[0]
+        uv = out[h:, k * w:(k + 1) * w]
+        uv[:, 0::2] = eye[1][0::2, 0::2]
+        uv[:, 1::2] = eye[2][0::2, 0::2]
+    return out.ravel()
+
+
+def sbs_nv12_frame(w: int, h: int, dmax: int, seed: int) -> np.ndarray:
+    """Seeded stereo pair as the side-by-side NV12 frame a camera node would publish."""
+    return sbs_nv12_from_planes(*stereo_pair_u8(w, h, dmax, seed))
+
+
+def sbs_nv12_from_model_input(in6: np.ndarray) -> np.ndarray:
+    """The side-by-side NV12 frame whose eyes are the planes of an int8 model tensor (6 x h x w, bytes ^ 0x80)."""
+    u8 = np.ascontiguousarray(in6).view(np.uint8) ^ np.uint8(0x80)
+    return sbs_nv12_from_planes(u8[:3], u8[3:])

@@ -83,10 +83,11 @@ typedef struct sn_config {
   int dmax;          /* max disparity D (multiple of 16, <= 256); 0 = from the model file        */
   int precision;     /* SN_PREC_*; 0 = SN_PREC_F16                                                */
   int task_num;      /* async slots for sn_submit; <=0 -> 4 (stereonet_node.cpp:144)              */
-  int refine_chunk;  /* pairs per refinement-tower launch; <=0 -> sized so that the activations in    */
-                     /* flight fill the 256 MB Infinity Cache (2 at 1280x720, 4 at 1248x384, max 8)  */
+  int refine_chunk;  /* pairs per refinement-tower launch; <=0 -> sized by work per launch, about    */
+                     /* 3.7 Mpx (4 at 1280x720, 8 at 1248x384, max 8); the per-layer forms           */
+                     /* (SN_FUSE=0, SN_PREC_F16X3, SN_PREC_FP32) keep the Infinity-Cache sizing       */
   int piece;         /* pairs per low-resolution piece of the pipeline; <=0 -> 16 (the first piece of */
-                     /* a call is 2 pairs: nothing overlaps its low-resolution branch)               */
+                     /* a call is 2-4 pairs: nothing overlaps its low-resolution branch)             */
 } sn_config;
 
 typedef struct sn_io_info {
@@ -169,6 +170,9 @@ int sn_mgpu_create(const char *model_file, const sn_config *cfg, const int *devi
 int sn_mgpu_destroy(sn_mgpu *m);
 int sn_mgpu_get_info(const sn_mgpu *m, int *ndev, int *per_device_batch, int *gather_kind /* 1 peer copy, 2 RCCL */);
 int sn_mgpu_get_handle(sn_mgpu *m, int k, sn_handle **h);                  /* the engine of shard k (borrowed) */
+/* The borrowed engine shares its workspace with the sn_mgpu_* calls: use it (sn_infer_*, sn_submit, ...) only while
+ * no sn_mgpu_submit_device ticket is in flight and no other sn_mgpu_* call runs; sn_mgpu_infer_batch itself returns
+ * SN_ERR_BUSY while tickets are outstanding. */
 int sn_mgpu_infer_batch(sn_mgpu *m, int n, const int8_t *in_nchw6_host, int32_t *out_i32_host, float *out_disp_host);
 int sn_mgpu_infer_batch_device(sn_mgpu *m, int n, const int8_t *const *in_per_device, int32_t *out_i32_root,
                                float *out_disp_root);

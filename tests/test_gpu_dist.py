@@ -75,6 +75,44 @@ def test_stream_mode_contract_c5():
     assert d["config"]["refine"] == "multi" and d["config"]["refine_levels"] == 4
     assert d["stream"]["h2d_bytes_per_pair"] == 6 * 1242 * 375 and d["stream"]["d2h_bytes_per_pair"] == 4 * 1242 * 375
     assert d["value"] > 0 and d["timed_seconds"] >= 2.0 and d["unit"] == "pairs/s"
+    # the maps the pipeline delivered to host memory were checked: both buffer sets == the synchronous path bit for bit,
+    # one frame within the bound of the CPU oracle
+    assert d["verified"] is True and "bit-exact" in d["verification"] and "CPU oracle" in d["verification"]
+    assert d["epe_vs_oracle_px"] is not None and d["epe_vs_oracle_px"] < 1e-3
+
+
+@pytest.mark.gpu
+def test_stream_mode_verified_c2_nv12():
+    """The sustained stream at the metric's shape with FeedImg's side-by-side NV12 ingest: seeded stereo frames, the host
+    outputs of both buffer sets equal sn_preprocess_sbs_nv12_batch + sn_infer_batch on the same frames, and frame 0 is within
+    the bound of the oracle's own split / pre-process / network."""
+    r, lines = _run(["--config", "c2", "--stream", "2", "--batch", "8"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = lines[0]
+    assert d["stream"]["h2d_bytes_per_pair"] == 3 * 1280 * 720 and "NV12" in d["stream"]["ingest"]
+    assert d["verified"] is True and "sn_preprocess_sbs_nv12_batch" in d["verification"]
+    assert d["epe_vs_oracle_px"] is not None and d["epe_vs_oracle_px"] < 1e-3
+
+
+@pytest.mark.gpu
+def test_stream_mode_two_ranks_every_rank_verifies():
+    """N = 2 on one GPU: each rank streams its own seeded shard and verifies its own host outputs; `verified` is the AND."""
+    r, lines = _run(["--gpus", "2", "--dist-backend", "gloo", "--device-map", "0,0", "--config", "c5", "--stream", "1",
+                     "--batch", "4", "--no-cpu-baseline"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["verified"] is True and "all 2 ranks" in d["verification"]
+
+
+@pytest.mark.gpu
+def test_default_bench_end_to_end_figures_are_verified():
+    """The default mode's host-to-host figures (batched stream + the async single-pair path) are checked against the
+    synchronous path before they are reported."""
+    r, lines = _run(["--batch", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-long"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = lines[0]
+    assert d["verified"] is True
+    assert d["end_to_end"]["verified"] is True and d["end_to_end"]["async_single_pair"]["verified"] is True
 
 
 @pytest.mark.gpu

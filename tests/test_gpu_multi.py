@@ -165,7 +165,7 @@ np.save(sys.argv[3], disp)
 
 
 @pytest.mark.parametrize("env,exact", [({"SN_TOWER_STREAMS": "2"}, True), ({"SN_NO_OVERLAP": "1"}, True), ({"SN_REV": "0"}, True),
-                                       ({"SN_HEAD_FUSE": "0"}, False), ({"SN_FUSE": "3"}, False),
+                                       ({"SN_HEAD_FUSE": "0"}, False),
                                        ({"SN_TOWER_STREAMS": "2", "SN_HEAD_FUSE": "0"}, False),
                                        # round 3: the streamed blocks are bit-identical to the two-launch form, so every way
                                        # of mixing them (none, dilation 1 / 2 only, all but the last block) changes nothing ...
