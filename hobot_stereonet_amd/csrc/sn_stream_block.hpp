@@ -64,11 +64,22 @@
 
 namespace sn {
 
-template <int DIL_, int TW_ = 64, int R_ = 4, int NXS_ = 6, int NWR_ = 4>
+// HEAD_ = true: the LAST block of the tower with the refinement head folded in (see "Tail form" below).
+template <int DIL_, int TW_ = 64, int R_ = 4, int NXS_ = 6, int NWR_ = 4, bool HEAD_ = false>
 struct StreamTile {
-  static constexpr int DIL = DIL_, TW = TW_, R = R_, NXS = NXS_, NTS = 3, PF = NXS_ - 4;
+  static constexpr bool HEAD = HEAD_;
+  // HEAD: conv2's waves fetch the residual rows of a slot one super-step early (into registers), so the x ring needs
+  // groups q-2 .. q+2 only
+  static constexpr int DIL = DIL_, TW = TW_, R = R_, NXS = NXS_, NTS = 3, PF = NXS_ - (HEAD_ ? 3 : 4);
   static constexpr int NWR = NWR_;                         // waves per role (conv1 / conv2): 4 or 8
-  static constexpr int OW = TW - 2 * DIL;                  // output columns of a strip
+  static constexpr int HS = HEAD_ ? 1 : 0;                 // the head needs one more y row / column on every side
+  static constexpr int YW = TW - 2 * DIL;                  // valid y columns of a strip
+  static constexpr int OW = YW - 2 * HS;                   // output columns of a strip = strip pitch
+  static constexpr int X0OFF = -HS;                        // image column of y column 0 of strip 0
+  static constexpr int LAG = HEAD_ ? 3 : 2;                // super-steps the last pipeline stage runs behind the slot stream
+  static constexpr int PROWS = 2 * R + 2;                  // HEAD: row ring of the head's partial sums P[row][tap][TW] (fp32)
+  static constexpr int PRING_BYTES = HEAD_ ? PROWS * 9 * TW * 4 : 0;
+  static constexpr int WIN_BYTES = HEAD_ ? NWR_ * 2 * 64 * 4 : 0;      // HEAD: per conv1 wave, two 64-column windows of the low-resolution map
   static constexpr int XW = TW + 2 * DIL;                  // x columns of a strip
   static constexpr int CSEG = TW / 32;                     // 32-pixel MFMA segments per row
   static constexpr int SPW = R * CSEG / NWR;               // segments per wave and conv
@@ -80,10 +91,11 @@ struct StreamTile {
   static constexpr int TGP = R * TROW;
   static constexpr int XRING = NXS * XGP;
   static constexpr int TRING = NTS * TGP + 64;             // conv2's kx taps of the junk columns run past the last row
-  static constexpr int LDS_BYTES = (XRING + TRING) * 16 + 2 * 2 * 16 * 4;      // + bias tables [conv][k-half][16]
+  static constexpr int LDS_BYTES = (XRING + TRING) * 16 + 2 * 2 * 16 * 4 + PRING_BYTES + WIN_BYTES;      // + bias tables [conv][k-half][16]
   // image rows a DMA group may touch outside [0, H): a unit's slot 0 starts R sub-rows above its first output row
   // (row -R DIL at v0 = 0) and its last group ends at sub-row hsub + R, i.e. image row <= H + (R + 2) DIL - 2
-  static constexpr int ROWS_ABOVE = R * DIL, ROWS_BELOW = (R + 2) * DIL - 1;
+  static constexpr int ROWS_ABOVE = (R + HS) * DIL, ROWS_BELOW = (R + 2 + HS) * DIL - 1;
+  static_assert(!HEAD_ || (DIL_ == 1 && R_ == 4 && TW_ == 64 && NWR_ == 4), "the tail form is written for the dilation-1 strip shape");
   static_assert(SPW == 1 || SPW == 2, "segments per wave");
   static_assert(CSEG % SPW == 0, "a wave's segments lie in one row");
   static_assert(PF == 2, "prefetch distance the counted waits are written for");
@@ -99,7 +111,7 @@ struct StreamSched {
 };
 
 // Walks the slots of one workgroup's share: units in order, n + 1 slots each.  All members wave-uniform.
-template <int R>
+template <int R, int HS = 0>
 struct StreamIter {
   int f, f_end, hsub;            // cursor (first flat row of the NEXT unit), end of the share
   int sp, v0, v1, n, j, live;    // current unit: strip-phase, output sub-rows [v0, v1), steps; slot j = 0 .. n
@@ -110,7 +122,7 @@ struct StreamIter {
     int L = hsub - v0;
     if (L > f_end - f) L = f_end - f;
     v1 = v0 + L;
-    n = (L + 2 + R - 1) / R;
+    n = (L + 2 + 2 * HS + R - 1) / R;
     j = 0;
     f += L;
     live = 1;
@@ -188,16 +200,45 @@ __device__ __forceinline__ void glds16(unsigned lds_dst, unsigned voff, const vo
       : "memory");
 }
 
-template <int DIL, int TW, int R, int NXS, int NWR>
+// 4-byte form: lane l lands at lds_dst + 4 l
+__device__ __forceinline__ void glds4(unsigned lds_dst, unsigned voff, const void* base) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %1\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dword %2, %3\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "s"(lds_dst), "v"(voff), "s"(base)
+      : "memory");
+}
+
+// Arguments of the tail form (HEAD): the refinement head conv 3x3 32 -> 1 + `disp = relu(up + D r)` + wire quantisation,
+// exactly k_head_final_f16's arithmetic (same MFMA sequence for P, same order of the nine additions).
+struct StreamHeadArgs {
+  const float* w;          // [32][9] fp32 head weights
+  const float* disp_low;   // [nimg][hl][wl] map the level starts from
+  float* out_disp;         // [nimg][H][W] (nullable)
+  int32_t* out_raw;        // [nimg][H][W] wire map (nullable)
+  float bias, dmax, inv_q;
+  int hl, wl, H, W;        // H, W: size of the output maps (<= g.H, g.W)
+  UpScale ups;
+};
+
+template <int DIL, int TW, int R, int NXS, int NWR, bool HEAD = false>
 __global__ __launch_bounds__(128 * NWR, NWR / 2) __attribute__((amdgpu_waves_per_eu(NWR / 2, NWR / 2))) void k_ref_block_stream_f16(const uint4* __restrict__ xin, uint4* __restrict__ yout,
                                                                 const uint4* __restrict__ wfrag1, const float* __restrict__ bias1,
                                                                 const uint4* __restrict__ wfrag2, const float* __restrict__ bias2,
-                                                                RefGeom g, StreamSched sc, uint4* __restrict__ dump) {
-  using T = StreamTile<DIL, TW, R, NXS, NWR>;
+                                                                RefGeom g, StreamSched sc, uint4* __restrict__ dump, StreamHeadArgs ha) {
+  using T = StreamTile<DIL, TW, R, NXS, NWR, HEAD>;
+  constexpr int HS = T::HS;
   extern __shared__ __attribute__((aligned(16))) uint4 lds[];
   uint4* const xring = lds;
   uint4* const tring = lds + T::XRING;
   float* const s_bias = reinterpret_cast<float*>(tring + T::TRING);      // [conv][k-half][16]
+  float* const pring = s_bias + 64;                                       // HEAD: [PROWS][9][TW]
+  float* const s_win = pring + T::PRING_BYTES / 4;                        // HEAD: [conv1 wave][2][64]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, gh = lane >> 5;
@@ -208,18 +249,18 @@ __global__ __launch_bounds__(128 * NWR, NWR / 2) __attribute__((amdgpu_waves_per
   if (f1 > sc.total_rows) f1 = sc.total_rows;
   if (f0 >= f1) return;                                     // uniform for the workgroup: before any barrier
   SN_STAMP_WG(0);
-  // super-steps of this workgroup: its slots + two to drain conv2's MFMAs and epilogue
-  int nss = 2;
+  // super-steps of this workgroup: its slots + LAG to drain conv2's MFMAs and epilogue (+ the head's last stage)
+  int nss = T::LAG;
   for (int f = f0; f < f1;) {
     const int v0 = f % sc.hsub;
     int L = sc.hsub - v0;
     if (L > f1 - f) L = f1 - f;
-    nss += (L + 2 + R - 1) / R + 1;
+    nss += (L + 2 + 2 * HS + R - 1) / R + 1;
     f += L;
   }
   auto decode_sp = [&](int sp, int& img, int& py, int& x0) {
     const int t = sp / sc.nstrips;
-    x0 = (sp - t * sc.nstrips) * T::OW;
+    x0 = (sp - t * sc.nstrips) * T::OW + T::X0OFF;
     img = t / DIL;
     py = t - img * DIL;
   };
@@ -272,11 +313,11 @@ __global__ __launch_bounds__(128 * NWR, NWR / 2) __attribute__((amdgpu_waves_per
     // 0 — inside the tensor's zero border for dilation 1 / 2, in the zero slots IN FRONT of the tensor for dilation 4 / 8
     // (ref_front() in the host code) when it is image 0, channel block 0
     long last_base = 0;
-    auto dma_issue = [&](const StreamIter<R>& it, int grp) {
+    auto dma_issue = [&](const StreamIter<R, HS>& it, int grp) {
       if (it.live) {
         int img, py, x0;
         decode_sp(it.sp, img, py, x0);
-        const int row = (it.v0 - R + R * it.j) * DIL + py;               // image row of the group's first row (>= -2 DIL)
+        const int row = (it.v0 - HS - R + R * it.j) * DIL + py;          // image row of the group's first row (>= -(R + HS) DIL)
         last_base = (((long)img * 4 * g.Hs + (row + kRefPad)) * (long)g.Ws + (x0 - 2 * DIL + kRefPad)) * 16;
       }
       const char* src = reinterpret_cast<const char*>(xin) + last_base;
@@ -291,8 +332,16 @@ __global__ __launch_bounds__(128 * NWR, NWR / 2) __attribute__((amdgpu_waves_per
       if (kw == KWMAX) wait_vmcnt<KWMAX + E>();
       else wait_vmcnt<KWMAX - 1 + E>();
     };
-    StreamIter<R> dm, c1;
-    dm.live = c1.live = 0;
+    StreamIter<R, HS> dm, c1, fin, fin2;
+    dm.live = c1.live = fin.live = fin2.live = 0;
+    int fin_img = 0, fin_x0 = 0, fin2_img = 0, fin2_x0 = 0;
+    // first low-resolution column any lane of a strip's row touches (x0 of upsample_map at the strip's column 0)
+    auto win_first_col = [&](int xs) {
+      float sx = ((float)xs + 0.5f) * ha.ups.rs - 0.5f;
+      sx = sx < 0.f ? 0.f : sx;
+      return (int)sx;
+    };
+    int p4 = 0;                           // HEAD: (4 q) mod PROWS, the P ring position of slot q
     dm.step(0, 0, f0, f1, sc.hsub);
     dma_issue(dm, 0);
     dm.step(1, 0, f0, f1, sc.hsub);
@@ -309,7 +358,79 @@ __global__ __launch_bounds__(128 * NWR, NWR / 2) __attribute__((amdgpu_waves_per
       const int gx0 = qx, gx1 = qx >= 1 ? qx - 1 : qx - 1 + NXS;
       const int gxp = qx + 2 >= NXS ? qx + 2 - NXS : qx + 2;
       SN_STAMP(0);
-      dma_issue(dm, gxp);                 // overwrites group q-4: last read (residual of slot q-3) in super-step q-1
+      if constexpr (HEAD) {
+        // ---- last stage of the tail form, slot q-3 (its P rows were written in super-step q-1, the rows above them in
+        // q-2): lane c = column c of this wave's row; out(y, x) = relu(up + D (bias + sum of nine shifted P values)).
+        // Runs BEFORE this step's DMA group is issued: its two stores are then older than the group and the counted
+        // wait below needs no extra term; the upsample taps come through scalar loads (lgkmcnt, not vmcnt).
+        fin.step(q, 3, f0, f1, sc.hsub);
+        if (fin.live && fin.j >= 1) {
+          if (fin.j == 1) {
+            int py;
+            decode_sp(fin.sp, fin_img, py, fin_x0);
+          }
+          const int o = fin.v0 - 4 + R * (fin.j - 1) + rowW;                   // output row of this wave
+          if (o >= fin.v0 && o < fin.v1 && o < ha.H) {                          // uniform
+            const int pb = p4 + 8 >= T::PROWS ? p4 + 8 - T::PROWS : p4 + 8;     // ring row of slot q-3's row 0
+            float acc = ha.bias;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+              int pr = pb + rowW - 2 + ky;
+              pr = pr < 0 ? pr + T::PROWS : (pr >= T::PROWS ? pr - T::PROWS : pr);
+              const float* prow = pring + pr * (9 * TW) + lane - 1;
+#pragma unroll
+              for (int kx = 0; kx < 3; ++kx) acc += prow[(ky * 3 + kx) * TW + kx];
+            }
+            const int X = fin_x0 + lane;
+            // upsample_map's arithmetic on the two row windows the previous super-step staged in LDS (column cb + l at l)
+            float sy = ((float)o + 0.5f) * ha.ups.rs - 0.5f;
+            float sx = ((float)X + 0.5f) * ha.ups.rs - 0.5f;
+            sy = sy < 0.f ? 0.f : sy;
+            sx = sx < 0.f ? 0.f : sx;
+            const int y0 = (int)sy, x0 = (int)sx;
+            const int x1 = x0 < ha.wl - 1 ? x0 + 1 : x0;
+            const float ly = sy - (float)y0, lx = sx - (float)x0;
+            const float hy = 1.0f - ly, hx = 1.0f - lx;
+            const int cb = win_first_col(fin_x0);
+            const float* w0 = s_win + rw * 128;
+            const float v = hy * (hx * w0[x0 - cb] + lx * w0[x1 - cb]) + ly * (hx * w0[64 + x0 - cb] + lx * w0[64 + x1 - cb]);
+            const float up = v * ha.ups.mul;
+            float d = up + ha.dmax * acc;
+            d = d > 0.f ? d : 0.f;
+            if (lane >= 1 && lane <= T::OW && X < ha.W) {
+              const size_t oi = ((size_t)fin_img * ha.H + o) * ha.W + X;
+              if (ha.out_disp) ha.out_disp[oi] = d;
+              if (ha.out_raw) ha.out_raw[oi] = (int32_t)__float2int_rn(d * ha.inv_q);
+            }
+          }
+        }
+      }
+      if constexpr (HEAD) {
+        // the two low-resolution row windows of the NEXT super-step's last stage, by 4-byte LDS-DMA: issued before this
+        // step's x group, so the counted wait at the end of the step (everything but the youngest group) covers them
+        fin2.step(q, 2, f0, f1, sc.hsub);
+        if (fin2.live && fin2.j >= 1) {
+          if (fin2.j == 1) {
+            int py;
+            decode_sp(fin2.sp, fin2_img, py, fin2_x0);
+          }
+          const int o = fin2.v0 - 4 + R * (fin2.j - 1) + rowW;
+          if (o >= fin2.v0 && o < fin2.v1 && o < ha.H) {                        // uniform
+            float sy = ((float)o + 0.5f) * ha.ups.rs - 0.5f;
+            sy = sy < 0.f ? 0.f : sy;
+            const int y0 = (int)sy;
+            const int y1 = y0 < ha.hl - 1 ? y0 + 1 : y0;
+            int c = win_first_col(fin2_x0) + lane;
+            c = c < ha.wl - 1 ? c : ha.wl - 1;
+            const float* lowp = ha.disp_low + (size_t)fin2_img * ha.hl * ha.wl;
+            const unsigned dst = lds_addr(s_win + rw * 128);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // this wave's reads of the windows above are done
+            glds4(dst, (unsigned)c * 4u, lowp + (size_t)y0 * ha.wl);
+            glds4(dst + 256u, (unsigned)c * 4u, lowp + (size_t)y1 * ha.wl);
+          }
+        }
+      }
+      dma_issue(dm, gxp);                 // overwrites group q+2-NXS: last read (residual of slot q-3 / HEAD: q-2) in super-step q-1
       SN_STAMP(1);
       if (do1) {
         if (c1.j == 1) {                  // a new unit: strip origin and row phase (two scalar divisions)
@@ -328,7 +449,7 @@ __global__ __launch_bounds__(128 * NWR, NWR / 2) __attribute__((amdgpu_waves_per
         stream_conv36<DIL, T::XW, T::SPW>(xp, wf, bv, acc);
         SN_STAMP(2);
         // epilogue: t = lrelu(acc) as fp16, zero outside the image (conv2's zero padding)
-        const int trow = (c1.v0 - 1 + R * (c1.j - 1) + rowW) * DIL + c1_py;            // image row of this wave's t row
+        const int trow = (c1.v0 - HS - 1 + R * (c1.j - 1) + rowW) * DIL + c1_py;       // image row of this wave's t row
         const bool row_ok = trow >= 0 && trow < g.H;
         const int tc0 = c1_x0 - DIL;                                                  // image column of t column 0
         const bool interior = row_ok && tc0 >= 0 && tc0 + TW <= g.W;
@@ -365,6 +486,7 @@ __global__ __launch_bounds__(128 * NWR, NWR / 2) __attribute__((amdgpu_waves_per
       block_barrier();
       qx = qx + 1 == NXS ? 0 : qx + 1;
       qt = qt + 1 == T::NTS ? 0 : qt + 1;
+      p4 = p4 + R >= T::PROWS ? p4 + R - T::PROWS : p4 + R;
     }
     SN_STAMP_WG(1);
   } else {
@@ -373,8 +495,28 @@ __global__ __launch_bounds__(128 * NWR, NWR / 2) __attribute__((amdgpu_waves_per
     const int lane_y = 2 * DIL + cseg0 * 32 + j;           // residual: block qd, 8 bytes at gh * 8
     block_barrier();
 
-    StreamIter<R> c2, ep;
+    StreamIter<R, HS> c2, ep;
     c2.live = ep.live = 0;
+    // HEAD: the head's A fragments as k_head_final_f16 builds them (row i = tap, k = 8 gh + e <-> channel 16 kk + 8 gh + e,
+    // fp32 weights split hi / lo), and the residual of the slot whose MFMAs run in this super-step, fetched one step early
+    half8 ah[2], al[2];
+    uint2 rres[T::SPW][4];
+    int p4 = 0;
+    if constexpr (HEAD) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float wv = j < 9 ? ha.w[(16 * kk + 8 * gh + e) * 9 + j] : 0.f;
+          const _Float16 hi = (_Float16)wv;
+          ah[kk][e] = hi;
+          al[kk][e] = (_Float16)((wv - (float)hi) * kSplitScale);
+        }
+#pragma unroll
+      for (int s = 0; s < T::SPW; ++s)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) rres[s][qd] = uint2{0u, 0u};
+    }
     int ep_img = 0, ep_py = 0, ep_x0 = 0;
     float one = 1.0f;
     asm volatile("" : "+v"(one));          // opaque: keeps the multiply so that hipcc selects v_fma_mix_f32 for the residual
@@ -398,8 +540,56 @@ __global__ __launch_bounds__(128 * NWR, NWR / 2) __attribute__((amdgpu_waves_per
       // wave is here, the SIMD's conv1 wave has the matrix pipe to itself; y = lrelu(x + acc) -> global memory ----
       if (doe) {
         if (ep.j == 1) decode_sp(ep.sp, ep_img, ep_py, ep_x0);
-        const int sub = ep.v0 - 2 + R * (ep.j - 1) + rowW;
+        const int sub = ep.v0 - HS - 2 + R * (ep.j - 1) + rowW;
         const int row = sub * DIL + ep_py;
+        if constexpr (HEAD) {
+          // ---- tail form: y (rounded to fp16 exactly as the tensor would have held it, zero outside the image) goes
+          // straight into the head's MFMAs as the B operand; P[tap][pixel] -> the P ring; nothing is stored ----
+          const bool row_ok = row >= 0 && row < g.H;
+          int prow = p4 + 2 + rowW;                            // ring row of slot q-2's row rowW
+          prow = prow >= T::PROWS ? prow - T::PROWS : prow;
+#pragma unroll
+          for (int s = 0; s < T::SPW; ++s) {
+            const int col = ep_x0 + (cseg0 + s) * 32 + j;
+            const bool ok = row_ok && col >= 0 && col < g.W;
+            unsigned pk[4][2];
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+              const half4 rv = *reinterpret_cast<const half4*>(&rres[s][qd]);
+              half4 hv;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float u = lrelu_fast(__builtin_fmaf((float)rv[e], one, acc[s][4 * qd + e]));
+                hv[e] = ok ? (_Float16)u : (_Float16)0.f;
+              }
+              const uint2 u2 = *reinterpret_cast<const uint2*>(&hv);
+              pk[qd][0] = u2.x;
+              pk[qd][1] = u2.y;
+            }
+            // half exchange between channel blocks (0, 1) and (2, 3): lanes gh = 0 end up with the whole slot of block 2 kk,
+            // lanes gh = 1 with that of block 2 kk + 1 = the B operand of K-step kk
+            f32x16 a0, a1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              a0[r] = 0.f;
+              a1[r] = 0.f;
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+              const auto r0 = __builtin_amdgcn_permlane32_swap(pk[2 * kk][0], pk[2 * kk + 1][0], false, false);
+              const auto r1 = __builtin_amdgcn_permlane32_swap(pk[2 * kk][1], pk[2 * kk + 1][1], false, false);
+              const uint4 sl = uint4{r0[0], r1[0], r0[1], r1[1]};
+              const half8 xh = *reinterpret_cast<const half8*>(&sl);
+              a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk], xh, a0, 0, 0, 0);
+              a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[kk], xh, a1, 0, 0, 0);
+            }
+            // accumulator row (r & 3) + 8 (r >> 2) + 4 gh: lanes gh = 0 hold taps 0..3 (r 0..3) and 8 (r 4), gh = 1 taps 4..7
+            float* dst = pring + prow * (9 * TW) + (cseg0 + s) * 32 + j;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[(4 * gh + r) * TW] = a0[r] + a1[r] * kSplitInv;
+            if (gh == 0) dst[8 * TW] = a0[4] + a1[4] * kSplitInv;
+          }
+        } else
         if (sub >= ep.v0 && sub < ep.v1 && row < g.H) {     // uniform: the unit's first two rows are junk
           const int rr = rowW - 2;
           const uint4* xrow = xring + (rr < 0 ? gx3 : gx2) * T::XGP + (rr & (R - 1)) * T::XROW + lane_y;
@@ -457,6 +647,16 @@ __global__ __launch_bounds__(128 * NWR, NWR / 2) __attribute__((amdgpu_waves_per
       SN_STAMP(1);
       // ---- conv2 MFMAs of slot q-1: t rows rowW-2 .. rowW of t slot q-1 (negative: the last rows of slot q-2) ----
       if (do2) {
+        if constexpr (HEAD) {        // residual rows of THIS slot (x groups q-2 / q-1), kept in registers for the next super-step's epilogue
+          const int rr = rowW - 2;
+          const int gx1 = qx >= 1 ? qx - 1 : qx - 1 + NXS;
+          const uint4* xrow = xring + (rr < 0 ? gx2 : gx1) * T::XGP + (rr & (R - 1)) * T::XROW + lane_y;
+#pragma unroll
+          for (int s = 0; s < T::SPW; ++s)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd)
+              rres[s][qd] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(xrow + qd * T::XW + s * 32) + gh * 8);
+        }
         const uint4* tp[3];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
@@ -472,6 +672,7 @@ __global__ __launch_bounds__(128 * NWR, NWR / 2) __attribute__((amdgpu_waves_per
       block_barrier();
       qx = qx + 1 == NXS ? 0 : qx + 1;
       qt = qt + 1 == T::NTS ? 0 : qt + 1;
+      p4 = p4 + R >= T::PROWS ? p4 + R - T::PROWS : p4 + R;
     }
   }
 }

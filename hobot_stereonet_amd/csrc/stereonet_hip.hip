@@ -151,6 +151,7 @@ struct sn_handle {
   bool overlap = true;
   int tower_streams = kMaxTowerStreams;
   bool stream_last = true;   // the last block streamed too + separate head launch (SN_STREAM_LAST=0: conv + fused conv/head)
+  bool tail_fuse = true;     // the streamed last block carries the head (tail form); SN_TAIL_FUSE=0: block + k_head_final_f16
   int fuse_mode = 4;         // SN_FUSE: 4 = streaming fused blocks (default), 0 = two launches per block
   bool head_fuse = true;     // last tower conv + head in one kernel (fp16 mode; SN_HEAD_FUSE=0 separates them)
   unsigned* dump = nullptr;  // 2 KB device scratch: where lanes without an output pixel store (fused head)
@@ -637,6 +638,8 @@ using StreamTile1 = StreamTile<1, 64, 4, 6, 4>;
 using StreamTile2 = StreamTile<2, 64, 4, 6, 4>;
 using StreamTile4 = StreamTile<4, 128, 2, 6, 4>;
 using StreamTile8 = StreamTile<8, 128, 2, 6, 4>;
+using StreamTileTail = StreamTile<1, 64, 4, 5, 4, true>;      // last block + refinement head (x ring of 5 groups: early residual fetch)
+static_assert(StreamTileTail::ROWS_ABOVE <= kRefPad && StreamTileTail::ROWS_BELOW <= StreamTile8::ROWS_BELOW, "tail form stays inside the zero rows");
 constexpr int cmax4(int a, int b, int c, int d) { return (a > b ? a : b) > (c > d ? c : d) ? (a > b ? a : b) : (c > d ? c : d); }
 constexpr int kStreamRowsAbove = cmax4(StreamTile1::ROWS_ABOVE, StreamTile2::ROWS_ABOVE, StreamTile4::ROWS_ABOVE, StreamTile8::ROWS_ABOVE);
 constexpr int kStreamRowsBelow = cmax4(StreamTile1::ROWS_BELOW, StreamTile2::ROWS_BELOW, StreamTile4::ROWS_BELOW, StreamTile8::ROWS_BELOW);
@@ -764,15 +767,18 @@ hipError_t launch_ref_f16_v2(hipStream_t st, const RefLayerF16& L, const RefGeom
 // the flattened (image, row phase, strip, sub-row) sequence.  x and y must be different tensors.  dump: >= 1 KB scratch.
 template <class T>
 hipError_t launch_ref_block_stream(hipStream_t st, const RefLayerF16& L1, const RefLayerF16& L2, const RefGeom& g, int num_cu,
-                                   const uint4* x, uint4* y, int nimg, unsigned* dump) {
+                                   const uint4* x, uint4* y, int nimg, unsigned* dump, const StreamHeadArgs& ha = StreamHeadArgs{}) {
   constexpr int DIL = T::DIL;
-  auto kern = k_ref_block_stream_f16<T::DIL, T::TW, T::R, T::NXS, T::NWR>;
+  auto kern = k_ref_block_stream_f16<T::DIL, T::TW, T::R, T::NXS, T::NWR, T::HEAD>;
   if (dump == nullptr) return hipErrorInvalidValue;
   hipError_t e = ensure_lds_attr(kern, T::LDS_BYTES);
   if (e != hipSuccess) return e;
   StreamSched sc;
-  sc.nstrips = (g.W + T::OW - 1) / T::OW;
-  sc.hsub = (g.H + DIL - 1) / DIL;
+  // the tail form walks the OUTPUT maps (H x W of the head, <= the tensor's valid area), the others the whole tensor
+  const int Wn = T::HEAD ? ha.W : g.W, Hn = T::HEAD ? ha.H : g.H;
+  if (T::HEAD && (!ha.w || !ha.disp_low || (!ha.out_disp && !ha.out_raw) || ha.W > g.W || ha.H > g.H || ha.ups.rs > 0.5f)) return hipErrorInvalidValue;
+  sc.nstrips = (Wn + T::OW - 1) / T::OW;
+  sc.hsub = (Hn + DIL - 1) / DIL;
   sc.total_rows = nimg * DIL * sc.nstrips * sc.hsub;
   static const int wg_env = getenv("SN_STREAM_WGS") ? atoi(getenv("SN_STREAM_WGS")) : 0;     // experiment switch
   int nwg = wg_env > 0 ? wg_env : num_cu;
@@ -781,8 +787,15 @@ hipError_t launch_ref_block_stream(hipStream_t st, const RefLayerF16& L1, const 
   sc.rows_per_wg = (sc.total_rows + nwg - 1) / nwg;
   const int grid = (sc.total_rows + sc.rows_per_wg - 1) / sc.rows_per_wg;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), T::LDS_BYTES, st, x, y, L1.wfrag, L1.bias, L2.wfrag, L2.bias, g, sc,
-                     reinterpret_cast<uint4*>(dump));
+                     reinterpret_cast<uint4*>(dump), ha);
   return hipGetLastError();
+}
+
+// Last block of the tower + the refinement head in one launch (tail form): y never leaves the CU, the head's maps are the
+// only thing written.  Same arithmetic as the streamed block followed by k_head_final_f16 (bit-identical maps).
+hipError_t ref_block_stream_tail(hipStream_t st, const RefLayerF16& L1, const RefLayerF16& L2, const RefGeom& g, int num_cu,
+                                 const uint4* x, int nimg, unsigned* dump, const StreamHeadArgs& ha) {
+  return launch_ref_block_stream<StreamTileTail>(st, L1, L2, g, num_cu, x, nullptr, nimg, dump, ha);
 }
 
 // Strip shapes: 64 columns x 4 rows per step for dilation 1 / 2 (62 / 60 of 64 columns are outputs); 128 columns x 2 rows
@@ -1232,6 +1245,8 @@ int refine_level(sn_handle* h, Workspace& ws, hipStream_t st, const Tower& T, fl
     // (a streamed last block leaves its output in memory: the head then runs as its own launch)
     const bool last_block_fused = h->fuse_mode == 4 && stream_block_supports(kRefDil[kNRefRes - 1]) && h->stream_last;
     const bool head_fused = !x3 && h->head_fuse && kRefDil[kNRefRes - 1] == 1 && !last_block_fused;
+    // tail form: the streamed last block computes the head too (its output tensor is never written, no head launch)
+    const bool tail = !x3 && last_block_fused && h->tail_fuse && kRefDil[kNRefRes - 1] == 1 && ups.rs <= 0.5f;
     for (int i = 0; i < kNRefRes; ++i) {
       if (x3) {
         HIP_TRY(h, ref_conv_f16x3(st, T.rres16[i][0], g, ncu, kRefDil[i], x16, t16, nullptr, lo_slots, c, true));
@@ -1243,6 +1258,10 @@ int refine_level(sn_handle* h, Workspace& ws, hipStream_t st, const Tower& T, fl
         if (pe) HIP_TRY(h, hipEventRecord(h->ev[5], st));          // the 11 plain tower launches end here
         HIP_TRY(h, launch_ref_conv_head_f16(st, T.rres16[i][1], g, ncu, t16, x16, c, ctr + kTileCtrStride, T.rout.w,
                                             T.rout.bias, src, sh, sw, H, W, dnorm, inv_q, ups, od, orw, h->dump));
+      } else if (tail && i == kNRefRes - 1) {
+        if (pe) HIP_TRY(h, hipEventRecord(h->ev[5], st));          // the plain tower launches end here
+        StreamHeadArgs ha{T.rout.w, src, od, orw, T.rout.bias, dnorm, inv_q, sh, sw, H, W, ups};
+        HIP_TRY(h, ref_block_stream_tail(st, T.rres16[i][0], T.rres16[i][1], g, ncu, x16, c, h->dump, ha));
       } else {
         const bool dom = pe && h->fuse_mode == 4 && stream_block_supports(kRefDil[i]) && h->dom_pairs < 6;
         if (dom) HIP_TRY(h, hipEventRecord(h->ev_dom[2 * h->dom_pairs], st));
@@ -1251,7 +1270,7 @@ int refine_level(sn_handle* h, Workspace& ws, hipStream_t st, const Tower& T, fl
         if (dom) HIP_TRY(h, hipEventRecord(h->ev_dom[2 * h->dom_pairs++ + 1], st));
       }
     }
-    if (!head_fused) {
+    if (!head_fused && !tail) {
       if (pe) HIP_TRY(h, hipEventRecord(h->ev[5], st));
       HIP_TRY(h, launch_head_final_f16(st, x3, x16, lo_slots, g, T.rout.w, T.rout.bias, src, sh, sw, H, W, dnorm, inv_q, ups,
                                        od, orw, c));
@@ -1650,6 +1669,7 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
   h->fuse_mode = fuse_env();
   // the last block streamed as well + the head as its own launch (default); SN_STREAM_LAST=0: conv + fused conv / head
   h->stream_last = !(getenv("SN_STREAM_LAST") != nullptr && atoi(getenv("SN_STREAM_LAST")) == 0);
+  h->tail_fuse = !(getenv("SN_TAIL_FUSE") != nullptr && atoi(getenv("SN_TAIL_FUSE")) == 0);
   h->head_fuse = head_fuse_env();
   if (hipMalloc(reinterpret_cast<void**>(&h->dump), 4096) != hipSuccess) return fail(SN_ERR_NOMEM);
 
@@ -2138,7 +2158,7 @@ int sn_get_dominant_kernel(sn_handle* h, char* name, size_t cap, int* launches, 
     int n = 0;
     for (int i = 0; i < kNRefRes; ++i) {
       const bool last = i == kNRefRes - 1;
-      if (stream_block_supports(kRefDil[i]) && (!last || h->stream_last || !h->head_fuse)) ++n;
+      if (stream_block_supports(kRefDil[i]) && (!last || ((h->stream_last || !h->head_fuse) && !(h->stream_last && h->tail_fuse)))) ++n;
     }
     if (n > 0) {     // (n == 0, e.g. SN_STREAM_DIL=0: nothing is streamed — the per-layer description below applies)
       if (name && cap)
