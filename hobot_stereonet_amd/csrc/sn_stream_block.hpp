@@ -62,6 +62,17 @@
 #define SN_STAMP_WG(k) do { } while (0)
 #endif
 
+#ifndef SN_T_WRITE_B64
+// 1 (default) = conv1 writes t as four 8-byte half slots per segment; 0 = half exchange (v_permlane32_swap) + two
+// conflict-free ds_write_b128.  The 16-byte form removes the t-write half of the kernel's LDS bank conflicts but its eight
+// extra VALU instructions per wave and step cost more than the conflicts did: 155.6 vs 152.8 us per dilation-1 block,
+// 163.3 vs 159.7 (dilation 2), 2760 vs 2776 pairs/s end to end (A/B on one box, round 4).
+#define SN_T_WRITE_B64 1
+#endif
+#ifndef SN_TAIL_EXP
+#define SN_TAIL_EXP 0      // development: 1 = no last stage, 2 = no head MFMAs / P writes, 3 = no head epilogue at all (wrong results)
+#endif
+
 namespace sn {
 
 // HEAD_ = true: the LAST block of the tower with the refinement head folded in (see "Tail form" below).
@@ -134,6 +145,17 @@ struct StreamIter {
     if (live && ++j > n) next_unit();
   }
 };
+
+// fp16 pair of (lrelu(a), lrelu(b)).  Deliberately scalar fp32 math: a packed form (v_pk_mul_f32, and hipcc then also
+// turned the residual's v_fma_mix_f32 into v_cvt_f32_f16 + v_pk_fma_f32) has the same instruction count and measured
+// 173 instead of 157 us per dilation-1 block — the packed fp32 instructions are not full rate here.
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned lrelu_pack2(float a, float b) {
+  half2v h;
+  h[0] = (_Float16)lrelu_fast(a);
+  h[1] = (_Float16)lrelu_fast(b);
+  return *reinterpret_cast<const unsigned*>(&h);
+}
 
 // 32-bit LDS byte address of a pointer into the workgroup's shared memory (operand of hand-written ds_* instructions)
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
@@ -364,7 +386,7 @@ __global__ __launch_bounds__(128 * NWR, NWR / 2) __attribute__((amdgpu_waves_per
         // Runs BEFORE this step's DMA group is issued: its two stores are then older than the group and the counted
         // wait below needs no extra term; the upsample taps come through scalar loads (lgkmcnt, not vmcnt).
         fin.step(q, 3, f0, f1, sc.hsub);
-        if (fin.live && fin.j >= 1) {
+        if (fin.live && fin.j >= 1 && SN_TAIL_EXP != 1) {
           if (fin.j == 1) {
             int py;
             decode_sp(fin.sp, fin_img, py, fin_x0);
@@ -409,7 +431,7 @@ __global__ __launch_bounds__(128 * NWR, NWR / 2) __attribute__((amdgpu_waves_per
         // the two low-resolution row windows of the NEXT super-step's last stage, by 4-byte LDS-DMA: issued before this
         // step's x group, so the counted wait at the end of the step (everything but the youngest group) covers them
         fin2.step(q, 2, f0, f1, sc.hsub);
-        if (fin2.live && fin2.j >= 1) {
+        if (fin2.live && fin2.j >= 1 && SN_TAIL_EXP != 1) {
           if (fin2.j == 1) {
             int py;
             decode_sp(fin2.sp, fin2_img, py, fin2_x0);
@@ -464,16 +486,29 @@ __global__ __launch_bounds__(128 * NWR, NWR / 2) __attribute__((amdgpu_waves_per
               const int c = tc0 + (cseg0 + s) * 32 + j;
               inside = row_ok && c >= 0 && c < g.W;
             }
+            unsigned pk[4][2];
 #pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-              half4 hv;
+            for (int qd = 0; qd < 4; ++qd)
 #pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const float u = lrelu_fast(acc[s][4 * qd + e]);
-                hv[e] = (decltype(is_interior)::value || inside) ? (_Float16)u : (_Float16)0.f;
+              for (int hp = 0; hp < 2; ++hp) {
+                const unsigned u = lrelu_pack2(acc[s][4 * qd + 2 * hp], acc[s][4 * qd + 2 * hp + 1]);
+                pk[qd][hp] = (decltype(is_interior)::value || inside) ? u : 0u;
               }
-              *reinterpret_cast<half4*>(reinterpret_cast<char*>(tw + qd * T::TW + s * 32) + gh * 8) = hv;
+#if SN_T_WRITE_B64
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd)
+              *reinterpret_cast<uint2*>(reinterpret_cast<char*>(tw + qd * T::TW + s * 32) + gh * 8) = uint2{pk[qd][0], pk[qd][1]};
+#else
+            // half exchange between blocks (k, k + 2) as in conv2's store path: lane (j, gh) ends up with the whole 16-byte
+            // slots of blocks 2 gh and 2 gh + 1 -> two conflict-free ds_write_b128 instead of four 8-byte writes at a
+            // 16-byte stride, which use half of the banks (SQ_LDS_BANK_CONFLICT: 11-14 % of the LDS cycles of round 3)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              const auto r0 = __builtin_amdgcn_permlane32_swap(pk[k][0], pk[k + 2][0], false, false);
+              const auto r1 = __builtin_amdgcn_permlane32_swap(pk[k][1], pk[k + 2][1], false, false);
+              tw[(2 * gh + k) * T::TW + s * 32] = uint4{r0[0], r1[0], r0[1], r1[1]};
             }
+#endif
           }
         };
         if (interior) write_t(std::true_type{});
@@ -542,10 +577,12 @@ __global__ __launch_bounds__(128 * NWR, NWR / 2) __attribute__((amdgpu_waves_per
         if (ep.j == 1) decode_sp(ep.sp, ep_img, ep_py, ep_x0);
         const int sub = ep.v0 - HS - 2 + R * (ep.j - 1) + rowW;
         const int row = sub * DIL + ep_py;
-        if constexpr (HEAD) {
+        if constexpr (HEAD && SN_TAIL_EXP == 3) {
+        } else if constexpr (HEAD) {
           // ---- tail form: y (rounded to fp16 exactly as the tensor would have held it, zero outside the image) goes
           // straight into the head's MFMAs as the B operand; P[tap][pixel] -> the P ring; nothing is stored ----
           const bool row_ok = row >= 0 && row < g.H;
+          const bool interior = row_ok && ep_x0 >= 0 && ep_x0 + TW <= g.W;      // uniform: no masking at all
           int prow = p4 + 2 + rowW;                            // ring row of slot q-2's row rowW
           prow = prow >= T::PROWS ? prow - T::PROWS : prow;
 #pragma unroll
@@ -556,15 +593,17 @@ __global__ __launch_bounds__(128 * NWR, NWR / 2) __attribute__((amdgpu_waves_per
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
               const half4 rv = *reinterpret_cast<const half4*>(&rres[s][qd]);
-              half4 hv;
 #pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const float u = lrelu_fast(__builtin_fmaf((float)rv[e], one, acc[s][4 * qd + e]));
-                hv[e] = ok ? (_Float16)u : (_Float16)0.f;
+              for (int hp = 0; hp < 2; ++hp)
+                pk[qd][hp] = lrelu_pack2(__builtin_fmaf((float)rv[2 * hp], one, acc[s][4 * qd + 2 * hp]),
+                                         __builtin_fmaf((float)rv[2 * hp + 1], one, acc[s][4 * qd + 2 * hp + 1]));
+            }
+            if (!interior) {
+#pragma unroll
+              for (int qd = 0; qd < 4; ++qd) {
+                pk[qd][0] = ok ? pk[qd][0] : 0u;
+                pk[qd][1] = ok ? pk[qd][1] : 0u;
               }
-              const uint2 u2 = *reinterpret_cast<const uint2*>(&hv);
-              pk[qd][0] = u2.x;
-              pk[qd][1] = u2.y;
             }
             // half exchange between channel blocks (0, 1) and (2, 3): lanes gh = 0 end up with the whole slot of block 2 kk,
             // lanes gh = 1 with that of block 2 kk + 1 = the B operand of K-step kk
@@ -573,6 +612,10 @@ __global__ __launch_bounds__(128 * NWR, NWR / 2) __attribute__((amdgpu_waves_per
             for (int r = 0; r < 16; ++r) {
               a0[r] = 0.f;
               a1[r] = 0.f;
+            }
+            if (SN_TAIL_EXP == 2) {
+              if (pk[0][0] == 0x12345678u) pring[lane] = (float)(pk[0][1] + pk[1][0] + pk[1][1] + pk[2][0] + pk[2][1] + pk[3][0] + pk[3][1]);
+              continue;
             }
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
@@ -605,18 +648,10 @@ __global__ __launch_bounds__(128 * NWR, NWR / 2) __attribute__((amdgpu_waves_per
 #else
               const half4 rv = *reinterpret_cast<const half4*>(reinterpret_cast<const char*>(xrow + qd * T::XW + s * 32) + gh * 8);
 #endif
-              half4 hv;
 #pragma unroll
-#if defined(SN_STREAM_EXP) && SN_STREAM_EXP == 3
-              for (int e = 0; e < 4; ++e) hv[e] = (_Float16)(__builtin_fmaf((float)rv[e], one, acc[s][4 * qd + e]));      // experiment: no lrelu
-#elif defined(SN_STREAM_EXP) && SN_STREAM_EXP == 4
-              for (int e = 0; e < 4; ++e) hv[e] = (_Float16)(acc[s][4 * qd + e]);      // experiment: only the conversion
-#else
-              for (int e = 0; e < 4; ++e) hv[e] = (_Float16)lrelu_fast(__builtin_fmaf((float)rv[e], one, acc[s][4 * qd + e]));
-#endif
-              const uint2 u = *reinterpret_cast<const uint2*>(&hv);
-              pk[qd][0] = u.x;
-              pk[qd][1] = u.y;
+              for (int hp = 0; hp < 2; ++hp)
+                pk[qd][hp] = lrelu_pack2(__builtin_fmaf((float)rv[2 * hp], one, acc[s][4 * qd + 2 * hp]),
+                                         __builtin_fmaf((float)rv[2 * hp + 1], one, acc[s][4 * qd + 2 * hp + 1]));
             }
             // half exchange (v_permlane32_swap: lanes 32-63 of the first operand <-> lanes 0-31 of the second): blocks
             // (0, 2) and (1, 3) trade halves, so lanes gh = 0 end up with the full slots of blocks 0, 1 and lanes gh = 1
