@@ -40,6 +40,9 @@ class DnnNode : public rclcpp::Node {
   // the GPU, bit-identical to the host steps, and the host ships 2.76 MB per frame instead of the 5.53 MB tensor.
   int RunSbsNv12(const uint8_t* sbs_nv12, int width2, int height, const std::shared_ptr<DnnNodeOutput>& output = nullptr,
                  bool is_sync_mode = false, int alloc_chn_timeout_ms = -1);
+  // Extension (measurement / shutdown helper): blocks until every asynchronous request accepted so far has been through
+  // PostProcess.
+  void WaitIdle();
 
  protected:
   virtual int SetNodePara() = 0;
@@ -62,6 +65,8 @@ class DnnNode : public rclcpp::Node {
   std::mutex mu_;
   std::condition_variable cv_;
   std::deque<Pending> pending_;
+  int busy_ = 0;                      // asynchronous requests accepted and not yet through PostProcess
+  std::condition_variable idle_cv_;
   std::atomic<bool> stop_{false};
   // fps statistics (the "input fps / out fps" log line, stereonet_node.cpp:1071-1086)
   int in_count_ = 0, out_count_ = 0;

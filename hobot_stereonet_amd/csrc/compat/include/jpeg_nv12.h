@@ -10,5 +10,7 @@ namespace hobot {
 namespace stereonet {
 // `pitch` = bytes per source row (w for a contiguous eye, 2w for the left half of a side-by-side frame).
 bool EncodeNv12ToJpeg(const uint8_t* nv12, int w, int h, int pitch, int quality, std::vector<uint8_t>& out);
+// The exact-DCT form of round 3 (slow): what the tests compare EncodeNv12ToJpeg against.
+bool EncodeNv12ToJpegReference(const uint8_t* nv12, int w, int h, int pitch, int quality, std::vector<uint8_t>& out);
 }  // namespace stereonet
 }  // namespace hobot

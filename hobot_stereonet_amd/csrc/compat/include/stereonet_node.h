@@ -12,6 +12,7 @@
 #pragma once
 
 #include <cstdint>
+#include <future>
 #include <memory>
 #include <string>
 #include <vector>
@@ -38,7 +39,12 @@ struct BinDataType {
 struct StereonetNodeOutput : public hobot::dnn_node::DnnNodeOutput {
   std::shared_ptr<BinDataType> sp_left_nv12;
   int preprocess_time_ms = 0;
+  // this implementation's own: set when the left-eye JPEG of this request is being encoded on a worker thread
+  // (sp_left_nv12->jpeg is complete once it yields true); PostProcess waits for it
+  std::shared_future<bool> jpeg_ready;
 };
+
+class JpegPool;      // worker threads that encode the left-eye JPEGs of requests in flight (stereonet_node.cpp)
 
 class StereonetNode : public hobot::dnn_node::DnnNode {
  public:
@@ -66,8 +72,9 @@ class StereonetNode : public hobot::dnn_node::DnnNode {
     std::string model_file = "config/hobot_stereonet.hbm";
     std::string image_topic = "hbmem_stereo_img";
     std::string output_topic = "/stereonet_node_output";
-    bool publish_output = true;
+    bool publish_output = true;       // the reference's enable_pub_output_ (a constant there); STEREONET_PUB_OUTPUT=0 turns it off
     int jpeg_quality = 95;
+    int jpeg_threads = 0;             // 0 = hardware threads / 4, clamped to 2..32; STEREONET_JPEG_THREADS overrides
     int feed_start_pause_ms = 1000;   // the reference waits for the viewer before / between offline frames
     int feed_frame_pause_ms = 300;    // (stereonet_node.cpp:890,974); STEREONET_FEED_PAUSE_MS overrides both
   };
@@ -82,6 +89,7 @@ class StereonetNode : public hobot::dnn_node::DnnNode {
   hobot::dnn_node::Model* net_ = nullptr;
   std::unique_ptr<PreProcess> pre_;
   std::vector<unsigned char> eye_l_, eye_r_;     // split NV12 eyes, reused across frames
+  std::shared_ptr<JpegPool> jpeg_pool_;          // live path: the left eye is encoded off the executor thread
 
   rclcpp::Subscription<hbm_img_msgs::msg::HbmMsg1080P>::ConstSharedPtr frames_in_;
   rclcpp::Publisher<sensor_msgs::msg::Image>::SharedPtr disparity_out_;

@@ -114,6 +114,9 @@ class Publisher {
   explicit Publisher(const std::string& topic) : topic_(norm_topic(topic)) {}
   void publish(const Msg& m) const { deliver(std::make_shared<const Msg>(m)); }
   void publish(Msg&& m) const { deliver(std::make_shared<const Msg>(std::move(m))); }
+  void publish(std::unique_ptr<Msg> m) const { deliver(std::shared_ptr<const Msg>(std::move(m))); }
+  // stand-in for a zero-copy transport (hbmem shared memory, loaned messages): hands an existing message over as is
+  void publish_shared(std::shared_ptr<const Msg> m) const { deliver(std::move(m)); }
   const std::string& get_topic_name() const { return topic_; }
 
  private:

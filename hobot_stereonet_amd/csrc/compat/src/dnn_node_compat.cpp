@@ -202,6 +202,7 @@ int DnnNode::Run(std::vector<std::shared_ptr<DNNTensor>>& inputs, const std::sha
     std::lock_guard<std::mutex> lk(mu_);
     ++in_count_;                       // only requests the engine accepted count as input frames
     pending_.push_back(Pending{ticket, out, ot});
+    ++busy_;
   }
   cv_.notify_all();
   return 0;
@@ -242,6 +243,7 @@ int DnnNode::RunSbsNv12(const uint8_t* sbs, int width2, int height, const std::s
     std::lock_guard<std::mutex> lk(mu_);
     ++in_count_;                       // only requests the engine accepted count as input frames
     pending_.push_back(Pending{ticket, out, ot});
+    ++busy_;
   }
   cv_.notify_all();
   return 0;
@@ -260,14 +262,24 @@ void DnnNode::CompletionLoop() {
     float ms = 0.f;
     if (sn_wait(engine_, p.ticket, &ms) != SN_OK) {
       RCLCPP_ERROR(rclcpp::get_logger("dnn"), "wait failed: %s", sn_last_error(engine_));
-      continue;
+    } else {
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        UpdateStat(p.output, ms);
+      }
+      PostProcess(p.output);
     }
     {
       std::lock_guard<std::mutex> lk(mu_);
-      UpdateStat(p.output, ms);
+      --busy_;
     }
-    PostProcess(p.output);
+    idle_cv_.notify_all();
   }
+}
+
+void DnnNode::WaitIdle() {
+  std::unique_lock<std::mutex> lk(mu_);
+  idle_cv_.wait(lk, [&] { return busy_ == 0; });
 }
 
 int DnnNode::PostProcess(const std::shared_ptr<DnnNodeOutput>&) { return 0; }

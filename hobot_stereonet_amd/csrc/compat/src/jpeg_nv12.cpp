@@ -1,6 +1,12 @@
-// jpeg_nv12.cpp — see include/jpeg_nv12.h.  Straightforward baseline encoder: 16x16 MCUs (4 Y + Cb + Cr
-// blocks), float separable DCT, standard quantisation tables scaled by the libjpeg quality rule, standard
-// Huffman tables.
+// jpeg_nv12.cpp — see include/jpeg_nv12.h.  Baseline encoder: 16x16 MCUs (4 Y + Cb + Cr blocks), standard
+// quantisation tables scaled by the libjpeg quality rule, standard Huffman tables.
+//   EncodeNv12ToJpeg           the product form: AAN 8x8 forward DCT on 8 columns at a time (the scale factors folded
+//                              into the reciprocal quantisers), table-driven entropy coder with a 64-bit bit buffer
+//                              writing into a pre-sized array (round 4: the node's left-eye JPEG, stereonet_node.cpp:
+//                              749-786, was 40 ms per 1280x720 frame and capped the drop-in node near 25 frames/s)
+//   EncodeNv12ToJpegReference  the round-3 form (exact separable float DCT, one push_back per byte): the checker the
+//                              tests compare the fast form against (same headers; coefficients may differ by one
+//                              quantisation step where a value sits on a rounding boundary)
 #include "jpeg_nv12.h"
 
 #include <cmath>
@@ -155,7 +161,7 @@ void put16(std::vector<uint8_t>& o, int v) {
 
 }  // namespace
 
-bool EncodeNv12ToJpeg(const uint8_t* nv12, int w, int h, int pitch, int quality, std::vector<uint8_t>& out) {
+bool EncodeNv12ToJpegReference(const uint8_t* nv12, int w, int h, int pitch, int quality, std::vector<uint8_t>& out) {
   if (!nv12 || w <= 0 || h <= 0 || (w & 1) || (h & 1) || pitch < w) return false;
   quality = quality < 1 ? 1 : (quality > 100 ? 100 : quality);
   const int sf = quality < 50 ? 5000 / quality : 200 - quality * 2;
@@ -238,6 +244,263 @@ bool EncodeNv12ToJpeg(const uint8_t* nv12, int w, int h, int pitch, int quality,
   bw.flush();
   out.push_back(0xFF);
   out.push_back(0xD9);
+  return true;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fast form
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+// One AAN (Arai / Agui / Nakajima) 8-point DCT along the FIRST index of d[8][8], for all 8 second-index positions at
+// once (the loop over c is what the compiler vectorises).  Outputs carry the AAN scale aan[u] (u = first index).
+inline void aan_pass(float (*d)[8]) {
+  for (int c = 0; c < 8; ++c) {
+    const float t0 = d[0][c] + d[7][c], t7 = d[0][c] - d[7][c];
+    const float t1 = d[1][c] + d[6][c], t6 = d[1][c] - d[6][c];
+    const float t2 = d[2][c] + d[5][c], t5 = d[2][c] - d[5][c];
+    const float t3 = d[3][c] + d[4][c], t4 = d[3][c] - d[4][c];
+    const float e0 = t0 + t3, e3 = t0 - t3, e1 = t1 + t2, e2 = t1 - t2;
+    d[0][c] = e0 + e1;
+    d[4][c] = e0 - e1;
+    const float z1 = (e2 + e3) * 0.707106781f;
+    d[2][c] = e3 + z1;
+    d[6][c] = e3 - z1;
+    const float o0 = t4 + t5, o1 = t5 + t6, o2 = t6 + t7;
+    const float z5 = (o0 - o2) * 0.382683433f;
+    const float z2 = 0.541196100f * o0 + z5;
+    const float z4 = 1.306562965f * o2 + z5;
+    const float z3 = o1 * 0.707106781f;
+    const float z11 = t7 + z3, z13 = t7 - z3;
+    d[5][c] = z13 + z2;
+    d[3][c] = z13 - z2;
+    d[1][c] = z11 + z4;
+    d[7][c] = z11 - z4;
+  }
+}
+
+struct FastTables {
+  int quality = -1;
+  uint8_t ql[64], qc[64];          // natural order
+  float rl[64], rc[64];            // reciprocal quantisers in ZIGZAG order, indexed like `src` below
+  uint8_t src[64];                 // zigzag position i -> index into the transposed coefficient block
+  Huff dcl, dcc, acl, acc;
+};
+
+void make_tables(int quality, FastTables* t) {
+  static const double aan[8] = {1.0, 1.387039845, 1.306562965, 1.175875602, 1.0, 0.785694958, 0.541196100, 0.275899379};
+  const int sf = quality < 50 ? 5000 / quality : 200 - quality * 2;
+  for (int i = 0; i < 64; ++i) {
+    int a = (kQLum[i] * sf + 50) / 100, b = (kQChr[i] * sf + 50) / 100;
+    t->ql[i] = (uint8_t)(a < 1 ? 1 : (a > 255 ? 255 : a));
+    t->qc[i] = (uint8_t)(b < 1 ? 1 : (b > 255 ? 255 : b));
+  }
+  for (int i = 0; i < 64; ++i) {
+    const int nat = kZigzag[i], v = nat >> 3, u = nat & 7;      // coefficient (vertical v, horizontal u)
+    // the two passes leave coefficient (v, u) at blk[u][v] (vertical pass, transpose, vertical pass again)
+    t->src[i] = (uint8_t)(u * 8 + v);
+    const double s = aan[u] * aan[v] * 8.0;
+    t->rl[i] = (float)(1.0 / (t->ql[nat] * s));
+    t->rc[i] = (float)(1.0 / (t->qc[nat] * s));
+  }
+  build_huff(kDcLumBits, kDcVals, &t->dcl);
+  build_huff(kDcChrBits, kDcVals, &t->dcc);
+  build_huff(kAcLumBits, kAcLumVals, &t->acl);
+  build_huff(kAcChrBits, kAcChrVals, &t->acc);
+  t->quality = quality;
+}
+
+// Branch-free bit appender: codes go MSB-first into a 64-bit window; after every symbol the window's whole bytes are
+// stored (always eight bytes, the pointer advances by the count of complete ones).  Byte stuffing (0x00 after every
+// 0xFF) is NOT done here: the unstuffed stream goes to a scratch buffer and stuff_copy() inserts the zeros afterwards —
+// on noisy content the data-dependent branches of a stuffing writer cost more than the second pass.
+struct FastBits {
+  uint8_t* p;
+  uint64_t acc = 0;                 // bits [63 .. 64-n] valid
+  int n = 0;                        // < 8 between calls
+  // len <= 27 (a 16-bit code + an 11-bit magnitude), code < 2^len
+  inline void put(uint32_t code, int len) {
+    acc |= (uint64_t)code << (64 - n - len);
+    n += len;
+    const uint64_t be = __builtin_bswap64(acc);
+    memcpy(p, &be, 8);
+    const int k = n >> 3;
+    p += k;
+    acc <<= 8 * k;
+    n &= 7;
+  }
+  inline void finish() {            // pad the last partial byte with ones
+    if (n > 0) {
+      *p++ = (uint8_t)((acc >> 56) | ((1u << (8 - n)) - 1));
+      n = 0;
+    }
+  }
+};
+
+// dst <- src with a zero byte after every 0xFF; returns the end of dst
+inline uint8_t* stuff_copy(uint8_t* dst, const uint8_t* src, size_t n) {
+  while (n) {
+    const uint8_t* ff = static_cast<const uint8_t*>(memchr(src, 0xFF, n));
+    if (!ff) {
+      memcpy(dst, src, n);
+      return dst + n;
+    }
+    const size_t k = (size_t)(ff - src) + 1;
+    memcpy(dst, src, k);
+    dst += k;
+    *dst++ = 0;
+    src += k;
+    n -= k;
+  }
+  return dst;
+}
+
+// 8x8 block whose top-left sample is (bx, by) of a plane of pw x ph samples at `plane` (row stride `stride`, `step` bytes
+// between horizontally adjacent samples): DCT, quantise, entropy-code.  Samples beyond the right / bottom edge replicate
+// the last column / row (as the reference form does).
+inline void fast_block(const uint8_t* plane, int stride, int step, int bx, int by, int pw, int ph, const float* recip,
+                       const uint8_t* src, const Huff& dc, const Huff& ac, int* last_dc, FastBits* bw) {
+  alignas(32) float a[8][8], b[8][8];
+  if (bx + 8 <= pw && by + 8 <= ph) {
+    const uint8_t* px = plane + (size_t)by * stride + (size_t)bx * step;
+    for (int y = 0; y < 8; ++y)
+      for (int x = 0; x < 8; ++x) a[y][x] = (float)px[(size_t)y * stride + x * step] - 128.0f;
+  } else {
+    for (int y = 0; y < 8; ++y) {
+      const int sy = by + y < ph ? by + y : ph - 1;
+      for (int x = 0; x < 8; ++x) {
+        const int sx = bx + x < pw ? bx + x : pw - 1;
+        a[y][x] = (float)plane[(size_t)sy * stride + (size_t)sx * step] - 128.0f;
+      }
+    }
+  }
+  aan_pass(a);                                   // vertical
+  for (int y = 0; y < 8; ++y)
+    for (int x = 0; x < 8; ++x) b[x][y] = a[y][x];
+  aan_pass(b);                                   // horizontal (on the transposed block)
+  const float* cf = &b[0][0];
+  int zz[64];
+  for (int i = 0; i < 64; ++i) zz[i] = (int)lrintf(cf[src[i]] * recip[i]);
+#ifdef JPEG_NO_ENTROPY
+  { int sacc = 0; for (int i = 0; i < 64; ++i) sacc += zz[i]; *last_dc += sacc; bw->p[0] = (uint8_t)*last_dc; return; }
+#endif
+  // DC
+  const int diff = zz[0] - *last_dc;
+  *last_dc = zz[0];
+  {
+    const int ad = diff < 0 ? -diff : diff;
+    const int nb = ad ? 32 - __builtin_clz((unsigned)ad) : 0;
+    bw->put(dc.code[nb], dc.len[nb]);
+    if (nb) bw->put((uint32_t)(diff < 0 ? diff + (1 << nb) - 1 : diff), nb);
+  }
+  // AC: walk the non-zero coefficients through a bit mask (bit i = zigzag position i)
+  uint64_t nz = 0;
+  for (int i = 1; i < 64; ++i) nz |= (uint64_t)(zz[i] != 0) << i;
+  int prev = 0;
+  while (nz) {
+    const int i = __builtin_ctzll(nz);
+    nz &= nz - 1;
+    int run = i - prev - 1;
+    prev = i;
+    while (run > 15) {
+      bw->put(ac.code[0xF0], ac.len[0xF0]);
+      run -= 16;
+    }
+    const int v = zz[i];
+    const int av = v < 0 ? -v : v;
+    const int nb = 32 - __builtin_clz((unsigned)av);
+    const int sym = (run << 4) | nb;
+    bw->put(((uint32_t)ac.code[sym] << nb) | (uint32_t)(v < 0 ? v + (1 << nb) - 1 : v), ac.len[sym] + nb);
+  }
+  if (prev != 63) bw->put(ac.code[0x00], ac.len[0x00]);
+}
+
+}  // namespace
+
+bool EncodeNv12ToJpeg(const uint8_t* nv12, int w, int h, int pitch, int quality, std::vector<uint8_t>& out) {
+  if (!nv12 || w <= 0 || h <= 0 || (w & 1) || (h & 1) || pitch < w) return false;
+  quality = quality < 1 ? 1 : (quality > 100 ? 100 : quality);
+  // tables of the last quality used by this thread (the node encodes every frame at one quality)
+  static thread_local FastTables tab;
+  if (tab.quality != quality) make_tables(quality, &tab);
+
+  out.resize(1024);        // headers: 623 bytes
+  uint8_t* p = out.data();
+  auto put8 = [&](int v) { *p++ = (uint8_t)v; };
+  auto put16b = [&](int v) {
+    *p++ = (uint8_t)(v >> 8);
+    *p++ = (uint8_t)v;
+  };
+  const uint8_t soi_app0[] = {0xFF, 0xD8, 0xFF, 0xE0, 0, 16, 'J', 'F', 'I', 'F', 0, 1, 1, 0, 0, 1, 0, 1, 0, 0};
+  memcpy(p, soi_app0, sizeof soi_app0);
+  p += sizeof soi_app0;
+  for (int t = 0; t < 2; ++t) {   // DQT
+    put8(0xFF);
+    put8(0xDB);
+    put16b(67);
+    put8(t);
+    for (int i = 0; i < 64; ++i) put8((t ? tab.qc : tab.ql)[kZigzag[i]]);
+  }
+  put8(0xFF);   // SOF0: 8 bit, 3 components, Y 2x2, Cb/Cr 1x1
+  put8(0xC0);
+  put16b(17);
+  put8(8);
+  put16b(h);
+  put16b(w);
+  put8(3);
+  const uint8_t comps[9] = {1, 0x22, 0, 2, 0x11, 1, 3, 0x11, 1};
+  memcpy(p, comps, 9);
+  p += 9;
+  auto dht = [&](int cls_id, const uint8_t* bits, const uint8_t* vals, int nvals) {
+    put8(0xFF);
+    put8(0xC4);
+    put16b(3 + 16 + nvals);
+    put8(cls_id);
+    memcpy(p, bits, 16);
+    p += 16;
+    memcpy(p, vals, nvals);
+    p += nvals;
+  };
+  dht(0x00, kDcLumBits, kDcVals, 12);
+  dht(0x10, kAcLumBits, kAcLumVals, 162);
+  dht(0x01, kDcChrBits, kDcVals, 12);
+  dht(0x11, kAcChrBits, kAcChrVals, 162);
+  const uint8_t sos[] = {0xFF, 0xDA, 0, 12, 3, 1, 0x00, 2, 0x11, 3, 0x11, 0, 63, 0};
+  memcpy(p, sos, sizeof sos);
+  p += sizeof sos;
+
+  // entropy-coded segment, unstuffed, into a per-thread scratch buffer: baseline Huffman coding spends at most 16 + 11
+  // bits on a coefficient (27 bits < 4 bytes), so 4 bytes per sample + slack for the 8-byte stores can never overflow
+  static thread_local std::vector<uint8_t> scratch;
+  const size_t mcus = (size_t)((w + 15) / 16) * ((h + 15) / 16);
+  const size_t worst = mcus * 384 * 4 + 64;
+  if (scratch.size() < worst) scratch.resize(worst);
+  FastBits bw;
+  bw.p = scratch.data();
+  int dc_y = 0, dc_cb = 0, dc_cr = 0;
+  const uint8_t* uv = nv12 + (size_t)h * pitch;
+  const int cw = w / 2, chh = h / 2;
+  for (int my = 0; my < h; my += 16)
+    for (int mx = 0; mx < w; mx += 16) {
+      for (int b = 0; b < 4; ++b)
+        fast_block(nv12, pitch, 1, mx + (b & 1) * 8, my + (b >> 1) * 8, w, h, tab.rl, tab.src, tab.dcl, tab.acl, &dc_y, &bw);
+      for (int comp = 0; comp < 2; ++comp)
+        fast_block(uv + comp, pitch, 2, mx / 2, my / 2, cw, chh, tab.rc, tab.src, tab.dcc, tab.acc, comp ? &dc_cr : &dc_cb, &bw);
+    }
+  bw.finish();
+  const size_t raw_n = (size_t)(bw.p - scratch.data());
+  const size_t head_n = (size_t)(p - out.data());
+  out.resize(head_n + raw_n + raw_n / 64 + 1024);       // room for the stuffed zeros: grown below if 0xFF is that frequent
+  size_t ffs = 0;
+  if (raw_n / 64 + 1000 < raw_n) {                       // (exact count only when the estimate could be short)
+    for (size_t i = 0; i < raw_n; ++i) ffs += scratch[i] == 0xFF;
+    if (head_n + raw_n + ffs + 2 > out.size()) out.resize(head_n + raw_n + ffs + 2);
+  }
+  uint8_t* e = stuff_copy(out.data() + head_n, scratch.data(), raw_n);
+  *e++ = 0xFF;
+  *e++ = 0xD9;
+  out.resize((size_t)(e - out.data()));
   return true;
 }
 

@@ -11,9 +11,13 @@
 #include <unistd.h>
 
 #include <chrono>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <fstream>
+#include <functional>
+#include <mutex>
 #include <thread>
 
 #include "image_io.h"
@@ -21,6 +25,60 @@
 
 namespace hobot {
 namespace stereonet {
+
+// The reference encodes the left eye on the executor thread inside FeedImg (stereonet_node.cpp:749-786), which is fine at
+// a 30 fps camera and a 15-40 ms encoder but serialises a backend that finishes a pair in 0.5 ms.  Here FeedImg only queues
+// the encode: a fixed set of worker threads works through the queue, several frames at a time, and PostProcess — which
+// the completion thread calls in request order — waits for the request's own JPEG.  The queue is bounded (back-pressure
+// on the executor thread) so that frames cannot pile up behind a slow encoder.
+class JpegPool {
+ public:
+  explicit JpegPool(int threads) : cap_(2 * (size_t)threads + 2) {
+    for (int i = 0; i < threads; ++i) th_.emplace_back([this] { Loop(); });
+  }
+  ~JpegPool() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+  std::shared_future<bool> Submit(std::function<bool()> job) {
+    std::packaged_task<bool()> task(std::move(job));
+    std::shared_future<bool> f = task.get_future().share();
+    {
+      std::unique_lock<std::mutex> lk(mu_);
+      room_.wait(lk, [&] { return q_.size() < cap_ || stop_; });
+      q_.push_back(std::move(task));
+    }
+    cv_.notify_one();
+    return f;
+  }
+  int threads() const { return (int)th_.size(); }
+
+ private:
+  void Loop() {
+    for (;;) {
+      std::packaged_task<bool()> task;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return stop_ || !q_.empty(); });
+        if (q_.empty()) return;
+        task = std::move(q_.front());
+        q_.pop_front();
+      }
+      room_.notify_one();
+      task();
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_, room_;
+  std::deque<std::packaged_task<bool()>> q_;
+  std::vector<std::thread> th_;
+  const size_t cap_;
+  bool stop_ = false;
+};
 
 namespace {
 const rclcpp::Logger kLog = rclcpp::get_logger("stereonet_node");
@@ -49,6 +107,16 @@ StereonetNode::StereonetNode(const std::string& node_name, const rclcpp::NodeOpt
   LogModelIo();
 
   pre_.reset(new PreProcess(""));
+  if (cfg_.publish_output) {
+    int n = cfg_.jpeg_threads;
+    if (const char* e = getenv("STEREONET_JPEG_THREADS")) n = atoi(e);
+    if (n <= 0) {
+      n = (int)std::thread::hardware_concurrency() / 4;
+      n = n < 2 ? 2 : (n > 32 ? 32 : n);
+    }
+    jpeg_pool_ = std::make_shared<JpegPool>(n);
+    RCLCPP_WARN_STREAM(kLog, "left-eye JPEG encoder threads: " << n);
+  }
   frames_in_ = create_subscription<hbm_img_msgs::msg::HbmMsg1080P>(
       cfg_.image_topic, 10, [this](hbm_img_msgs::msg::HbmMsg1080P::ConstSharedPtr m) { OnStereoFrame(m); });
   targets_out_ = create_publisher<ai_msgs::msg::PerceptionTargets>("/Stereonet_node_sample", 10);
@@ -69,6 +137,7 @@ void StereonetNode::DeclareAndReadParameters() {
     declare_parameter<std::string>(it.name, *it.value);
     get_parameter<std::string>(it.name, *it.value);
   }
+  if (const char* e = getenv("STEREONET_PUB_OUTPUT")) cfg_.publish_output = atoi(e) != 0;
   RCLCPP_WARN_STREAM(kLog, "\n config_file: " << cfg_.config_file << "\n model_file: " << cfg_.model_file
                                               << "\n sub_hbmem_topic_name: " << cfg_.image_topic
                                               << "\n ros_img_topic_name: " << cfg_.output_topic);
@@ -134,12 +203,12 @@ void StereonetNode::OnStereoFrame(const hbm_img_msgs::msg::HbmMsg1080P::ConstSha
   const bool host_tensor = want_tensor || ((2 * net_w_) & 7) != 0 || (net_h_ & 1) != 0;
   // de-interleave the eyes: every source row carries w bytes of the left eye, then w bytes of the right eye
   const unsigned char* row = frame->data.data();
-  if (host_tensor || cfg_.publish_output) {
+  if (host_tensor) {
     eye_l_.resize((size_t)w * rows);
-    if (host_tensor) eye_r_.resize((size_t)w * rows);
+    eye_r_.resize((size_t)w * rows);
     for (int r = 0; r < rows; ++r, row += pitch) {
       memcpy(eye_l_.data() + (size_t)r * w, row, w);
-      if (host_tensor) memcpy(eye_r_.data() + (size_t)r * w, row + w, w);
+      memcpy(eye_r_.data() + (size_t)r * w, row + w, w);
     }
   }
   std::vector<std::shared_ptr<DNNTensor>> tensors;
@@ -149,15 +218,15 @@ void StereonetNode::OnStereoFrame(const hbm_img_msgs::msg::HbmMsg1080P::ConstSha
     return;
   }
   if (cfg_.publish_output) {
+    // the left eye is the left half of every row of the side-by-side frame: the encoder reads it in place (pitch 2w); the
+    // job keeps the message alive, nothing is copied on this thread
     auto left = std::make_shared<BinDataType>();
     left->w = w;
     left->h = h;
-    if (!EncodeNv12ToJpeg(eye_l_.data(), w, h, w, cfg_.jpeg_quality, left->jpeg)) {
-      RCLCPP_ERROR(kLog, "invalid sp_left_nv12");
-      rclcpp::shutdown();
-      return;
-    }
     request->sp_left_nv12 = left;
+    const int quality = cfg_.jpeg_quality;
+    request->jpeg_ready = jpeg_pool_->Submit(
+        [frame, left, w, h, pitch, quality] { return EncodeNv12ToJpeg(frame->data.data(), w, h, pitch, quality, left->jpeg); });
   }
   request->preprocess_time_ms = elapsed_ms(t_pre);
   RCLCPP_INFO(kLog, "Preprocess done, time cost %d ms", request->preprocess_time_ms);
@@ -273,6 +342,11 @@ int StereonetNode::PostProcess(const std::shared_ptr<hobot::dnn_node::DnnNodeOut
   }
   const auto t_pub = std::chrono::steady_clock::now();
   int pack_ms = 0;
+  if (cfg_.publish_output && request->sp_left_nv12 && request->jpeg_ready.valid() && !request->jpeg_ready.get()) {
+    RCLCPP_ERROR(kLog, "invalid sp_left_nv12");      // the worker's encode failed (FeedImg's check, stereonet_node.cpp:797)
+    rclcpp::shutdown();
+    return -1;
+  }
   if (cfg_.publish_output && request->sp_left_nv12 && !request->output_tensors.empty()) {
     // wire format consumed by the render node: sensor_msgs/Image, encoding "jpeg",
     // data = the raw int32 output tensor followed by the JPEG of the left eye, step = total length
@@ -283,10 +357,12 @@ int StereonetNode::PostProcess(const std::shared_ptr<hobot::dnn_node::DnnNodeOut
     msg.width = request->sp_left_nv12->w;
     msg.height = request->sp_left_nv12->h;
     msg.encoding = "jpeg";
-    msg.data.resize(out.memSize + jpeg.size());
+    // one allocation, two copies, no zero fill (resize() + memcpy wrote the 3.7 MB twice)
+    const uint8_t* raw = static_cast<const uint8_t*>(out.virAddr);
+    msg.data.reserve(out.memSize + jpeg.size());
+    msg.data.insert(msg.data.end(), raw, raw + out.memSize);
+    msg.data.insert(msg.data.end(), jpeg.begin(), jpeg.end());
     msg.step = (uint32_t)msg.data.size();
-    memcpy(msg.data.data(), out.virAddr, out.memSize);
-    memcpy(msg.data.data() + out.memSize, jpeg.data(), jpeg.size());
     pack_ms = elapsed_ms(t_pub);
     RCLCPP_INFO(kLog, "publish output with msg index: %s, topic: %s, time cost ms: %d",
                 request->msg_header->frame_id.c_str(), cfg_.output_topic.c_str(), pack_ms);
