@@ -75,6 +75,8 @@ class StereonetNode : public hobot::dnn_node::DnnNode {
     bool publish_output = true;       // the reference's enable_pub_output_ (a constant there); STEREONET_PUB_OUTPUT=0 turns it off
     int jpeg_quality = 95;
     int jpeg_threads = 0;             // 0 = hardware threads / 4, clamped to 2..32; STEREONET_JPEG_THREADS overrides
+    int jpeg_slices = 8;              // restart-interval slices per frame, encoded in parallel (1 = one scan, no RSTm);
+                                      // STEREONET_JPEG_SLICES overrides
     int feed_start_pause_ms = 1000;   // the reference waits for the viewer before / between offline frames
     int feed_frame_pause_ms = 300;    // (stereonet_node.cpp:890,974); STEREONET_FEED_PAUSE_MS overrides both
   };

@@ -418,15 +418,23 @@ inline void fast_block(const uint8_t* plane, int stride, int step, int bx, int b
 
 }  // namespace
 
-bool EncodeNv12ToJpeg(const uint8_t* nv12, int w, int h, int pitch, int quality, std::vector<uint8_t>& out) {
-  if (!nv12 || w <= 0 || h <= 0 || (w & 1) || (h & 1) || pitch < w) return false;
-  quality = quality < 1 ? 1 : (quality > 100 ? 100 : quality);
-  // tables of the last quality used by this thread (the node encodes every frame at one quality)
+namespace {
+const FastTables& tables_for(int quality) {      // tables of the last quality used by this thread (one quality per node)
   static thread_local FastTables tab;
   if (tab.quality != quality) make_tables(quality, &tab);
+  return tab;
+}
+inline int clamp_quality(int q) { return q < 1 ? 1 : (q > 100 ? 100 : q); }
+}  // namespace
 
-  out.resize(1024);        // headers: 623 bytes
-  uint8_t* p = out.data();
+int JpegMcuRows(int h) { return (h + 15) / 16; }
+
+bool JpegAppendHeader(int w, int h, int quality, int restart_mcus, std::vector<uint8_t>& out) {
+  if (w <= 0 || h <= 0 || (w & 1) || (h & 1) || restart_mcus < 0 || restart_mcus > 65535) return false;
+  const FastTables& tab = tables_for(clamp_quality(quality));
+  const size_t at = out.size();
+  out.resize(at + 1024);        // 623 bytes (+ 6 with a restart interval)
+  uint8_t* p = out.data() + at;
   auto put8 = [&](int v) { *p++ = (uint8_t)v; };
   auto put16b = [&](int v) {
     *p++ = (uint8_t)(v >> 8);
@@ -466,14 +474,26 @@ bool EncodeNv12ToJpeg(const uint8_t* nv12, int w, int h, int pitch, int quality,
   dht(0x10, kAcLumBits, kAcLumVals, 162);
   dht(0x01, kDcChrBits, kDcVals, 12);
   dht(0x11, kAcChrBits, kAcChrVals, 162);
+  if (restart_mcus > 0) {          // DRI: the entropy-coded data restarts (DC predictors = 0, byte aligned) every so many MCUs
+    put8(0xFF);
+    put8(0xDD);
+    put16b(4);
+    put16b(restart_mcus);
+  }
   const uint8_t sos[] = {0xFF, 0xDA, 0, 12, 3, 1, 0x00, 2, 0x11, 3, 0x11, 0, 63, 0};
   memcpy(p, sos, sizeof sos);
   p += sizeof sos;
+  out.resize((size_t)(p - out.data()));
+  return true;
+}
 
+bool JpegAppendMcuRows(const uint8_t* nv12, int w, int h, int pitch, int quality, int row0, int row1, std::vector<uint8_t>& out) {
+  if (!nv12 || w <= 0 || h <= 0 || (w & 1) || (h & 1) || pitch < w || row0 < 0 || row1 > JpegMcuRows(h) || row0 >= row1) return false;
+  const FastTables& tab = tables_for(clamp_quality(quality));
   // entropy-coded segment, unstuffed, into a per-thread scratch buffer: baseline Huffman coding spends at most 16 + 11
   // bits on a coefficient (27 bits < 4 bytes), so 4 bytes per sample + slack for the 8-byte stores can never overflow
   static thread_local std::vector<uint8_t> scratch;
-  const size_t mcus = (size_t)((w + 15) / 16) * ((h + 15) / 16);
+  const size_t mcus = (size_t)((w + 15) / 16) * (size_t)(row1 - row0);
   const size_t worst = mcus * 384 * 4 + 64;
   if (scratch.size() < worst) scratch.resize(worst);
   FastBits bw;
@@ -481,7 +501,7 @@ bool EncodeNv12ToJpeg(const uint8_t* nv12, int w, int h, int pitch, int quality,
   int dc_y = 0, dc_cb = 0, dc_cr = 0;
   const uint8_t* uv = nv12 + (size_t)h * pitch;
   const int cw = w / 2, chh = h / 2;
-  for (int my = 0; my < h; my += 16)
+  for (int my = row0 * 16; my < row1 * 16; my += 16)
     for (int mx = 0; mx < w; mx += 16) {
       for (int b = 0; b < 4; ++b)
         fast_block(nv12, pitch, 1, mx + (b & 1) * 8, my + (b >> 1) * 8, w, h, tab.rl, tab.src, tab.dcl, tab.acl, &dc_y, &bw);
@@ -490,17 +510,36 @@ bool EncodeNv12ToJpeg(const uint8_t* nv12, int w, int h, int pitch, int quality,
     }
   bw.finish();
   const size_t raw_n = (size_t)(bw.p - scratch.data());
-  const size_t head_n = (size_t)(p - out.data());
-  out.resize(head_n + raw_n + raw_n / 64 + 1024);       // room for the stuffed zeros: grown below if 0xFF is that frequent
   size_t ffs = 0;
-  if (raw_n / 64 + 1000 < raw_n) {                       // (exact count only when the estimate could be short)
-    for (size_t i = 0; i < raw_n; ++i) ffs += scratch[i] == 0xFF;
-    if (head_n + raw_n + ffs + 2 > out.size()) out.resize(head_n + raw_n + ffs + 2);
+  for (size_t i = 0; i < raw_n; ++i) ffs += scratch[i] == 0xFF;
+  const size_t at = out.size();
+  out.resize(at + raw_n + ffs);
+  stuff_copy(out.data() + at, scratch.data(), raw_n);
+  return true;
+}
+
+bool EncodeNv12ToJpeg(const uint8_t* nv12, int w, int h, int pitch, int quality, std::vector<uint8_t>& out) {
+  out.clear();
+  if (!nv12 || pitch < w || !JpegAppendHeader(w, h, quality, 0, out)) return false;
+  if (!JpegAppendMcuRows(nv12, w, h, pitch, quality, 0, JpegMcuRows(h), out)) return false;
+  out.push_back(0xFF);
+  out.push_back(0xD9);
+  return true;
+}
+
+bool EncodeNv12ToJpegSliced(const uint8_t* nv12, int w, int h, int pitch, int quality, int rows_per_slice,
+                            std::vector<uint8_t>& out) {
+  out.clear();
+  const int rows = JpegMcuRows(h);
+  if (rows_per_slice <= 0 || rows_per_slice >= rows) return EncodeNv12ToJpeg(nv12, w, h, pitch, quality, out);
+  if (!nv12 || pitch < w || !JpegAppendHeader(w, h, quality, rows_per_slice * ((w + 15) / 16), out)) return false;
+  int k = 0;
+  for (int r = 0; r < rows; r += rows_per_slice, ++k) {
+    const int r1 = r + rows_per_slice < rows ? r + rows_per_slice : rows;
+    if (!JpegAppendMcuRows(nv12, w, h, pitch, quality, r, r1, out)) return false;
+    out.push_back(0xFF);
+    out.push_back(r1 < rows ? (uint8_t)(0xD0 + (k & 7)) : (uint8_t)0xD9);      // RSTm between slices, EOI after the last
   }
-  uint8_t* e = stuff_copy(out.data() + head_n, scratch.data(), raw_n);
-  *e++ = 0xFF;
-  *e++ = 0xD9;
-  out.resize((size_t)(e - out.data()));
   return true;
 }
 

@@ -10,6 +10,7 @@
 
 #include <unistd.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
@@ -33,7 +34,7 @@ namespace stereonet {
 // on the executor thread) so that frames cannot pile up behind a slow encoder.
 class JpegPool {
  public:
-  explicit JpegPool(int threads) : cap_(2 * (size_t)threads + 2) {
+  explicit JpegPool(int threads) : cap_(4 * (size_t)threads + 16) {
     for (int i = 0; i < threads; ++i) th_.emplace_back([this] { Loop(); });
   }
   ~JpegPool() {
@@ -44,23 +45,20 @@ class JpegPool {
     cv_.notify_all();
     for (auto& t : th_) t.join();
   }
-  std::shared_future<bool> Submit(std::function<bool()> job) {
-    std::packaged_task<bool()> task(std::move(job));
-    std::shared_future<bool> f = task.get_future().share();
+  void Post(std::function<void()> job) {
     {
       std::unique_lock<std::mutex> lk(mu_);
       room_.wait(lk, [&] { return q_.size() < cap_ || stop_; });
-      q_.push_back(std::move(task));
+      q_.push_back(std::move(job));
     }
     cv_.notify_one();
-    return f;
   }
   int threads() const { return (int)th_.size(); }
 
  private:
   void Loop() {
     for (;;) {
-      std::packaged_task<bool()> task;
+      std::function<void()> task;
       {
         std::unique_lock<std::mutex> lk(mu_);
         cv_.wait(lk, [&] { return stop_ || !q_.empty(); });
@@ -74,7 +72,7 @@ class JpegPool {
   }
   std::mutex mu_;
   std::condition_variable cv_, room_;
-  std::deque<std::packaged_task<bool()>> q_;
+  std::deque<std::function<void()>> q_;
   std::vector<std::thread> th_;
   const size_t cap_;
   bool stop_ = false;
@@ -82,6 +80,26 @@ class JpegPool {
 
 namespace {
 const rclcpp::Logger kLog = rclcpp::get_logger("stereonet_node");
+
+// STEREONET_NODE_STATS=1: average microseconds per frame of the node's own stages, printed when the process ends
+struct StageStats {
+  const bool on = getenv("STEREONET_NODE_STATS") != nullptr && atoi(getenv("STEREONET_NODE_STATS")) == 1;
+  std::atomic<long> us[6] = {};
+  std::atomic<long> n[6] = {};
+  void add(int k, std::chrono::steady_clock::time_point t0) {
+    if (!on) return;
+    us[k] += (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+    ++n[k];
+  }
+  ~StageStats() {
+    if (!on) return;
+    static const char* name[6] = {"FeedImg total", "FeedImg: queue JPEG", "FeedImg: Run (submit)", "PostProcess: wait for the JPEG",
+                                  "PostProcess: build the message", "PostProcess: publish"};
+    for (int k = 0; k < 6; ++k)
+      if (n[k]) fprintf(stderr, "[node stats] %-34s %8.1f us/frame over %ld frames\n", name[k], (double)us[k] / n[k], (long)n[k]);
+  }
+};
+StageStats g_stats;
 
 int elapsed_ms(std::chrono::steady_clock::time_point since) {
   return (int)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - since).count();
@@ -115,7 +133,8 @@ StereonetNode::StereonetNode(const std::string& node_name, const rclcpp::NodeOpt
       n = n < 2 ? 2 : (n > 32 ? 32 : n);
     }
     jpeg_pool_ = std::make_shared<JpegPool>(n);
-    RCLCPP_WARN_STREAM(kLog, "left-eye JPEG encoder threads: " << n);
+    if (const char* e = getenv("STEREONET_JPEG_SLICES")) cfg_.jpeg_slices = atoi(e);
+    RCLCPP_WARN_STREAM(kLog, "left-eye JPEG encoder threads: " << n << ", slices per frame: " << cfg_.jpeg_slices);
   }
   frames_in_ = create_subscription<hbm_img_msgs::msg::HbmMsg1080P>(
       cfg_.image_topic, 10, [this](hbm_img_msgs::msg::HbmMsg1080P::ConstSharedPtr m) { OnStereoFrame(m); });
@@ -225,14 +244,54 @@ void StereonetNode::OnStereoFrame(const hbm_img_msgs::msg::HbmMsg1080P::ConstSha
     left->h = h;
     request->sp_left_nv12 = left;
     const int quality = cfg_.jpeg_quality;
-    request->jpeg_ready = jpeg_pool_->Submit(
-        [frame, left, w, h, pitch, quality] { return EncodeNv12ToJpeg(frame->data.data(), w, h, pitch, quality, left->jpeg); });
+    const auto tq = std::chrono::steady_clock::now();
+    // One frame = several slices of MCU rows behind restart markers, one pool task each: with task_num = 4 requests in
+    // flight, whole-frame tasks would keep at most ~5 encoder threads busy and PostProcess would wait for the JPEG (measured:
+    // 13.6 ms per frame and thread -> 400 frames/s whatever the pool size).  The task that finishes last assembles the
+    // stream (header, slice, RSTm, slice, ..., EOI) and completes the request's future; nobody waits inside the pool.
+    struct Sliced {
+      std::vector<std::vector<uint8_t>> part;
+      std::atomic<int> left_to_do{0};
+      std::atomic<bool> ok{true};
+      std::promise<bool> done;
+    };
+    const int rows = JpegMcuRows(h);
+    int nsl = cfg_.jpeg_slices < 1 ? 1 : cfg_.jpeg_slices;
+    if (nsl > rows) nsl = rows;
+    const int per = (rows + nsl - 1) / nsl;
+    nsl = (rows + per - 1) / per;
+    auto st = std::make_shared<Sliced>();
+    st->part.resize((size_t)nsl);
+    st->left_to_do = nsl;
+    request->jpeg_ready = st->done.get_future().share();
+    for (int k = 0; k < nsl; ++k)
+      jpeg_pool_->Post([frame, left, st, w, h, pitch, quality, per, rows, nsl, k] {
+        const int r0 = k * per, r1 = r0 + per < rows ? r0 + per : rows;
+        if (!JpegAppendMcuRows(frame->data.data(), w, h, pitch, quality, r0, r1, st->part[(size_t)k])) st->ok = false;
+        if (--st->left_to_do != 0) return;
+        bool ok = st->ok && JpegAppendHeader(w, h, quality, nsl > 1 ? per * ((w + 15) / 16) : 0, left->jpeg);
+        if (ok) {
+          size_t total = left->jpeg.size();
+          for (const auto& p : st->part) total += p.size() + 2;
+          left->jpeg.reserve(total);
+          for (int i = 0; i < nsl; ++i) {
+            left->jpeg.insert(left->jpeg.end(), st->part[(size_t)i].begin(), st->part[(size_t)i].end());
+            left->jpeg.push_back(0xFF);
+            left->jpeg.push_back(i + 1 < nsl ? (uint8_t)(0xD0 + (i & 7)) : (uint8_t)0xD9);
+          }
+        }
+        st->done.set_value(ok);
+      });
+    g_stats.add(1, tq);
   }
   request->preprocess_time_ms = elapsed_ms(t_pre);
   RCLCPP_INFO(kLog, "Preprocess done, time cost %d ms", request->preprocess_time_ms);
 
+  const auto tr = std::chrono::steady_clock::now();
   const int rc = host_tensor ? Run(tensors, request, /*is_sync_mode=*/false, -1, -1)
                              : RunSbsNv12(frame->data.data(), 2 * w, h, request, /*is_sync_mode=*/false, -1);
+  g_stats.add(2, tr);
+  g_stats.add(0, t_pre);
   if (rc < 0) {
     RCLCPP_ERROR(kLog, "Run infer fail!");
     return;
@@ -342,7 +401,10 @@ int StereonetNode::PostProcess(const std::shared_ptr<hobot::dnn_node::DnnNodeOut
   }
   const auto t_pub = std::chrono::steady_clock::now();
   int pack_ms = 0;
-  if (cfg_.publish_output && request->sp_left_nv12 && request->jpeg_ready.valid() && !request->jpeg_ready.get()) {
+  const auto tw = std::chrono::steady_clock::now();
+  const bool jpeg_bad = cfg_.publish_output && request->sp_left_nv12 && request->jpeg_ready.valid() && !request->jpeg_ready.get();
+  g_stats.add(3, tw);
+  if (jpeg_bad) {
     RCLCPP_ERROR(kLog, "invalid sp_left_nv12");      // the worker's encode failed (FeedImg's check, stereonet_node.cpp:797)
     rclcpp::shutdown();
     return -1;
@@ -366,7 +428,10 @@ int StereonetNode::PostProcess(const std::shared_ptr<hobot::dnn_node::DnnNodeOut
     pack_ms = elapsed_ms(t_pub);
     RCLCPP_INFO(kLog, "publish output with msg index: %s, topic: %s, time cost ms: %d",
                 request->msg_header->frame_id.c_str(), cfg_.output_topic.c_str(), pack_ms);
+    g_stats.add(4, t_pub);
+    const auto tp = std::chrono::steady_clock::now();
     disparity_out_->publish(std::move(msg));
+    g_stats.add(5, tp);
   } else {
     RCLCPP_INFO(kLog, "publish is unable");
   }

@@ -67,6 +67,14 @@ long snhost_jpeg_nv12(const unsigned char* nv12, int w, int h, int pitch, int qu
   return (long)j.size();
 }
 
+// restart-interval form (rows_per_slice MCU rows per slice); returns the JPEG size (<= cap) or -1
+long snhost_jpeg_nv12_sliced(const unsigned char* nv12, int w, int h, int pitch, int quality, int rows_per_slice, unsigned char* out, long cap) {
+  std::vector<uint8_t> j;
+  if (!hobot::stereonet::EncodeNv12ToJpegSliced(nv12, w, h, pitch, quality, rows_per_slice, j) || (long)j.size() > cap) return -1;
+  memcpy(out, j.data(), j.size());
+  return (long)j.size();
+}
+
 // the exact-DCT form of round 3 (the checker of the fast encoder); returns the JPEG size (<= cap) or -1
 long snhost_jpeg_nv12_reference(const unsigned char* nv12, int w, int h, int pitch, int quality, unsigned char* out, long cap) {
   std::vector<uint8_t> j;

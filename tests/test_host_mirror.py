@@ -27,6 +27,8 @@ def hostlib():
     lib.snhost_quantize_byte.argtypes = [ci]
     lib.snhost_jpeg_nv12.restype = C.c_long
     lib.snhost_jpeg_nv12.argtypes = [vp, ci, ci, ci, ci, vp, C.c_long]
+    lib.snhost_jpeg_nv12_sliced.restype = C.c_long
+    lib.snhost_jpeg_nv12_sliced.argtypes = [vp, ci, ci, ci, ci, ci, vp, C.c_long]
     lib.snhost_jpeg_nv12_reference.restype = C.c_long
     lib.snhost_jpeg_nv12_reference.argtypes = [vp, ci, ci, ci, ci, vp, C.c_long]
     lib.snhost_parse.argtypes = [vp, ci, ci, C.c_float, vp, vp]
@@ -108,6 +110,26 @@ def test_fast_jpeg_matches_the_exact_dct_encoder(hostlib, w, h, q):
     assert mse == 0 or 10 * np.log10(255.0 ** 2 / mse) >= 50.0
     src_y = fr[:h, :W].astype(np.float64)
     assert abs(np.mean((a[..., 0] - src_y) ** 2) - np.mean((b[..., 0] - src_y) ** 2)) < 0.05
+
+
+@pytest.mark.parametrize("w,h,per", [(1280, 720, 6), (96, 64, 1), (70, 50, 3), (64, 48, 2), (1242, 374, 5)])
+def test_sliced_jpeg_decodes_to_the_same_image(hostlib, w, h, per):
+    """Restart-interval form (what the node's encoder threads produce, one slice per task): DRI + RSTm markers in the
+    stream, and a decoded image identical to the single-scan stream's, pixel for pixel."""
+    from PIL import Image
+    W = w + (w & 1)
+    fr = synth.sbs_nv12_frame(W, h, 32, 9).reshape(h * 3 // 2, 2 * W)
+    one, sl = np.empty(W * h * 4 + 8192, np.uint8), np.empty(W * h * 4 + 8192, np.uint8)
+    n = hostlib.snhost_jpeg_nv12(fr.ctypes.data, W, h, 2 * W, 95, one.ctypes.data, one.size)
+    m = hostlib.snhost_jpeg_nv12_sliced(fr.ctypes.data, W, h, 2 * W, 95, per, sl.ctypes.data, sl.size)
+    rows = (h + 15) // 16
+    nsl = (rows + per - 1) // per
+    assert m > 0 and (bytes(sl[:m]).count(b"\xff\xdd\x00\x04") == 1) == (nsl > 1)
+    if nsl > 1:
+        assert sum(bytes(sl[:m]).count(bytes([0xFF, 0xD0 + k])) for k in range(8)) >= nsl - 1
+    a = np.asarray(Image.open(io.BytesIO(one[:n].tobytes())))
+    b = np.asarray(Image.open(io.BytesIO(sl[:m].tobytes())))
+    assert a.shape == (h, W, 3) and (a == b).all()
 
 
 @pytest.mark.gpu
