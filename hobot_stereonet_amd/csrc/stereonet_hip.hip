@@ -151,6 +151,7 @@ struct sn_handle {
   bool overlap = true;
   int tower_streams = kMaxTowerStreams;
   bool stream_last = true;   // the last block streamed too + separate head launch (SN_STREAM_LAST=0: conv + fused conv/head)
+  unsigned ablate_x = 0;     // SN_ABLATE_X mask (diagnostic): layers whose input tensor gets its lo slots zeroed
   bool tail_fuse = true;     // the streamed last block carries the head (tail form); SN_TAIL_FUSE=0: block + k_head_final_f16
   int fuse_mode = 4;         // SN_FUSE: 4 = streaming fused blocks (default), 0 = two launches per block
   bool head_fuse = true;     // last tower conv + head in one kernel (fp16 mode; SN_HEAD_FUSE=0 separates them)
@@ -269,7 +270,7 @@ int upload_conv3d(sn_handle* h, const HostLayer& l, ConvLayer* out) {
 
 // split fp16 A-fragments for k_conv3x3_c32_x3: wv(co, c', tap) is the weight of virtual input channel c'
 template <class WV>
-int upload_x3(sn_handle* h, int cin_virtual, WV wv, ConvLayer* out, int taps = 9) {
+int upload_x3(sn_handle* h, int cin_virtual, WV wv, ConvLayer* out, int taps = 9, bool zero_lo = false) {
   const int nchunk = cin_virtual / 16;
   std::vector<_Float16> pk((size_t)nchunk * taps * 2 * 64 * 8);
   for (int ch = 0; ch < nchunk; ++ch)
@@ -281,7 +282,7 @@ int upload_x3(sn_handle* h, int cin_virtual, WV wv, ConvLayer* out, int taps = 9
           const _Float16 hi = (_Float16)w;
           const size_t base = (((size_t)ch * taps + tap) * 2) * 64 * 8 + (size_t)lane * 8 + e;
           pk[base] = hi;
-          pk[base + 64 * 8] = (_Float16)((w - (float)hi) * kSplitScale);
+          pk[base + 64 * 8] = zero_lo ? (_Float16)0.f : (_Float16)((w - (float)hi) * kSplitScale);
         }
   HIP_TRY(h, dalloc(&out->wx3, pk.size() / 8));
   HIP_TRY(h, hipMemcpy(out->wx3, pk.data(), pk.size() * sizeof(_Float16), hipMemcpyHostToDevice));
@@ -414,11 +415,55 @@ hipError_t launch_conv_x3s(hipStream_t st, const ConvLayer& L, const Loader& ld,
   return hipGetLastError();
 }
 
+// ---- precision ablation of the low-resolution branch (diagnostic; scripts/lowres_ablation.py) ------------------------
+// The split-operand layers evaluate x*w as xh*wh + (xh*wl + xl*wh) / 2048 (three fp16 MFMAs).  What a cheaper form of a
+// layer would compute is reproduced exactly with zeroed operands (an MFMA with a zero operand adds exact zeros):
+//   SN_ABLATE_W=<layers>  the layer's weights rounded to fp16: its lo A-fragments are uploaded as zeros  (drops xh*wl)
+//   SN_ABLATE_X=<layers>  the layer's input rounded to fp16: the lo slots of its input tensor are zeroed in front of the
+//                         launch (drops xl*wh; runs the plain split-slot layouts, which are bit-identical to the
+//                         zero-bordered ones; for the first conv of a residual block the rounded tensor is also the
+//                         block's residual input, so that entry is an upper bound)
+// <layers>: comma-separated names out of down1..down3, f0..f12 (the thirteen 3x3 feature convs), agg0..agg3, or "all".
+enum { kAblDown = 0, kAblFeat = 3, kAblAgg = 16, kAblCount = 20 };
+unsigned ablate_mask(const char* var) {
+  const char* e = getenv(var);
+  if (!e || !*e) return 0u;
+  if (!strcmp(e, "all")) return (1u << kAblCount) - 1u;
+  unsigned m = 0;
+  std::string str(e);
+  size_t pos = 0;
+  while (pos <= str.size()) {
+    size_t c = str.find(',', pos);
+    if (c == std::string::npos) c = str.size();
+    const std::string t = str.substr(pos, c - pos);
+    int idx = -1;
+    if (t.rfind("down", 0) == 0 && t.size() == 5 && t[4] >= '1' && t[4] <= '3') idx = kAblDown + (t[4] - '1');
+    else if (t.rfind("agg", 0) == 0 && t.size() == 4 && t[3] >= '0' && t[3] <= '3') idx = kAblAgg + (t[3] - '0');
+    else if (t.size() >= 2 && t[0] == 'f' && atoi(t.c_str() + 1) >= 0 && atoi(t.c_str() + 1) <= 12 && isdigit((unsigned char)t[1])) idx = kAblFeat + atoi(t.c_str() + 1);
+    if (idx >= 0) m |= 1u << idx;
+    pos = c + 1;
+  }
+  return m;
+}
+
+// split-slot tensor [nblk][hi | lo][hw] (nblk = images x 4 channel blocks): zero the lo halves
+__global__ void k_zero_lo_slots(uint4* t, size_t hw, size_t nblk) {
+  const size_t total = nblk * hw;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t b = i / hw, r = i - b * hw;
+    t[(2 * b + 1) * hw + r] = uint4{0u, 0u, 0u, 0u};
+  }
+}
+inline hipError_t zero_lo_slots(hipStream_t st, float* tensor, int nimg, size_t hw) {
+  hipLaunchKernelGGL(k_zero_lo_slots, dim3(1024), dim3(256), 0, st, reinterpret_cast<uint4*>(tensor), hw, (size_t)nimg * 4);
+  return hipGetLastError();
+}
+
 // SN_AGG_DMA=0: aggregation layers on the plain split-slot volumes (k_conv_x3s) instead of the zero-bordered ones
 bool agg_dma_enabled() {
   static const bool on = [] {
     const char* e = getenv("SN_AGG_DMA");
-    return !(e && *e == '0');
+    return !(e && *e == '0') && ablate_mask("SN_ABLATE_X") == 0;
   }();
   return on;
 }
@@ -458,7 +503,7 @@ hipError_t launch_agg_dma(hipStream_t st, const ConvLayer& L, const uint4* vin, 
 bool down_dma_enabled() {
   static const bool on = [] {
     const char* e = getenv("SN_DOWN_DMA");
-    return !(e && *e == '0');
+    return !(e && *e == '0') && ablate_mask("SN_ABLATE_X") == 0;
   }();
   return on;
 }
@@ -1074,6 +1119,7 @@ int lowres_slots(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, con
     float* dst[3] = {ws.down[1], ws.down[2], ws.low[0]};
     for (int i = 0; i < 3; ++i) {
       const int Hi = Hp >> (i + 1), Wi = Wp >> (i + 1);
+      if ((h->ablate_x >> (kAblDown + i)) & 1u) HIP_TRY(h, zero_lo_slots(st, src[i], ni, (size_t)Hi * Wi));
       SlotIn ld{U4(src[i]), 0, Hi, Wi};
       HIP_TRY(h, (launch_conv_x3s<5, 2, 32, 4, 32, 32, 1, true, SlotIn>(st, h->down[i + 1], ld, ni, Hi / 2, Wi / 2, dst[i],
                                                                        nullptr, false, ncu)));
@@ -1084,10 +1130,13 @@ int lowres_slots(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, con
   float* t = ws.low[1];
   for (int i = 0; i < kNFeatRes; ++i) {
     SlotIn lx{U4(x), 0, hl, wl}, lt{U4(t), 0, hl, wl};
+    if ((h->ablate_x >> (kAblFeat + 2 * i)) & 1u) HIP_TRY(h, zero_lo_slots(st, x, ni, (size_t)hl * wl));
     HIP_TRY(h, (launch_conv_x3s<3, 1, 32, 8, 16, 16, 2, true, SlotIn>(st, h->fres[i][0], lx, ni, hl, wl, t, nullptr, true, ncu)));
+    if ((h->ablate_x >> (kAblFeat + 2 * i + 1)) & 1u) HIP_TRY(h, zero_lo_slots(st, t, ni, (size_t)hl * wl));
     HIP_TRY(h, (launch_conv_x3s<3, 1, 32, 8, 16, 16, 2, true, SlotIn>(st, h->fres[i][1], lt, ni, hl, wl, x, x, true, ncu)));
   }
   {
+    if ((h->ablate_x >> (kAblFeat + 12)) & 1u) HIP_TRY(h, zero_lo_slots(st, x, ni, (size_t)hl * wl));
     SlotIn lx{U4(x), 0, hl, wl};
     HIP_TRY(h, (launch_conv_x3s<3, 1, 32, 8, 16, 16, 1, false, SlotIn>(st, h->fout, lx, ni, hl, wl, ws.feat, nullptr, false, ncu)));
   }
@@ -1110,10 +1159,12 @@ int lowres_slots(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, con
     const long total = (long)m * Dl * 4 * hl * wl;
     hipLaunchKernelGGL(k_cost_slots, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ws.feat,
                        reinterpret_cast<uint4*>(ws.vol[1]), Dl, hl, wl, m);
+    if ((h->ablate_x >> kAblAgg) & 1u) HIP_TRY(h, zero_lo_slots(st, ws.vol[1], m * Dl, (size_t)hl * wl));
     SlotIn lc{U4(ws.vol[1]), Dl, hl, wl};
     HIP_TRY(h, (launch_conv_x3s<3, 1, 96, 8, 16, 16, 1, true, SlotIn>(st, h->agg[0], lc, m * Dl, hl, wl, ws.vol[0], nullptr, true, ncu)));
   }
   for (int i = 1; i < kNAgg; ++i) {
+    if ((h->ablate_x >> (kAblAgg + i)) & 1u) HIP_TRY(h, zero_lo_slots(st, ws.vol[(i - 1) & 1], m * Dl, (size_t)hl * wl));
     SlotIn lv{U4(ws.vol[(i - 1) & 1]), Dl, hl, wl};
     if (i + 1 < kNAgg)
       HIP_TRY(h, (launch_conv_x3s<3, 1, 96, 8, 16, 16, 1, true, SlotIn>(st, h->agg[i], lv, m * Dl, hl, wl, ws.vol[i & 1], nullptr, true, ncu)));
@@ -1675,13 +1726,16 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
 
   BlobWalker bw{blob.data()};
   const bool low_x3 = h->precision != SN_PREC_FP32;     // fp16 modes: low-resolution layers on split fp16 operands
+  const unsigned abl_w = ablate_mask("SN_ABLATE_W");
+  h->ablate_x = ablate_mask("SN_ABLATE_X");
+  int feat_idx = 0;
   for (int i = 0; i < kNDown; ++i) {
     const HostLayer hl_ = bw.next(kC, i == 0 ? 3 : kC, 25);
     if ((rc = upload_conv2d(h, hl_, 4, &h->down[i]))) return fail(rc);
     if (low_x3 && i == 0 && (rc = upload_down0_f16(h, hl_, &h->down0))) return fail(rc);
     if (low_x3 && i > 0 &&
         (rc = upload_x3(h, kC, [&](int co, int c, int tap) { return hl_.w[((size_t)co * kC + c) * 25 + tap]; },
-                        &h->down[i], 25)))
+                        &h->down[i], 25, (abl_w >> (kAblDown + i - 1)) & 1u)))
       return fail(rc);
   }
   // fp16 modes: the low-resolution 3x3 / 3x3x3 layers also get split fp16 A-fragments (22-bit operands on the
@@ -1690,7 +1744,9 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
     const HostLayer hl_ = bw.next(kC, kC, 9);
     int r = upload_conv2d(h, hl_, 8, L);
     if (r || !low_x3) return r;
-    return upload_x3(h, kC, [&](int co, int c, int tap) { return hl_.w[((size_t)co * kC + c) * 9 + tap]; }, L);
+    const bool z = (abl_w >> (kAblFeat + feat_idx)) & 1u;
+    ++feat_idx;
+    return upload_x3(h, kC, [&](int co, int c, int tap) { return hl_.w[((size_t)co * kC + c) * 9 + tap]; }, L, 9, z);
   };
   for (int i = 0; i < kNFeatRes; ++i)
     for (int j = 0; j < 2; ++j)
@@ -1701,7 +1757,7 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
     if ((rc = upload_conv3d(h, hl_, &h->agg[i]))) return fail(rc);
     if (low_x3 && (rc = upload_x3(h, 96, [&](int co, int c, int tap) {      // c = kz*32 + ci
           return hl_.w[(((size_t)co * kC + (c & 31)) * 3 + (c >> 5)) * 9 + tap];
-        }, &h->agg[i])))
+        }, &h->agg[i], 9, (abl_w >> (kAblAgg + i)) & 1u)))
       return fail(rc);
   }
   if ((rc = upload_head(h, bw.next(1, kC, 27), &h->aout))) return fail(rc);
