@@ -1705,12 +1705,25 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
     if (hipEventCreate(&e) != hipSuccess) return fail(SN_ERR_DEVICE);
   // (Disjoint CU sets for the pipeline streams through hipExtStreamCreateWithCUMask were measured and dropped:
   // 1940 pairs/s shared vs 1700 / 1680 / 1510 with 64 / 96 / 128 CUs split off for the low-resolution branch.)
-  if (hipStreamCreateWithFlags(&h->s_low, hipStreamNonBlocking) != hipSuccess ||
+  // SN_STREAM_PRIORITY=1: the pipeline streams are created with the device's highest stream priority.  HIP multiplexes
+  // streams onto GPU_MAX_HW_QUEUES (4) hardware queues PER PRIORITY LEVEL, and two streams that share a hardware queue
+  // run in order: a caller's other streams (a communication library's receive kernels on the gather root, copy streams)
+  // can land on the tower's queue and serialise with it.  High-priority streams draw from their own queues.
+  int prio = 0;
+  {
+    int least = 0, greatest = 0;
+    const char* e = getenv("SN_STREAM_PRIORITY");
+    if (e && atoi(e) == 1 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess) prio = greatest;
+  }
+  auto mk_stream = [&](hipStream_t* st) {
+    return prio != 0 ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio) : hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+  };
+  if (mk_stream(&h->s_low) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess)
     return fail(SN_ERR_DEVICE);
   for (int i = 0; i < kMaxTowerStreams; ++i)
-    if (hipStreamCreateWithFlags(&h->s_tow[i], hipStreamNonBlocking) != hipSuccess ||
+    if (mk_stream(&h->s_tow[i]) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_tow_join[i], hipEventDisableTiming) != hipSuccess)
       return fail(SN_ERR_DEVICE);
   for (auto& e : h->ev_piece)
@@ -2710,6 +2723,17 @@ int sn_dbg_ref_block_f16(sn_handle* h, const float* in, int h_px, int w, const f
           }
       }
   return SN_OK;
+}
+
+__global__ __launch_bounds__(256) void k_copy_limited(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+int sn_dbg_copy_limited(void* dst, const void* src, size_t bytes, int workgroups, void* stream) {
+  if (!dst || !src || (bytes & 15) || workgroups <= 0 || workgroups > 65535 || ((uintptr_t)dst & 15) || ((uintptr_t)src & 15)) return SN_ERR_ARG;
+  hipLaunchKernelGGL(k_copy_limited, dim3((unsigned)workgroups), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<uint4*>(dst), static_cast<const uint4*>(src), bytes / 16);
+  return hipGetLastError() == hipSuccess ? SN_OK : SN_ERR_DEVICE;
 }
 
 int sn_dbg_read(sn_handle* h, const char* what, float* dst, size_t cap, size_t* n) {

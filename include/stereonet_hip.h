@@ -244,14 +244,19 @@ int sn_dbg_ref_conv_f16(sn_handle *h, const float *in, int h_px, int w, const fl
 int sn_dbg_ref_conv_f16x3(sn_handle *h, const float *in, int h_px, int w, const float *wt, const float *bias,
                           int dil, int lrelu, const float *residual, float *out);
 /* one residual block y = lrelu(x + conv2(lrelu(conv1(x)+b1)) + b2) of the fp16 tower; fp32 [32][h][w] host tensors.
- * dil = 1 / 2 / 4 / 8 in bits 0..7; bits 8.. select the form: 0 = two convolution launches, 1 = the tile-fused kernel
- * (dilation 1 only), 2 = the row-streaming fused kernel the pipeline runs by default (every dilation). */
+ * dil = 1 / 2 / 4 / 8 in bits 0..7; bits 8.. select the form: 0 = two convolution launches, 2 = the row-streaming fused
+ * kernel the pipeline runs by default (every dilation). */
 int sn_dbg_ref_block_f16(sn_handle *h, const float *in, int h_px, int w, const float *w1, const float *b1,
                          const float *w2, const float *b2, int dil, float *out);
 /* intermediates of the most recent batch-1 inference: "feat_l" / "feat_r" [32][hl][wl],
  * "cost" [Dl][hl][wl], "disp_low" [hl][wl], and for a hierarchical model "level1" .. "level3" (the map of that
  * refinement level, [Hp/2^k][Wp/2^k]); returns the element count in *n (dst may be NULL to query). */
 int sn_dbg_read(sn_handle *h, const char *what, float *dst, size_t cap, size_t *n);
+/* Measurement hook (bench.py --emulate-root-ingress): a device-to-device copy of `bytes` bytes by a kernel of exactly
+ * `workgroups` workgroups of 256 threads on `stream` — the footprint of one RCCL receive (a few channels = a few
+ * workgroups per peer), so that the tax of the gather root's ingress on a concurrently running batch can be measured
+ * on one GPU.  dst / src: device pointers, 16-byte aligned; bytes a multiple of 16. */
+int sn_dbg_copy_limited(void *dst, const void *src, size_t bytes, int workgroups, void *stream);
 
 #ifdef __cplusplus
 }
