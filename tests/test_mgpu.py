@@ -147,6 +147,9 @@ def test_two_shards_on_one_device_through_the_worker_threads(model_factory, monk
         with pytest.raises(api.StereoNetError) as e:
             m.submit_device(n, ptrs(tx), out[0][0].data_ptr(), out[0][1].data_ptr())
         assert e.value.code == -6
+        with pytest.raises(api.StereoNetError) as e:      # the host form shares the engines' workspaces: refused while
+            m.infer(xs)                                   # device-resident batches are in flight (SN_ERR_BUSY)
+        assert e.value.code == -6
         m.wait(t2)
         m.wait(t1)
         assert (out[0][0].cpu().numpy() == raw_x).all() and (out[1][0].cpu().numpy() == raw_y).all()
