@@ -1196,6 +1196,24 @@ __device__ __forceinline__ float lrelu_fast(float v) {
   return r;
 }
 
+// Activation of the fp16 tower (SN_PREC_F16), round 4: every value a tower layer stores is
+//     h = fp16(v);  out = max(h, fp16(slope * h))            (slope = 0.2, or 1 for "no activation")
+// i.e. LeakyReLU is applied AFTER the rounding to fp16, on packed pairs (v_cvt_pk_f16_f32, v_pk_mul_f16, v_pk_max_f16:
+// 1.5 instead of 2.5 VALU instructions per value).  For v >= 0 nothing changes; for v < 0 the product is rounded from
+// fp16(v) instead of v (one extra fp16 rounding: EPE vs the oracle 3.75e-4 -> 3.80e-4 px at 1280x720, 6.48e-4 -> 6.56e-4
+// for the hierarchical model at 1242x375).  Epilogue VALU instructions are on the critical path of the streamed block
+// (sn_stream_block.hpp): -3.5 % per block, +1.2 % end to end.  EVERY kernel of the fp16 tower uses this one function, so
+// the streamed, per-layer and head-fused forms stay bit-identical to each other.
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned act_pack2_f16(float a, float b, _Float16 slope) {
+  half2v h;
+  h[0] = (_Float16)a;
+  h[1] = (_Float16)b;
+  const half2v m = h * slope;
+  h = __builtin_elementwise_max(h, m);
+  return *reinterpret_cast<const unsigned*>(&h);
+}
+
 // Workgroup barrier for the hand-synchronised kernels: a bare s_barrier (no vmcnt drain, unlike __syncthreads())
 // fenced on both sides so that hipcc cannot move LDS / global accesses across it.
 __device__ __forceinline__ void block_barrier() {
@@ -1465,7 +1483,7 @@ __global__ __launch_bounds__(256, MINW) void k_ref_conv_f16_v2(const uint4* __re
     // ---- epilogue: exactly NSTORE stores per wave; out-of-image pixels store zeros.  Tiles that lie
     // completely inside the image (all of them at 1280x720) skip the per-element masking. ----
     const bool interior = y0 + T::TH <= g.H && x0 + T::TW <= g.W;            // wave-uniform
-    const float slope = lrelu ? kSlope : 1.0f;         // max(v, v) = v: one code path with and without the activation
+    const _Float16 slope_h = lrelu ? (_Float16)kSlope : (_Float16)1.0f;         // max(h, h) = h: one code path with and without the activation
     float one = 1.0f;
     asm volatile("" : "+v"(one));                      // opaque: keeps the multiply so that hipcc selects v_fma_mix_f32
     // (the epilogue body exists twice, selected by ONE uniform branch per tile: with the test inside, hipcc put two
@@ -1481,20 +1499,13 @@ __global__ __launch_bounds__(256, MINW) void k_ref_conv_f16_v2(const uint4* __re
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf((float)rv[e], one, v[e]);
       }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float t = v[e] * slope;
-        asm("v_max_f32 %0, %1, %2" : "=v"(v[e]) : "v"(v[e]), "v"(t));
-      }
-      half4 hv;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) hv[e] = (_Float16)v[e];
+      uint2 hv{act_pack2_f16(v[0], v[1], slope_h), act_pack2_f16(v[2], v[3], slope_h)};      // round, then activate (act_pack2_f16)
       if (!decltype(inside)::value) {
         const int seg = seg0 + s;
         const int y = y0 + seg / T::CSEG, x = x0 + (seg % T::CSEG) * 32 + j;
-        if (!(y < g.H && x < g.W)) hv = half4{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+        if (!(y < g.H && x < g.W)) hv = uint2{0u, 0u};
       }
-      return *reinterpret_cast<const uint2*>(&hv);
+      return hv;
     };
     auto store_tile = [&](auto inside) {
 #pragma unroll
@@ -1793,11 +1804,13 @@ __global__ __launch_bounds__(256, 2) void k_ref_conv_head_f16(const uint4* __res
       for (int q = 0; q < 4; ++q) {
         const uint2 rw = rres[s * 4 + q];
         const half4 rv = *reinterpret_cast<const half4*>(&rw);
+        float u[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float v = lrelu_fast(__builtin_fmaf((float)rv[e], one, acc[s][4 * q + e]));      // v_fma_mix_f32
-          yk[q >> 1][4 * (q & 1) + e] = inside ? (_Float16)v : (_Float16)0.f;
-        }
+        for (int e = 0; e < 4; ++e) u[e] = __builtin_fmaf((float)rv[e], one, acc[s][4 * q + e]);      // v_fma_mix_f32
+        const uint2 pk{act_pack2_f16(u[0], u[1], (_Float16)kSlope), act_pack2_f16(u[2], u[3], (_Float16)kSlope)};
+        const half4 hq = *reinterpret_cast<const half4*>(&pk);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) yk[q >> 1][4 * (q & 1) + e] = inside ? hq[e] : (_Float16)0.f;
       }
       f32x16 pa, pb;
 #pragma unroll
@@ -2308,13 +2321,21 @@ __global__ __launch_bounds__(256, 2) void k_refin_f16(const float* __restrict__ 
           char* oq = reinterpret_cast<char*>(out) + (tb + (unsigned)q * plane_b);                  // uniform
           char* oql = oq + lo_off_bytes;
           half4 hh, hl4;
+          if (SPLIT) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float v = acc0[s][4 * q + e] + acc1[s][4 * q + e] * kSplitInv;
-            v = lrelu_fast(v);
-            const _Float16 hi = (_Float16)v;
-            hh[e] = hi;
-            if (SPLIT) hl4[e] = (_Float16)((v - (float)hi) * kSplitScale);
+            for (int e = 0; e < 4; ++e) {
+              float v = acc0[s][4 * q + e] + acc1[s][4 * q + e] * kSplitInv;
+              v = lrelu_fast(v);
+              const _Float16 hi = (_Float16)v;
+              hh[e] = hi;
+              hl4[e] = (_Float16)((v - (float)hi) * kSplitScale);
+            }
+          } else {      // SN_PREC_F16: the tower's activation rule (act_pack2_f16: round, then LeakyReLU on the packed pair)
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc0[s][4 * q + e] + acc1[s][4 * q + e] * kSplitInv;
+            const uint2 pk{act_pack2_f16(v[0], v[1], (_Float16)kSlope), act_pack2_f16(v[2], v[3], (_Float16)kSlope)};
+            hh = *reinterpret_cast<const half4*>(&pk);
           }
           bool ok = true;
           if (!interior) {

@@ -146,15 +146,20 @@ struct StreamIter {
   }
 };
 
-// fp16 pair of (lrelu(a), lrelu(b)).  Deliberately scalar fp32 math: a packed form (v_pk_mul_f32, and hipcc then also
-// turned the residual's v_fma_mix_f32 into v_cvt_f32_f16 + v_pk_fma_f32) has the same instruction count and measured
-// 173 instead of 157 us per dilation-1 block — the packed fp32 instructions are not full rate here.
-typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned lrelu_pack2(float a, float b) {
-  half2v h;
-  h[0] = (_Float16)lrelu_fast(a);
-  h[1] = (_Float16)lrelu_fast(b);
-  return *reinterpret_cast<const unsigned*>(&h);
+// fp16 pair of the activated values (act_pack2_f16, sn_kernels.hpp: round to fp16, then LeakyReLU on the packed pair).
+// fp32 packed math was measured and is NOT the way: v_pk_mul_f32 (and the v_cvt_f32_f16 + v_pk_fma_f32 hipcc then makes of the
+// residual add) has the same instruction count as the scalar form and ran 173 instead of 157 us per dilation-1 block.
+__device__ __forceinline__ unsigned lrelu_pack2(float a, float b) { return act_pack2_f16(a, b, (_Float16)kSlope); }
+
+// acc + (float)(fp16 half `HI` of the packed pair r): ONE v_fma_mix_f32.  Pinned as inline asm: left to hipcc the
+// conversion and the add come out as v_cvt_f32_f16 + v_pk_fma_f32 as soon as the result feeds a packed conversion
+// (3 instructions per pair instead of 2, and the packed fp32 instruction is not full rate).
+template <int HI>
+__device__ __forceinline__ float res_add(unsigned r, float acc) {
+  float d;
+  if (HI) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(r), "v"(acc));
+  else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(r), "v"(acc));
+  return d;
 }
 
 // 32-bit LDS byte address of a pointer into the workgroup's shared memory (operand of hand-written ds_* instructions)
@@ -593,10 +598,9 @@ __global__ __launch_bounds__(128 * NWR, NWR / 2) __attribute__((amdgpu_waves_per
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
               const half4 rv = *reinterpret_cast<const half4*>(&rres[s][qd]);
-#pragma unroll
-              for (int hp = 0; hp < 2; ++hp)
-                pk[qd][hp] = lrelu_pack2(__builtin_fmaf((float)rv[2 * hp], one, acc[s][4 * qd + 2 * hp]),
-                                         __builtin_fmaf((float)rv[2 * hp + 1], one, acc[s][4 * qd + 2 * hp + 1]));
+              const uint2 rw2 = *reinterpret_cast<const uint2*>(&rv);
+              pk[qd][0] = lrelu_pack2(res_add<0>(rw2.x, acc[s][4 * qd]), res_add<1>(rw2.x, acc[s][4 * qd + 1]));
+              pk[qd][1] = lrelu_pack2(res_add<0>(rw2.y, acc[s][4 * qd + 2]), res_add<1>(rw2.y, acc[s][4 * qd + 3]));
             }
             if (!interior) {
 #pragma unroll
@@ -648,10 +652,9 @@ __global__ __launch_bounds__(128 * NWR, NWR / 2) __attribute__((amdgpu_waves_per
 #else
               const half4 rv = *reinterpret_cast<const half4*>(reinterpret_cast<const char*>(xrow + qd * T::XW + s * 32) + gh * 8);
 #endif
-#pragma unroll
-              for (int hp = 0; hp < 2; ++hp)
-                pk[qd][hp] = lrelu_pack2(__builtin_fmaf((float)rv[2 * hp], one, acc[s][4 * qd + 2 * hp]),
-                                         __builtin_fmaf((float)rv[2 * hp + 1], one, acc[s][4 * qd + 2 * hp + 1]));
+              const uint2 rw2 = *reinterpret_cast<const uint2*>(&rv);
+              pk[qd][0] = lrelu_pack2(res_add<0>(rw2.x, acc[s][4 * qd]), res_add<1>(rw2.x, acc[s][4 * qd + 1]));
+              pk[qd][1] = lrelu_pack2(res_add<0>(rw2.y, acc[s][4 * qd + 2]), res_add<1>(rw2.y, acc[s][4 * qd + 3]));
             }
             // half exchange (v_permlane32_swap: lanes 32-63 of the first operand <-> lanes 0-31 of the second): blocks
             // (0, 2) and (1, 3) trade halves, so lanes gh = 0 end up with the full slots of blocks 0, 1 and lanes gh = 1

@@ -42,6 +42,16 @@ constexpr int kMaxTowerStreams = 2;
     }                                                                                 \
   } while (0)
 
+// hipMemset runs on the legacy default stream and may return before the device has finished; the engine's streams are
+// created hipStreamNonBlocking and do NOT order themselves behind it.  A kernel launched on one of them right after a
+// plain hipMemset of its output can therefore be overtaken by the memset (seen once as a parity-hook flake in round 4:
+// zeros in a freshly written tensor).  Every memset of a buffer that another stream touches next goes through this.
+inline hipError_t memset_now(void* p, int v, size_t bytes) {
+  hipError_t e = hipMemset(p, v, bytes);
+  if (e != hipSuccess) return e;
+  return hipStreamSynchronize(nullptr);
+}
+
 // Device buffers of a parity hook (sn_dbg_*): freed on EVERY return path, error paths included.
 struct DevScope {
   std::vector<void*> ptrs;
@@ -707,7 +717,7 @@ hipError_t alloc_ref16(const RefGeom& g, size_t tensor_and_slack_slots, uint4** 
   const size_t front = ref_front(g), all = front + tensor_and_slack_slots;
   hipError_t e = dalloc(raw, all);
   if (e != hipSuccess) return e;
-  e = hipMemset(*raw, 0, all * sizeof(uint4));        // the zero borders are never written again
+  e = memset_now(*raw, 0, all * sizeof(uint4));        // the zero borders are never written again
   *base = *raw + front;
   return e;
 }
@@ -1009,7 +1019,7 @@ int alloc_ws(sn_handle* h, Workspace* ws, int nb, int rb, int ns) {
   for (int k = 0; k < 2; ++k) HIP_TRY(h, dalloc(&ws->vol[k], (size_t)pb * h->Dl * kC * hw));
   for (int k = 0; k < 3 && padded_down; ++k) {
     HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&ws->downp[k]), downp_bytes[k]));
-    HIP_TRY(h, hipMemset(ws->downp[k], 0, downp_bytes[k]));   // the borders stay zero: kernels write image pixels only
+    HIP_TRY(h, memset_now(ws->downp[k], 0, downp_bytes[k]));   // the borders stay zero: kernels write image pixels only
   }
   if (h->precision != SN_PREC_FP32 && agg_dma_enabled()) {
     const VolPad g = vol_pad(h->Dl, h->hl, h->wl);
@@ -1017,7 +1027,7 @@ int alloc_ws(sn_handle* h, Workspace* ws, int nb, int rb, int ns) {
     // the kernel addresses the volume with 32-bit byte offsets; a piece that large keeps the plain volumes
     for (int k = 0; k < 2 && bytes < ((size_t)1 << 32); ++k) {
       HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&ws->volp[k]), bytes));
-      HIP_TRY(h, hipMemset(ws->volp[k], 0, bytes));       // the borders stay zero: kernels write image pixels only
+      HIP_TRY(h, memset_now(ws->volp[k], 0, bytes));       // the borders stay zero: kernels write image pixels only
     }
   }
   HIP_TRY(h, dalloc(&ws->cost, (size_t)nb * h->Dl * hw));
@@ -2306,7 +2316,7 @@ int sn_dbg_conv2d(sn_handle* h, const float* in, int cin, int h_px, int w, const
       HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&pdout), pout.size() * 2));
       ds.track(pdout);
       HIP_TRY(h, hipMemcpy(pdin, pin.data(), pin.size() * 2, hipMemcpyHostToDevice));
-      HIP_TRY(h, hipMemset(pdout, 0, pout.size() * 2));
+      HIP_TRY(h, memset_now(pdout, 0, pout.size() * 2));
       HIP_TRY(h, launch_down_dma(h->stream, Ls, pdin, 1, Ho, Wo, pdout, go, lrelu != 0, h->num_cu));
       HIP_TRY(h, hipStreamSynchronize(h->stream));
       HIP_TRY(h, hipMemcpy(pout.data(), pdout, pout.size() * 2, hipMemcpyDeviceToHost));
@@ -2426,7 +2436,7 @@ int sn_dbg_refin(sn_handle* h, const float* disp_low, const int8_t* in6, int h_p
   HIP_TRY(h, hipMemcpy(ddl, disp_low, (size_t)hl * wl * 4, hipMemcpyHostToDevice));
   HIP_TRY(h, hipMemcpy(dbias, bias, kC * 4, hipMemcpyHostToDevice));
   HIP_TRY(h, hipMemcpy(din, in6, (size_t)6 * h_px * w, hipMemcpyHostToDevice));
-  HIP_TRY(h, hipMemset(dout, 0, 2 * slots * 16));
+  HIP_TRY(h, memset_now(dout, 0, 2 * slots * 16));
   HIP_TRY(h, launch_refin_f16(h->stream, L, dbias, ddl, din, false, hl, wl, h_px, w, 1.0f / (float)dmax,
                               UpScale{1.0f / 16.0f, 16.0f}, g, 1, dout, split != 0, slots * 16, h->num_cu));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -2498,7 +2508,7 @@ int sn_dbg_conv3d(sn_handle* h, const float* in, int d, int h_px, int w, const f
       HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&pdout), nsl * 16));
       ds.track(pdout);
       HIP_TRY(h, hipMemcpy(pdin, pin.data(), nsl * 16, hipMemcpyHostToDevice));
-      HIP_TRY(h, hipMemset(pdout, 0, nsl * 16));
+      HIP_TRY(h, memset_now(pdout, 0, nsl * 16));
       HIP_TRY(h, launch_agg_dma<true>(h->stream, L, pdin, g, 1, pdout, lrelu != 0, h->num_cu));
       HIP_TRY(h, hipStreamSynchronize(h->stream));
       HIP_TRY(h, hipMemcpy(pout.data(), pdout, nsl * 16, hipMemcpyDeviceToHost));
@@ -2571,7 +2581,7 @@ int sn_dbg_ref_conv_f16(sn_handle* h, const float* in, int h_px, int w, const fl
     HIP_TRY(h, hipMemcpy(dout, hres.data(), slots * 16, hipMemcpyHostToDevice));
     dres = dout;
   } else {
-    HIP_TRY(h, hipMemset(dout, 0, slots * 16));
+    HIP_TRY(h, memset_now(dout, 0, slots * 16));
   }
   unsigned* ctr = h->ws.tile_ctr;
   if (!ctr) {
@@ -2643,7 +2653,7 @@ int sn_dbg_ref_conv_f16x3(sn_handle* h, const float* in, int h_px, int w, const 
     HIP_TRY(h, hipMemcpy(dout, hres.data(), slots * 16, hipMemcpyHostToDevice));
     dres = dout;
   } else {
-    HIP_TRY(h, hipMemset(dout, 0, slots * 16));
+    HIP_TRY(h, memset_now(dout, 0, slots * 16));
   }
   HIP_TRY(h, ref_conv_f16x3(h->stream, L, g, h->num_cu, dil, din, dout, dres, lo_slots, 1, lrelu != 0));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
