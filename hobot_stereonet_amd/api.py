@@ -106,11 +106,12 @@ def load_library(path: Optional[str] = None):
     lib.sn_dbg_ref_block_f16.argtypes = [vp, fp, ip, ip, fp, fp, fp, fp, ip, fp]
     lib.sn_dbg_read.argtypes = [vp, C.c_char_p, fp, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.sn_dbg_copy_limited.argtypes = [vp, vp, C.c_size_t, ip, vp]
+    lib.sn_depth_from_raw.argtypes = [vp, ip, i32p, C.c_float, C.c_float, fp, fp, ip, vp]
     for name in ("sn_create", "sn_destroy", "sn_get_io_info", "sn_infer_i8", "sn_infer_batch", "sn_preprocess_nv12",
                  "sn_infer_sbs_nv12", "sn_preprocess_sbs_nv12_batch", "sn_submit", "sn_submit_nv12", "sn_wait", "sn_synchronize", "sn_set_profiling",
                  "sn_get_stage_ms", "sn_get_dominant_kernel", "sn_mgpu_shard", "sn_mgpu_create", "sn_mgpu_destroy",
                  "sn_mgpu_get_info", "sn_mgpu_get_handle", "sn_mgpu_infer_batch", "sn_mgpu_infer_batch_device",
-                 "sn_mgpu_submit_device", "sn_mgpu_wait", "sn_mgpu_ring_init", "sn_mgpu_ring_submit", "sn_mgpu_ring_wait", "sn_dbg_conv2d", "sn_dbg_down0", "sn_dbg_refin", "sn_dbg_conv3d", "sn_dbg_ref_conv_f16", "sn_dbg_ref_conv_f16x3", "sn_dbg_ref_block_f16", "sn_dbg_read", "sn_dbg_copy_limited"):
+                 "sn_mgpu_submit_device", "sn_mgpu_wait", "sn_mgpu_ring_init", "sn_mgpu_ring_submit", "sn_mgpu_ring_wait", "sn_dbg_conv2d", "sn_dbg_down0", "sn_dbg_refin", "sn_dbg_conv3d", "sn_dbg_ref_conv_f16", "sn_dbg_ref_conv_f16x3", "sn_dbg_ref_block_f16", "sn_dbg_read", "sn_dbg_copy_limited", "sn_depth_from_raw"):
         getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
@@ -249,6 +250,18 @@ class StereoNetHIP:
         ms = C.c_float()
         self._check(self._lib.sn_wait(self._h, ticket, C.byref(ms)), "sn_wait")
         return ms.value
+
+    def depth_from_raw(self, raw: np.ndarray, focal_px: float = 527.1931762695312, baseline_mm: float = 119.89382172,
+                       want_disp: bool = False):
+        """Parse()'s dequantisation + depth (parser.cpp:84-86) on the GPU: int32 (H,W) or (n,H,W) -> depth in metres
+        (float32, inf where raw == 0) [, disparity px]; bit-identical to the host Parse."""
+        r = np.ascontiguousarray(raw, dtype=np.int32)
+        n = 1 if r.ndim == 2 else r.shape[0]
+        depth = np.empty(r.shape, np.float32)
+        disp = np.empty(r.shape, np.float32) if want_disp else None
+        self._check(self._lib.sn_depth_from_raw(self._h, n, r.ctypes.data, focal_px, baseline_mm, depth.ctypes.data,
+                                                _np_ptr(disp), SN_MEM_HOST, None), "sn_depth_from_raw")
+        return (depth, disp) if want_disp else depth
 
     def synchronize(self):
         self._check(self._lib.sn_synchronize(self._h), "sn_synchronize")

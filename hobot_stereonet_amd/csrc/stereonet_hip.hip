@@ -2735,6 +2735,55 @@ int sn_dbg_ref_block_f16(sn_handle* h, const float* in, int h_px, int w, const f
   return SN_OK;
 }
 
+// Parse's arithmetic per element (parser.cpp:84-86): the product f * B is a float, everything after it is double
+__global__ __launch_bounds__(256) void k_depth_from_raw(const int32_t* __restrict__ raw, size_t n, float scale, float fB,
+                                                        float* __restrict__ depth, float* __restrict__ disp) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float dis = (float)raw[i] * scale;
+    depth[i] = (float)((double)fB / ((double)dis * 16.0 * 12.0) / 1000.0);
+    if (disp) disp[i] = dis * 16.0f * 12.0f;
+  }
+}
+
+int sn_depth_from_raw(sn_handle* h, int n, const int32_t* raw, float focal_px, float baseline_mm, float* depth_m, float* disp_px,
+                      int mem, void* stream) {
+  if (!h || !raw || !depth_m || n <= 0 || n > h->max_batch || (mem != SN_MEM_HOST && mem != SN_MEM_DEVICE)) return SN_ERR_ARG;
+  int rc = check_device(h);
+  if (rc) return rc;
+  const size_t cnt = (size_t)n * h->H * h->W;
+  hipStream_t st = stream ? static_cast<hipStream_t>(stream) : h->stream;
+  const float fB = focal_px * baseline_mm;      // float product, as in the reference expression
+  const int32_t* draw = raw;
+  float *ddepth = depth_m, *ddisp = disp_px;
+  DevScope ds;
+  if (mem == SN_MEM_HOST) {
+    int32_t* a = nullptr;
+    float *b = nullptr, *c = nullptr;
+    HIP_TRY(h, dalloc(&a, cnt));
+    ds.track(a);
+    HIP_TRY(h, dalloc(&b, cnt));
+    ds.track(b);
+    if (disp_px) {
+      HIP_TRY(h, dalloc(&c, cnt));
+      ds.track(c);
+    }
+    HIP_TRY(h, hipMemcpyAsync(a, raw, cnt * 4, hipMemcpyHostToDevice, st));
+    draw = a;
+    ddepth = b;
+    ddisp = c;
+  }
+  unsigned grid = (unsigned)((cnt + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(k_depth_from_raw, dim3(grid), dim3(256), 0, st, draw, cnt, kOutScale, fB, ddepth, ddisp);
+  HIP_TRY(h, hipGetLastError());
+  if (mem == SN_MEM_HOST) {
+    HIP_TRY(h, hipMemcpyAsync(depth_m, ddepth, cnt * 4, hipMemcpyDeviceToHost, st));
+    if (disp_px) HIP_TRY(h, hipMemcpyAsync(disp_px, ddisp, cnt * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
+  }
+  return SN_OK;
+}
+
 __global__ __launch_bounds__(256) void k_copy_limited(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }

@@ -252,6 +252,14 @@ int sn_dbg_ref_block_f16(sn_handle *h, const float *in, int h_px, int w, const f
  * "cost" [Dl][hl][wl], "disp_low" [hl][wl], and for a hierarchical model "level1" .. "level3" (the map of that
  * refinement level, [Hp/2^k][Wp/2^k]); returns the element count in *n (dst may be NULL to query). */
 int sn_dbg_read(sn_handle *h, const char *what, float *dst, size_t cap, size_t *n);
+/* Parse()'s dequantisation + depth (stereonet_infer/src/parser.cpp:84-86) on the GPU, for n maps of the model's size:
+ *     dis = (float)raw * out_scale;   depth_m = (float)((double)(focal_px * baseline_mm) / (dis * 16.0 * 12.0) / 1000.0)
+ * with the reference's float / double mix, so the result is bit-identical to the host Parse (raw = 0 gives IEEE inf).
+ * The reference's constants are focal_px = 527.1931762695312, baseline_mm = 119.89382172 (parser.cpp:70-71).
+ * raw / depth_m: host or device buffers per `mem`; disp_px (nullable) receives dis * 16 * 12 as Parse's disparity. */
+int sn_depth_from_raw(sn_handle *h, int n, const int32_t *raw, float focal_px, float baseline_mm, float *depth_m,
+                      float *disp_px, int mem, void *stream);
+
 /* Measurement hook (bench.py --emulate-root-ingress): a device-to-device copy of `bytes` bytes by a kernel of exactly
  * `workgroups` workgroups of 256 threads on `stream` — the footprint of one RCCL receive (a few channels = a few
  * workgroups per peer), so that the tax of the gather root's ingress on a concurrently running batch can be measured

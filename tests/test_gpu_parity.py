@@ -357,3 +357,24 @@ def test_lowres_split_conv5x5_stride2(small_engine, oracle, h, w):
     a = small_engine.dbg_conv2d(x, wt, b, 5, 2, 1, lrelu=True, x3=True, slots=True)
     a_dma = small_engine.dbg_conv2d(x, wt, b, 5, 2, 1, lrelu=True, x3=True, slots=True, dma=True)
     assert np.array_equal(a_dma, a)
+
+
+@pytest.mark.gpu
+def test_device_depth_matches_host_parse_bit_for_bit(model_factory):
+    """sn_depth_from_raw = Parse()'s dequantisation + depth (parser.cpp:84-86) as a kernel: the reference's float / double
+    mix reproduced, so the GPU map equals the host twin's arithmetic bit for bit, including raw = 0 -> inf and the KAT of
+    SURVEY §8(c) (int32 200000 -> 0.632 m)."""
+    w, h, d = 96, 64, 48
+    rng = np.random.default_rng(12)
+    raw = rng.integers(0, 400000, (2, h, w)).astype(np.int32)
+    raw[0, 0, :4] = [0, 1, 200000, 2 ** 31 - 1]
+    with api.StereoNetHIP(model_factory(w, h, d), max_batch=2) as eng:
+        depth, disp = eng.depth_from_raw(raw, want_disp=True)
+        scale = np.float32(eng.out_scale)
+    f, B = np.float32(527.1931762695312), np.float32(119.89382172)
+    dis = raw.astype(np.float32) * scale                                           # float
+    with np.errstate(divide="ignore"):
+        ref = (np.float64(f * B) / (dis.astype(np.float64) * 16.0 * 12.0) / 1000.0).astype(np.float32)
+    assert np.array_equal(depth, ref) and np.isinf(depth[0, 0, 0])
+    assert abs(float(depth[0, 0, 2]) - 0.632) < 1e-3
+    assert np.array_equal(disp, dis * np.float32(16.0) * np.float32(12.0))
