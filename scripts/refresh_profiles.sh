@@ -28,7 +28,7 @@ $T rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --outpu
 cd $ROOT
 python scripts/lds_conflicts.py $(find $OUT/${TAG}_pmc_lds -name "*counter_collection.csv" | head -1) $OUT/${TAG}_lds_conflicts.json > $OUT/${TAG}_lds_conflicts.txt 2>&1
 python scripts/pmc_traffic.py $(find $OUT/${TAG}_pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1) \
-    $(find $OUT/${TAG}_pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1) $OUT/${TAG}_pmc_traffic.json k_ref_block_stream_f16 ${PAIRS_PER_LAUNCH:-4} > $OUT/${TAG}_pmc_summary.txt 2>&1
+    $(find $OUT/${TAG}_pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1) $OUT/${TAG}_pmc_traffic.json k_ref_block_stream_f16 ${PAIRS_PER_LAUNCH:-4} ", true>" > $OUT/${TAG}_pmc_summary.txt 2>&1
 python scripts/mfma_busy.py $(find $OUT/${TAG}_pmc_mfma -name "*counter_collection.csv" | head -1) $OUT/${TAG}_mfma_busy.json > $OUT/${TAG}_mfma_busy.txt 2>&1
 $T python bench.py --precision f16x3 --no-cpu-baseline --no-end-to-end --steps 20 > $OUT/${TAG}_f16x3_b64_bench.json 2>> $OUT/${TAG}_bench.err
 $T python bench.py --precision fp32 --no-cpu-baseline --no-end-to-end --steps 5 --batch 16 > $OUT/${TAG}_fp32_b16_bench.json 2>> $OUT/${TAG}_bench.err
@@ -39,6 +39,8 @@ $T python bench.py --refine multi --steps 40 --no-cpu-baseline --no-end-to-end >
 $T python bench.py --gpus 2 --dist-backend gloo --device-map 0,0 --batch 16 --steps 10 --no-cpu-baseline --no-end-to-end > $OUT/${TAG}_two_ranks_one_gpu_gloo.json 2>> $OUT/${TAG}_bench.err   # functional N > 1 run
 $T python bench.py --stream 10 --batch 16 > $OUT/${TAG}_stream_c2_b16.json 2>> $OUT/${TAG}_bench.err
 $T python bench.py --config c5 --stream 10 --batch 16 > $OUT/${TAG}_stream_c5_b16.json 2>> $OUT/${TAG}_bench.err
+python scripts/node_bench.py 800 > $OUT/${TAG}_node_bench_publish1.json 2>> $OUT/${TAG}_bench.err
+python scripts/node_bench.py 800 STEREONET_PUB_OUTPUT=0 > $OUT/${TAG}_node_bench_publish0.json 2>> $OUT/${TAG}_bench.err
 [ -x scripts/build/mall_probe ] && ./scripts/build/mall_probe > $OUT/${TAG}_mall_probe.txt 2>&1
 # clock and package power while the timed workload runs (the tower runs at the 1400 W cap)
 python bench.py --steps 2000 --no-cpu-baseline --no-end-to-end --no-verify > /dev/null 2>&1 &

@@ -83,7 +83,7 @@ static hipError_t launch_stream(hipStream_t st, const Layer& L1, const Layer& L2
   if (nwg > sc.total_rows) nwg = sc.total_rows;
   sc.rows_per_wg = (sc.total_rows + nwg - 1) / nwg;
   const int grid = (sc.total_rows + sc.rows_per_wg - 1) / sc.rows_per_wg;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * PROBE_NWR), T::LDS_BYTES, st, x, y, L1.wfrag, L1.bias, L2.wfrag, L2.bias, g, sc, dump);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * PROBE_NWR), T::LDS_BYTES, st, x, y, L1.wfrag, L1.bias, L2.wfrag, L2.bias, g, sc, dump, StreamHeadArgs{});
   return hipGetLastError();
 }
 
