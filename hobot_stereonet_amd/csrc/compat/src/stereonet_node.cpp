@@ -23,60 +23,49 @@
 
 #include "image_io.h"
 #include "jpeg_nv12.h"
+#include "jpeg_pool.h"
 
 namespace hobot {
 namespace stereonet {
 
-// The reference encodes the left eye on the executor thread inside FeedImg (stereonet_node.cpp:749-786), which is fine at
-// a 30 fps camera and a 15-40 ms encoder but serialises a backend that finishes a pair in 0.5 ms.  Here FeedImg only queues
-// the encode: a fixed set of worker threads works through the queue, several frames at a time, and PostProcess — which
-// the completion thread calls in request order — waits for the request's own JPEG.  The queue is bounded (back-pressure
-// on the executor thread) so that frames cannot pile up behind a slow encoder.
-class JpegPool {
- public:
-  explicit JpegPool(int threads) : cap_(4 * (size_t)threads + 16) {
-    for (int i = 0; i < threads; ++i) th_.emplace_back([this] { Loop(); });
-  }
-  ~JpegPool() {
-    {
-      std::lock_guard<std::mutex> lk(mu_);
-      stop_ = true;
-    }
-    cv_.notify_all();
-    for (auto& t : th_) t.join();
-  }
-  void Post(std::function<void()> job) {
-    {
-      std::unique_lock<std::mutex> lk(mu_);
-      room_.wait(lk, [&] { return q_.size() < cap_ || stop_; });
-      q_.push_back(std::move(job));
-    }
-    cv_.notify_one();
-  }
-  int threads() const { return (int)th_.size(); }
-
- private:
-  void Loop() {
-    for (;;) {
-      std::function<void()> task;
-      {
-        std::unique_lock<std::mutex> lk(mu_);
-        cv_.wait(lk, [&] { return stop_ || !q_.empty(); });
-        if (q_.empty()) return;
-        task = std::move(q_.front());
-        q_.pop_front();
+std::shared_future<bool> SubmitSlicedJpeg(JpegPool& pool, std::shared_ptr<const void> keep_alive, const uint8_t* nv12, int w, int h,
+                                          int pitch, int quality, int slices, std::shared_ptr<BinDataType> out) {
+  struct Sliced {
+    std::vector<std::vector<uint8_t>> part;
+    std::atomic<int> left_to_do{0};
+    std::atomic<bool> ok{true};
+    std::promise<bool> done;
+  };
+  const int rows = JpegMcuRows(h);
+  int nsl = slices < 1 ? 1 : slices;
+  if (nsl > rows) nsl = rows;
+  const int per = (rows + nsl - 1) / nsl;
+  nsl = (rows + per - 1) / per;
+  auto st = std::make_shared<Sliced>();
+  st->part.resize((size_t)nsl);
+  st->left_to_do = nsl;
+  std::shared_future<bool> fut = st->done.get_future().share();
+  for (int k = 0; k < nsl; ++k)
+    pool.Post([keep_alive, nv12, out, st, w, h, pitch, quality, per, rows, nsl, k] {
+      const int r0 = k * per, r1 = r0 + per < rows ? r0 + per : rows;
+      if (!JpegAppendMcuRows(nv12, w, h, pitch, quality, r0, r1, st->part[(size_t)k])) st->ok = false;
+      if (--st->left_to_do != 0) return;
+      out->jpeg.clear();
+      bool ok = st->ok && JpegAppendHeader(w, h, quality, nsl > 1 ? per * ((w + 15) / 16) : 0, out->jpeg);
+      if (ok) {
+        size_t total = out->jpeg.size();
+        for (const auto& p : st->part) total += p.size() + 2;
+        out->jpeg.reserve(total);
+        for (int i = 0; i < nsl; ++i) {
+          out->jpeg.insert(out->jpeg.end(), st->part[(size_t)i].begin(), st->part[(size_t)i].end());
+          out->jpeg.push_back(0xFF);
+          out->jpeg.push_back(i + 1 < nsl ? (uint8_t)(0xD0 + (i & 7)) : (uint8_t)0xD9);
+        }
       }
-      room_.notify_one();
-      task();
-    }
-  }
-  std::mutex mu_;
-  std::condition_variable cv_, room_;
-  std::deque<std::function<void()>> q_;
-  std::vector<std::thread> th_;
-  const size_t cap_;
-  bool stop_ = false;
-};
+      st->done.set_value(ok);
+    });
+  return fut;
+}
 
 namespace {
 const rclcpp::Logger kLog = rclcpp::get_logger("stereonet_node");
@@ -245,43 +234,7 @@ void StereonetNode::OnStereoFrame(const hbm_img_msgs::msg::HbmMsg1080P::ConstSha
     request->sp_left_nv12 = left;
     const int quality = cfg_.jpeg_quality;
     const auto tq = std::chrono::steady_clock::now();
-    // One frame = several slices of MCU rows behind restart markers, one pool task each: with task_num = 4 requests in
-    // flight, whole-frame tasks would keep at most ~5 encoder threads busy and PostProcess would wait for the JPEG (measured:
-    // 13.6 ms per frame and thread -> 400 frames/s whatever the pool size).  The task that finishes last assembles the
-    // stream (header, slice, RSTm, slice, ..., EOI) and completes the request's future; nobody waits inside the pool.
-    struct Sliced {
-      std::vector<std::vector<uint8_t>> part;
-      std::atomic<int> left_to_do{0};
-      std::atomic<bool> ok{true};
-      std::promise<bool> done;
-    };
-    const int rows = JpegMcuRows(h);
-    int nsl = cfg_.jpeg_slices < 1 ? 1 : cfg_.jpeg_slices;
-    if (nsl > rows) nsl = rows;
-    const int per = (rows + nsl - 1) / nsl;
-    nsl = (rows + per - 1) / per;
-    auto st = std::make_shared<Sliced>();
-    st->part.resize((size_t)nsl);
-    st->left_to_do = nsl;
-    request->jpeg_ready = st->done.get_future().share();
-    for (int k = 0; k < nsl; ++k)
-      jpeg_pool_->Post([frame, left, st, w, h, pitch, quality, per, rows, nsl, k] {
-        const int r0 = k * per, r1 = r0 + per < rows ? r0 + per : rows;
-        if (!JpegAppendMcuRows(frame->data.data(), w, h, pitch, quality, r0, r1, st->part[(size_t)k])) st->ok = false;
-        if (--st->left_to_do != 0) return;
-        bool ok = st->ok && JpegAppendHeader(w, h, quality, nsl > 1 ? per * ((w + 15) / 16) : 0, left->jpeg);
-        if (ok) {
-          size_t total = left->jpeg.size();
-          for (const auto& p : st->part) total += p.size() + 2;
-          left->jpeg.reserve(total);
-          for (int i = 0; i < nsl; ++i) {
-            left->jpeg.insert(left->jpeg.end(), st->part[(size_t)i].begin(), st->part[(size_t)i].end());
-            left->jpeg.push_back(0xFF);
-            left->jpeg.push_back(i + 1 < nsl ? (uint8_t)(0xD0 + (i & 7)) : (uint8_t)0xD9);
-          }
-        }
-        st->done.set_value(ok);
-      });
+    request->jpeg_ready = SubmitSlicedJpeg(*jpeg_pool_, frame, frame->data.data(), w, h, pitch, quality, cfg_.jpeg_slices, left);
     g_stats.add(1, tq);
   }
   request->preprocess_time_ms = elapsed_ms(t_pre);

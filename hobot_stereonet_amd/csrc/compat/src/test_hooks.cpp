@@ -4,6 +4,7 @@
 
 #include "image_io.h"
 #include "jpeg_nv12.h"
+#include "jpeg_pool.h"
 #include "parser.h"
 #include "preprocess.h"
 #include "render.h"
@@ -73,6 +74,35 @@ long snhost_jpeg_nv12_sliced(const unsigned char* nv12, int w, int h, int pitch,
   if (!hobot::stereonet::EncodeNv12ToJpegSliced(nv12, w, h, pitch, quality, rows_per_slice, j) || (long)j.size() > cap) return -1;
   memcpy(out, j.data(), j.size());
   return (long)j.size();
+}
+
+// The node's encoder-thread path without the node: `frames` copies of one image go through a JpegPool of `threads`
+// threads as `slices` slices each, all in flight together; every assembled stream must equal EncodeNv12ToJpegSliced's.
+// Returns the stream size (written to out, <= cap), -1 on an encoder failure, -2 on a mismatch.
+long snhost_jpeg_pool(const unsigned char* nv12, int w, int h, int pitch, int quality, int threads, int slices, int frames,
+                      unsigned char* out, long cap) {
+  using namespace hobot::stereonet;
+  const int rows = JpegMcuRows(h);
+  int nsl = slices < 1 ? 1 : (slices > rows ? rows : slices);
+  const int per = (rows + nsl - 1) / nsl;
+  std::vector<uint8_t> want;
+  if (!EncodeNv12ToJpegSliced(nv12, w, h, pitch, quality, per, want)) return -1;
+  std::vector<std::shared_ptr<BinDataType>> outs;
+  std::vector<std::shared_future<bool>> futs;
+  {
+    JpegPool pool(threads);
+    for (int f = 0; f < frames; ++f) {
+      outs.push_back(std::make_shared<BinDataType>());
+      futs.push_back(SubmitSlicedJpeg(pool, nullptr, nv12, w, h, pitch, quality, slices, outs.back()));
+    }
+    for (auto& fu : futs)
+      if (!fu.get()) return -1;
+  }      // the pool joins its threads here
+  for (auto& o : outs)
+    if (o->jpeg != want) return -2;
+  if ((long)want.size() > cap) return -1;
+  memcpy(out, want.data(), want.size());
+  return (long)want.size();
 }
 
 // the exact-DCT form of round 3 (the checker of the fast encoder); returns the JPEG size (<= cap) or -1

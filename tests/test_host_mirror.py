@@ -29,6 +29,8 @@ def hostlib():
     lib.snhost_jpeg_nv12.argtypes = [vp, ci, ci, ci, ci, vp, C.c_long]
     lib.snhost_jpeg_nv12_sliced.restype = C.c_long
     lib.snhost_jpeg_nv12_sliced.argtypes = [vp, ci, ci, ci, ci, ci, vp, C.c_long]
+    lib.snhost_jpeg_pool.restype = C.c_long
+    lib.snhost_jpeg_pool.argtypes = [vp, ci, ci, ci, ci, ci, ci, ci, vp, C.c_long]
     lib.snhost_jpeg_nv12_reference.restype = C.c_long
     lib.snhost_jpeg_nv12_reference.argtypes = [vp, ci, ci, ci, ci, vp, C.c_long]
     lib.snhost_parse.argtypes = [vp, ci, ci, C.c_float, vp, vp]
@@ -130,6 +132,22 @@ def test_sliced_jpeg_decodes_to_the_same_image(hostlib, w, h, per):
     a = np.asarray(Image.open(io.BytesIO(one[:n].tobytes())))
     b = np.asarray(Image.open(io.BytesIO(sl[:m].tobytes())))
     assert a.shape == (h, W, 3) and (a == b).all()
+
+
+@pytest.mark.parametrize("w,h,threads,slices,frames", [(640, 360, 4, 8, 12), (96, 64, 3, 4, 40), (70, 50, 2, 9, 25), (64, 48, 1, 1, 5)])
+def test_encoder_threads_assemble_the_sliced_stream(hostlib, w, h, threads, slices, frames):
+    """The node's encoder-thread path (JpegPool + SubmitSlicedJpeg: one task per slice, the last one to finish assembles)
+    without the node: many frames in flight together, every assembled stream identical to EncodeNv12ToJpegSliced's and
+    decodable.  Also runs under ASan / UBSan (scripts/run_sanitized.sh)."""
+    from PIL import Image
+    W = w + (w & 1)
+    fr = synth.sbs_nv12_frame(W, h, 32, 13).reshape(h * 3 // 2, 2 * W)
+    buf = np.empty(W * h * 4 + 8192, np.uint8)
+    n = hostlib.snhost_jpeg_pool(fr.ctypes.data, W, h, 2 * W, 90, threads, slices, frames, buf.ctypes.data, buf.size)
+    assert n > 600, n
+    img = Image.open(io.BytesIO(buf[:n].tobytes()))
+    assert img.size == (W, h)
+    assert np.abs(np.asarray(img.convert("YCbCr"), np.float32)[..., 0] - fr[:h, :W]).mean() < 6.0
 
 
 @pytest.mark.gpu
