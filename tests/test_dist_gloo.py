@@ -55,6 +55,17 @@ def _worker(rank, world, port, n, out_path):
         assert [int(t[0, 0]) for t in rb] == [r * 10 + 2 for r in range(world)]
     else:
         assert ra is None and rb is None
+    # the root's receive lists allocated once and reused step after step (bench.py's two buffer sets)
+    bufs = [sdist.AsyncGather.alloc_root_buffers(a, dst=0) for _ in range(2)]
+    assert (bufs[0] is None) == (rank != 0)
+    for step in range(4):
+        src = torch.full((2, 3), rank * 100 + step, dtype=torch.int32)
+        got_s = sdist.AsyncGather(src, dst=0, bufs=bufs[step & 1]).wait()
+        if rank == 0:
+            assert got_s is bufs[step & 1] and [int(t[1, 2]) for t in got_s] == [r * 100 + step for r in range(world)]
+    if rank == 0:
+        with pytest.raises(ValueError):
+            sdist.AsyncGather(a, dst=0, bufs=bufs[0][:1])
     dist.barrier()
     dist.destroy_process_group()
 
