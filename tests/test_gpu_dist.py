@@ -161,3 +161,30 @@ def test_rccl_gather_path_single_rank():
         assert torch.equal(out, a)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_emulated_root_ingress_runs_and_verifies():
+    """bench.py --emulate-root-ingress G: the gather root's receive side emulated on one GPU (G - 1 shard-sized copies per
+    step through sn_dbg_copy_limited on a side stream, overlapping the next step).  The batch must still verify."""
+    r, lines = _run(["--batch", "4", "--steps", "3", "--warmup", "1", "--emulate-root-ingress", "4", "--ingress-workgroups", "8",
+                     "--no-cpu-baseline", "--no-end-to-end", "--no-long"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = lines[0]
+    assert d["verified"] is True and d["n_gpus"] == 1
+    assert d["emulated_root_ingress"]["copies_per_step"] == 3 and d["emulated_root_ingress"]["bytes_per_copy"] == 4 * 1280 * 720 * 4
+
+
+@pytest.mark.gpu
+def test_limited_copy_hook_copies():
+    import torch
+    from hobot_stereonet_amd import api
+    lib = api.load_library()
+    dev = torch.device("cuda", 0)
+    src = torch.arange(1 << 20, dtype=torch.int32, device=dev)
+    dst = torch.zeros_like(src)
+    st = torch.cuda.Stream(device=dev)
+    assert lib.sn_dbg_copy_limited(dst.data_ptr(), src.data_ptr(), src.numel() * 4, 3, st.cuda_stream) == 0
+    st.synchronize()
+    assert torch.equal(src, dst)
+    assert lib.sn_dbg_copy_limited(dst.data_ptr(), src.data_ptr(), 12, 3, st.cuda_stream) != 0      # not a multiple of 16
