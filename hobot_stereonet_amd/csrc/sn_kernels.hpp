@@ -1533,341 +1533,6 @@ __global__ __launch_bounds__(256, MINW) void k_ref_conv_f16_v2(const uint4* __re
 }
 
 // ------------------------------------------------------------------------------------------
-// Last tower layer + refinement head in ONE kernel (fp16 mode):
-//   y    = lrelu(x + conv2(t) + b2)                      (block 6, second conv; y rounded to fp16 as the tensor would be)
-//   r    = b_h + sum_{c,tap} w_h[c][tap] * y[c][. + tap]  (3x3, 32 -> 1, zero padding outside Hp x Wp)
-//   disp = relu(up16(disp_low) + D * r)   ->   float map + int32 wire map
-// Unfused, y costs a 59 MB write and a 59 MB (x1.3 halo) read per pair plus a launch.  Here the conv runs on
-// OVERLAPPING 8 x 64 tiles (origin 6 ty - 1, 62 tx - 1: 1.4x the tiles of this one layer, whose matrix pipes are 25 %
-// busy) and each tile finishes its 6 x 62 interior:
-//   * the accumulator rows of a segment ARE the head's B operand: lane (j, g) holds y of channels e + 8q + 4g
-//     (q = r >> 2, e = r & 3), and registers 8kk .. 8kk+7 are exactly the eight K values it must supply to K-step kk
-//     when the head's A rows are packed in that channel order — no LDS transpose, one cvt_pk per pair;
-//   * taps are the M dimension (as in k_head_final_f16): P[tap][pixel] from 4 MFMAs per segment (hi / lo weights);
-//   * P (9 x 8 x 64 fp32 = 18 KB) goes into the ring buffer the tile's second phase has just consumed — it is free until
-//     the next tile's first barrier, after which the DMA group g0+4 refills it — so LDS stays at 63 KB (two
-//     workgroups per CU); two extra barriers per tile;
-//   * every thread then sums nine shifted P values for (up to) two output pixels.  The four bilinear taps of the
-//     upsampled disparity are fetched with inline-asm loads next to the residual loads (older than the DMA group
-//     that follows, so the counted vmcnt retires them without draining the ring); the two maps are written by
-//     exactly four store instructions per wave and tile (lanes without a pixel store into a dump buffer), so the
-//     counted waits stay valid.
-// ------------------------------------------------------------------------------------------
-struct HeadFuse {
-  static constexpr int OH = 6, OW = 62;                    // head outputs per conv tile
-  static constexpr int NPX = OH * OW;                      // 372: threads handle p = tid and tid + 256
-  static constexpr int NOUT = 4;                           // store instructions per wave and tile
-  static constexpr int NUP = 8;                            // upsample tap loads per lane and tile
-  // LDS behind the ring: tile-queue words (16 B), conv bias per (g, r) (128 B), the head's four A fragments (4 KB) —
-  // kept out of the register file (the plain residual kernel already uses 252 VGPRs)
-  static constexpr int EXTRA_BYTES = 16 + 128 + 4 * 64 * 16;
-};
-
-__global__ __launch_bounds__(256, 2) void k_ref_conv_head_f16(const uint4* __restrict__ in, const uint4* __restrict__ res,
-                                                              const uint4* __restrict__ wfrag, const float* __restrict__ bias,
-                                                              RefGeom g, int nimg, unsigned* tile_ctr,
-                                                              const float* __restrict__ hw,      // head weights [32][9]
-                                                              float hbias, const float* __restrict__ disp_low, int hl,
-                                                              int wl, int H, int W, float dmax, float inv_q, UpScale ups,
-                                                              float* out_disp, int32_t* out_raw, unsigned* dump) {
-  constexpr int DIL = 1, TW = 64, TH = 8, NB = 3;
-  using T = RefTile2<DIL, TW, TH, NB>;
-  using F = HeadFuse;
-  static_assert(9 * TH * TW * 4 <= T::BUF * 16, "P tile must fit one ring buffer");
-  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int j = lane & 31, gh = lane >> 5;
-
-  const int per_img = g.tiles_x * g.tiles_y;               // tile grid of the HEAD outputs (6 x 62 steps)
-  const int total = per_img * nimg;
-  const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, nlb = gridDim.x >> 3;
-  const int t_begin = (int)((long)xcd * total / 8), t_end = (int)((long)(xcd + 1) * total / 8);
-  const int t0 = t_begin + lb;
-  if (t0 >= t_end) return;
-
-  const int seg0 = wave * T::SPW;
-  const int lane_off = gh * T::PLANE + (seg0 / T::CSEG) * T::COLS + j;
-  const unsigned plane_b = (unsigned)g.Hs * (unsigned)g.Ws * 16u;
-  unsigned dma_voff[T::KW];
-#pragma unroll
-  for (int k = 0; k < T::KW; ++k) {
-    int i = wave + 4 * k;
-    i = i < T::NINST ? i : T::NINST - 1;
-    int s = i * 64 + lane;
-    s = s < T::HALF ? s : T::HALF - 1;
-    const int pc = s / T::PLANE;
-    const int rem = s - pc * T::PLANE;
-    const int r = rem / T::COLS;
-    const int c = rem - r * T::COLS;
-    dma_voff[k] = (unsigned)pc * plane_b + ((unsigned)r * (unsigned)g.Ws + (unsigned)c) * 16u;
-  }
-  unsigned io_voff[T::SPW];
-#pragma unroll
-  for (int s = 0; s < T::SPW; ++s) {
-    const int seg = seg0 + s;
-    io_voff[s] = ((unsigned)(seg / T::CSEG) * (unsigned)g.Ws + (unsigned)((seg % T::CSEG) * 32 + j)) * 16u + gh * 8u;
-  }
-  // output pixels of this thread inside the 6 x 62 interior (tile-relative), -1 = none
-  int opy[2], opx[2];
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int p = tid + 256 * k;
-    opy[k] = p < F::NPX ? p / F::OW : -1;
-    opx[k] = p < F::NPX ? p - (p / F::OW) * F::OW : 0;
-  }
-
-  auto tile_xy = [&](int t, int& img, int& y0, int& x0) {      // conv tile origin = head tile origin - 1
-    if (g.rev) t = t_begin + (t_end - 1 - t);
-    img = t / per_img;
-    const int rem = t - img * per_img;
-    const int ty = rem / g.tiles_x;
-    y0 = ty * F::OH - 1;
-    x0 = (rem - ty * g.tiles_x) * F::OW - 1;
-  };
-  auto tile_base = [&](int img, int y, int x) -> unsigned {
-    return (((unsigned)img * 4u * (unsigned)g.Hs + (unsigned)(y + kRefPad)) * (unsigned)g.Ws + (unsigned)(x + kRefPad)) * 16u;
-  };
-  auto issue = [&](int gp, int img, int y0, int x0) {
-    const char* src = reinterpret_cast<const char*>(in) + (tile_base(img, y0 - DIL, x0 - DIL) + 2u * (gp & 1) * plane_b);
-    uint4* dst = lds + (gp % NB) * T::BUF;
-#pragma unroll
-    for (int k = 0; k < T::KW; ++k) {
-      int i = wave + 4 * k;
-      i = i < T::NINST ? i : T::NINST - 1;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + dma_voff[k]),
-                                       (__attribute__((address_space(3))) void*)(dst + i * 64), 16, 0, 0);
-    }
-  };
-
-  int img, y0, x0, nimg_ = 0, ny0 = 0, nx0 = 0;
-  tile_xy(t0, img, y0, x0);
-  issue(0, img, y0, x0);
-  issue(1, img, y0, x0);
-  half8 wf[18];
-#pragma unroll
-  for (int i = 0; i < 18; ++i) {
-    const uint4 v = wfrag[i * 64 + lane];
-    wf[i] = *reinterpret_cast<const half8*>(&v);
-  }
-  // conv bias and head A fragments live in LDS behind the ring (written once, read per tile)
-  float* s_bias = reinterpret_cast<float*>(lds + NB * T::BUF + 1);              // [g][16]
-  uint4* s_hw = lds + NB * T::BUF + 1 + 8;                                       // [kk][hi|lo][64 lanes]
-  if (tid < 32) s_bias[tid] = bias[(tid & 3) + 8 * ((tid & 15) >> 2) + 4 * (tid >> 4)];
-  if (wave == 0) {
-    // head A fragments: row = tap (lane & 31 < 9), K-step kk, k = 8 g + m  <->  channel (m & 3) + 8 (2 kk + (m >> 2)) + 4 g
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      half8 hi8, lo8;
-#pragma unroll
-      for (int m = 0; m < 8; ++m) {
-        const int c = (m & 3) + 8 * (2 * kk + (m >> 2)) + 4 * gh;
-        const float wv = j < 9 ? hw[c * 9 + j] : 0.f;
-        const _Float16 hi = (_Float16)wv;
-        hi8[m] = hi;
-        lo8[m] = (_Float16)((wv - (float)hi) * kSplitScale);
-      }
-      s_hw[(2 * kk) * 64 + lane] = *reinterpret_cast<const uint4*>(&hi8);
-      s_hw[(2 * kk + 1) * 64 + lane] = *reinterpret_cast<const uint4*>(&lo8);
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 18; ++i) asm volatile("" : "+v"(wf[i]));
-  wait_vmcnt<0>();
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the first tile's first barrier publishes s_bias / s_hw
-  int t_next = t0 + nlb;
-  int t_next2 = t0 + 2 * nlb;
-  unsigned* tile_slot = reinterpret_cast<unsigned*>(lds + NB * T::BUF);
-  unsigned* const my_ctr = tile_ctr + 16 * xcd;
-  const size_t HWo = (size_t)H * W;
-  const int dump_off = tid;
-
-  f32x16 acc[T::SPW];
-  for (int ti = 0;; ++ti) {
-    const int g0 = 2 * ti;
-    const bool has_next = t_next < t_end;
-    if (has_next) tile_xy(t_next, nimg_, ny0, nx0);
-    // ---- phase g0 ----
-    if (ti == 0) wait_vmcnt<T::KW>();
-    else wait_vmcnt<T::KW + F::NOUT>();
-    block_barrier();
-    unsigned fetched;
-    asm volatile("" : "=v"(fetched));
-    if (has_next && wave == 0) {
-      unsigned one = 1;
-      unsigned long long saved_exec;
-      asm volatile(
-          "s_mov_b64 %1, exec\n\t"
-          "s_mov_b64 exec, 1\n\t"
-          "v_mov_b32 %0, -1\n\t"
-          "global_atomic_add %0, %2, %3, off sc0\n\t"
-          "s_mov_b64 exec, %1"
-          : "+v"(fetched), "=&s"(saved_exec)
-          : "v"(my_ctr), "v"(one)
-          : "memory");
-    }
-    if (has_next) issue(g0 + 2, nimg_, ny0, nx0);
-    // residual loads spread over this phase's MFMAs (see k_ref_conv_f16_v2): SGPR base + 32-bit VGPR offset
-    const unsigned tb = tile_base(img, y0, x0);
-    uint2 rres[T::NSTORE];
-    const char* const rbase = reinterpret_cast<const char*>(res) + tb;                         // uniform
-    auto res_load = [&](int m) {
-      if ((m & 1) && (m >> 1) < T::NSTORE) {
-        const int i = m >> 1, q = i / T::SPW, sg = i - q * T::SPW;
-        const char* rq = rbase + (unsigned)q * plane_b;
-        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(rres[sg * 4 + q]) : "v"(io_voff[sg]), "s"(rq) : "memory");
-      }
-    };
-    {
-      f32x16 binit;                        // conv bias of this lane's 16 rows, from LDS: C operand of the first MFMAs
-      const f32x4* bq = reinterpret_cast<const f32x4*>(s_bias + 16 * gh);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 b4 = bq[q];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) binit[4 * q + e] = b4[e];
-      }
-      ref2_compute_init<DIL, TW, TH>(lds + (g0 % NB) * T::BUF + lane_off, wf, binit, acc, res_load);
-    }
-
-    // ---- phase g0+1 ----
-    if (has_next) wait_vmcnt<T::KW + T::NSTORE>();            // younger than group g0+1: group g0+2 + the residual loads
-    else wait_vmcnt<T::NSTORE>();
-    if (has_next && wave == 0) {
-      asm volatile("" : "+v"(fetched));
-      if (__builtin_amdgcn_readfirstlane(fetched) == 0xFFFFFFFFu) {
-        wait_vmcnt<0>();
-        asm volatile("" : "+v"(fetched));
-      }
-      if (lane == 0) tile_slot[ti & 1] = fetched;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-    block_barrier();
-    if (has_next) t_next2 = t_begin + 2 * nlb + (int)__builtin_amdgcn_readfirstlane(tile_slot[ti & 1]);
-    else t_next2 = t_end;
-
-    // the bilinear taps of this thread's output pixels: inline asm, issued BEFORE the next DMA group
-    float uv[F::NUP];
-    const float* dl = disp_low + (size_t)img * hl * wl;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      int Y = y0 + 1 + (opy[k] < 0 ? 0 : opy[k]), X = x0 + 1 + opx[k];
-      Y = Y < H ? Y : H - 1;
-      X = X < W ? X : W - 1;
-      float sy = ((float)Y + 0.5f) * ups.rs - 0.5f;
-      float sx = ((float)X + 0.5f) * ups.rs - 0.5f;
-      sy = sy < 0.f ? 0.f : sy;
-      sx = sx < 0.f ? 0.f : sx;
-      const int yy0 = (int)sy, xx0 = (int)sx;
-      const int yy1 = yy0 < hl - 1 ? yy0 + 1 : yy0, xx1 = xx0 < wl - 1 ? xx0 + 1 : xx0;
-      const float* a00 = dl + yy0 * wl + xx0;
-      const float* a01 = dl + yy0 * wl + xx1;
-      const float* a10 = dl + yy1 * wl + xx0;
-      const float* a11 = dl + yy1 * wl + xx1;
-      asm volatile("global_load_dword %0, %1, off" : "=v"(uv[4 * k + 0]) : "v"(a00) : "memory");
-      asm volatile("global_load_dword %0, %1, off" : "=v"(uv[4 * k + 1]) : "v"(a01) : "memory");
-      asm volatile("global_load_dword %0, %1, off" : "=v"(uv[4 * k + 2]) : "v"(a10) : "memory");
-      asm volatile("global_load_dword %0, %1, off" : "=v"(uv[4 * k + 3]) : "v"(a11) : "memory");
-    }
-    const bool more = has_next;
-    if (more) issue(g0 + 3, nimg_, ny0, nx0);
-    ref2_compute<DIL, TW, 1, TH>(lds + ((g0 + 1) % NB) * T::BUF + lane_off, wf, acc);
-    if (more) wait_vmcnt<T::KW>(); else wait_vmcnt<0>();
-#pragma unroll
-    for (int i = 0; i < T::NSTORE; ++i) asm volatile("" : "+v"(rres[i]));
-#pragma unroll
-    for (int i = 0; i < F::NUP; ++i) asm volatile("" : "+v"(uv[i]));
-
-    float one = 1.0f;
-    asm volatile("" : "+v"(one));          // opaque multiplier: hipcc then adds the fp16 residual with one v_fma_mix_f32
-    // ---- y (fp16) -> P[tap][pixel] on the matrix core ----
-    const bool interior = y0 >= 0 && y0 + TH <= g.H && x0 >= 0 && x0 + TW <= g.W;     // wave-uniform
-    float* s_p = reinterpret_cast<float*>(lds + ((g0 + 1) % NB) * T::BUF);          // [9][TH][TW], free from here on
-    block_barrier();                      // every wave is done reading ring buffer (g0+1) % NB
-    half8 ah[2], al[2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const uint4 a = s_hw[(2 * kk) * 64 + lane], b = s_hw[(2 * kk + 1) * 64 + lane];
-      ah[kk] = *reinterpret_cast<const half8*>(&a);
-      al[kk] = *reinterpret_cast<const half8*>(&b);
-    }
-#pragma unroll
-    for (int s = 0; s < T::SPW; ++s) {
-      const int seg = seg0 + s;
-      bool inside = true;
-      if (!interior) {
-        const int gy = y0 + seg / T::CSEG, gx = x0 + (seg % T::CSEG) * 32 + j;
-        inside = (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W;
-      }
-      half8 yk[2];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const uint2 rw = rres[s * 4 + q];
-        const half4 rv = *reinterpret_cast<const half4*>(&rw);
-        float u[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) u[e] = __builtin_fmaf((float)rv[e], one, acc[s][4 * q + e]);      // v_fma_mix_f32
-        const uint2 pk{act_pack2_f16(u[0], u[1], (_Float16)kSlope), act_pack2_f16(u[2], u[3], (_Float16)kSlope)};
-        const half4 hq = *reinterpret_cast<const half4*>(&pk);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) yk[q >> 1][4 * (q & 1) + e] = inside ? hq[e] : (_Float16)0.f;
-      }
-      f32x16 pa, pb;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        pa[r] = 0.f;
-        pb[r] = 0.f;
-      }
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        pa = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk], yk[kk], pa, 0, 0, 0);
-        pb = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[kk], yk[kk], pb, 0, 0, 0);
-      }
-      float* dst = s_p + (seg / T::CSEG) * TW + (seg % T::CSEG) * 32 + j;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) dst[(4 * gh + r) * (TH * TW)] = pa[r] + pb[r] * kSplitInv;
-      if (gh == 0) dst[8 * (TH * TW)] = pa[4] + pb[4] * kSplitInv;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    block_barrier();                      // P complete
-    // ---- nine shifted sums, epilogue, exactly NOUT store instructions per wave ----
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int oy = opy[k] < 0 ? 0 : opy[k], ox = opx[k];
-      float r = hbias;
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) r += s_p[(ky * 3 + kx) * (TH * TW) + (oy + ky) * TW + ox + kx];
-      const int Y = y0 + 1 + oy, X = x0 + 1 + ox;
-      const bool ok = opy[k] >= 0 && Y < H && X < W;
-      // bilinear weights of (Y, X) (the same arithmetic as at the loads above; out-of-image lanes are discarded)
-      float sy = ((float)(Y < H ? Y : H - 1) + 0.5f) * ups.rs - 0.5f;
-      float sx = ((float)(X < W ? X : W - 1) + 0.5f) * ups.rs - 0.5f;
-      sy = sy < 0.f ? 0.f : sy;
-      sx = sx < 0.f ? 0.f : sx;
-      const float ly = sy - (float)(int)sy, lx = sx - (float)(int)sx;
-      const float hy = 1.0f - ly, hx = 1.0f - lx;
-      const float up = (hy * (hx * uv[4 * k] + lx * uv[4 * k + 1]) + ly * (hx * uv[4 * k + 2] + lx * uv[4 * k + 3])) * ups.mul;
-      float d = up + dmax * r;
-      d = d > 0.f ? d : 0.f;
-      const size_t o = (size_t)img * HWo + (size_t)Y * W + X;
-      float* pd = (ok && out_disp) ? out_disp + o : reinterpret_cast<float*>(dump) + dump_off;
-      int32_t* pr = (ok && out_raw) ? out_raw + o : reinterpret_cast<int32_t*>(dump) + 256 + dump_off;
-      asm volatile("global_store_dword %0, %1, off" ::"v"(pd), "v"(d) : "memory");
-      const int32_t q = (int32_t)__float2int_rn(d * inv_q);
-      asm volatile("global_store_dword %0, %1, off" ::"v"(pr), "v"(q) : "memory");
-    }
-    if (!has_next) break;
-    img = nimg_;
-    y0 = ny0;
-    x0 = nx0;
-    t_next = t_next2;
-    t_next2 = t_end;
-  }
-}
-
-// ------------------------------------------------------------------------------------------
 // SN_PREC_F16X3: the v2 tower kernel on split operands.  Every activation / weight is a pair of fp16 numbers
 // (hi = fp16(v), lo = fp16((v - hi) * 2^11)), i.e. 22 significant bits, and a product is evaluated with three
 // fp16 MFMAs:  x*w ~= xhi*whi + (xhi*wlo + xlo*whi) * 2^-11   (the dropped xlo*wlo term is 2^-22 relative).

@@ -160,11 +160,9 @@ struct sn_handle {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_tow_join[kMaxTowerStreams] = {}, ev_piece[kMaxPieceEvents] = {};
   bool overlap = true;
   int tower_streams = kMaxTowerStreams;
-  bool stream_last = true;   // the last block streamed too + separate head launch (SN_STREAM_LAST=0: conv + fused conv/head)
   unsigned ablate_x = 0;     // SN_ABLATE_X mask (diagnostic): layers whose input tensor gets its lo slots zeroed
   bool tail_fuse = true;     // the streamed last block carries the head (tail form); SN_TAIL_FUSE=0: block + k_head_final_f16
   int fuse_mode = 4;         // SN_FUSE: 4 = streaming fused blocks (default), 0 = two launches per block
-  bool head_fuse = true;     // last tower conv + head in one kernel (fp16 mode; SN_HEAD_FUSE=0 separates them)
   unsigned* dump = nullptr;  // 2 KB device scratch: where lanes without an output pixel store (fused head)
   bool use_graphs = true;    // hipGraph replay for the async single-pair path (SN_NO_GRAPH disables)
   ConvLayer down[kNDown], fres[kNFeatRes][2], fout, agg[kNAgg];
@@ -887,38 +885,6 @@ hipError_t launch_head_final_f16(hipStream_t st, bool split, const uint4* x, siz
   return hipGetLastError();
 }
 
-// last tower layer + head in one launch (fp16 mode): overlapping 8 x 64 conv tiles, 6 x 62 head outputs each
-hipError_t launch_ref_conv_head_f16(hipStream_t st, const RefLayerF16& L, const RefGeom& g, int num_cu, const uint4* in,
-                                    const uint4* res, int nimg, unsigned* tile_ctr, const float* hw, float hbias,
-                                    const float* disp_low, int hl, int wl, int H, int W, float dmax, float inv_q,
-                                    UpScale ups, float* out_disp, int32_t* out_raw, unsigned* dump) {
-  using T = RefTile2<1, 64, 8, 3>;
-  auto kern = k_ref_conv_head_f16;
-  if (tile_ctr == nullptr || dump == nullptr) return hipErrorInvalidValue;
-  constexpr int lds_bytes = 3 * T::BUF * 16 + HeadFuse::EXTRA_BYTES;
-  static_assert(2 * lds_bytes <= 160 * 1024, "two workgroups per CU");
-  {
-    hipError_t e = ensure_lds_attr(kern, lds_bytes);
-    if (e != hipSuccess) return e;
-  }
-  RefGeom gt = g;
-  gt.tiles_x = (W + HeadFuse::OW - 1) / HeadFuse::OW;
-  gt.tiles_y = (H + HeadFuse::OH - 1) / HeadFuse::OH;
-  const int total = gt.tiles_x * gt.tiles_y * nimg;
-  const int band = (total + 7) / 8;
-  int cap = num_cu * 2 / 8;
-  if (cap < 1) cap = 1;
-  const int nlb = cap < band ? cap : band;
-  hipLaunchKernelGGL(kern, dim3(nlb * 8), dim3(256), lds_bytes, st, in, res, L.wfrag, L.bias, gt, nimg, tile_ctr, hw,
-                     hbias, disp_low, hl, wl, H, W, dmax, inv_q, ups, out_disp, out_raw, dump);
-  return hipGetLastError();
-}
-
-bool head_fuse_env() {   // SN_HEAD_FUSE=0: separate last conv + head launches (A/B switch)
-  static const bool on = !(getenv("SN_HEAD_FUSE") != nullptr && atoi(getenv("SN_HEAD_FUSE")) == 0);
-  return on;
-}
-
 // SN_FUSE: how the residual blocks of the fp16 tower run.  4 (default) = the row-streaming fused kernel for the
 // dilations it supports, 0 = two launches per block.
 int fuse_env() {
@@ -1301,24 +1267,13 @@ int refine_level(sn_handle* h, Workspace& ws, hipStream_t st, const Tower& T, fl
                                 lo_slots * 16, ncu));
     if (pe) HIP_TRY(h, hipEventRecord(h->ev[4], st));
     flip();
-    // fp16 mode: the last conv of the tower and the head run as one kernel (the tower's output tensor is never
-    // written); needs the last block to be an unfused dilation-1 block
-    // (a streamed last block leaves its output in memory: the head then runs as its own launch)
-    const bool last_block_fused = h->fuse_mode == 4 && stream_block_supports(kRefDil[kNRefRes - 1]) && h->stream_last;
-    const bool head_fused = !x3 && h->head_fuse && kRefDil[kNRefRes - 1] == 1 && !last_block_fused;
     // tail form: the streamed last block computes the head too (its output tensor is never written, no head launch)
-    const bool tail = !x3 && last_block_fused && h->tail_fuse && kRefDil[kNRefRes - 1] == 1 && ups.rs <= 0.5f;
+    const bool last_streamed = h->fuse_mode == 4 && stream_block_supports(kRefDil[kNRefRes - 1]);
+    const bool tail = !x3 && last_streamed && h->tail_fuse && kRefDil[kNRefRes - 1] == 1 && ups.rs <= 0.5f;
     for (int i = 0; i < kNRefRes; ++i) {
       if (x3) {
         HIP_TRY(h, ref_conv_f16x3(st, T.rres16[i][0], g, ncu, kRefDil[i], x16, t16, nullptr, lo_slots, c, true));
         HIP_TRY(h, ref_conv_f16x3(st, T.rres16[i][1], g, ncu, kRefDil[i], t16, x16, x16, lo_slots, c, true));
-      } else if (head_fused && i == kNRefRes - 1) {
-        unsigned* ctr = chunk_ctr + 2 * i * kTileCtrStride;
-        HIP_TRY(h, ref_conv_f16(st, T.rres16[i][0], g, ncu, 1, x16, t16, nullptr, c, true, ctr));
-        flip();
-        if (pe) HIP_TRY(h, hipEventRecord(h->ev[5], st));          // the 11 plain tower launches end here
-        HIP_TRY(h, launch_ref_conv_head_f16(st, T.rres16[i][1], g, ncu, t16, x16, c, ctr + kTileCtrStride, T.rout.w,
-                                            T.rout.bias, src, sh, sw, H, W, dnorm, inv_q, ups, od, orw, h->dump));
       } else if (tail && i == kNRefRes - 1) {
         if (pe) HIP_TRY(h, hipEventRecord(h->ev[5], st));          // the plain tower launches end here
         StreamHeadArgs ha{T.rout.w, src, od, orw, T.rout.bias, dnorm, inv_q, sh, sw, H, W, ups};
@@ -1331,7 +1286,7 @@ int refine_level(sn_handle* h, Workspace& ws, hipStream_t st, const Tower& T, fl
         if (dom) HIP_TRY(h, hipEventRecord(h->ev_dom[2 * h->dom_pairs++ + 1], st));
       }
     }
-    if (!head_fused && !tail) {
+    if (!tail) {
       if (pe) HIP_TRY(h, hipEventRecord(h->ev[5], st));
       HIP_TRY(h, launch_head_final_f16(st, x3, x16, lo_slots, g, T.rout.w, T.rout.bias, src, sh, sw, H, W, dnorm, inv_q, ups,
                                        od, orw, c));
@@ -1741,10 +1696,7 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
   h->overlap = getenv("SN_NO_OVERLAP") == nullptr;
   h->use_graphs = getenv("SN_NO_GRAPH") == nullptr;
   h->fuse_mode = fuse_env();
-  // the last block streamed as well + the head as its own launch (default); SN_STREAM_LAST=0: conv + fused conv / head
-  h->stream_last = !(getenv("SN_STREAM_LAST") != nullptr && atoi(getenv("SN_STREAM_LAST")) == 0);
   h->tail_fuse = !(getenv("SN_TAIL_FUSE") != nullptr && atoi(getenv("SN_TAIL_FUSE")) == 0);
-  h->head_fuse = head_fuse_env();
   if (hipMalloc(reinterpret_cast<void**>(&h->dump), 4096) != hipSuccess) return fail(SN_ERR_NOMEM);
 
   BlobWalker bw{blob.data()};
@@ -2237,7 +2189,7 @@ int sn_get_dominant_kernel(sn_handle* h, char* name, size_t cap, int* launches, 
     int n = 0;
     for (int i = 0; i < kNRefRes; ++i) {
       const bool last = i == kNRefRes - 1;
-      if (stream_block_supports(kRefDil[i]) && (!last || ((h->stream_last || !h->head_fuse) && !(h->stream_last && h->tail_fuse)))) ++n;
+      if (stream_block_supports(kRefDil[i]) && !(last && h->tail_fuse)) ++n;
     }
     if (n > 0) {     // (n == 0, e.g. SN_STREAM_DIL=0: nothing is streamed — the per-layer description below applies)
       if (name && cap)
@@ -2253,9 +2205,7 @@ int sn_get_dominant_kernel(sn_handle* h, char* name, size_t cap, int* launches, 
              h->precision == SN_PREC_F16     ? "k_ref_conv_f16<DIL> (refinement 3x3 C->C, fp16 MFMA 32x32x16)"
              : h->precision == SN_PREC_F16X3 ? "k_ref_conv_f16x3<DIL> (refinement 3x3 C->C, 3x fp16 MFMA on hi/lo split operands)"
                                              : "k_ref_conv_f32<DIL> (refinement 3x3 C->C, weights-stationary, fp32 MFMA 32x32x2)");
-  // fp16 mode with the fused last layer: the timed span holds the 11 plain tower launches (6 without, 5 with residual)
-  const bool hf = f16 && h->head_fuse;
-  const int n_plain = kNRefRes, n_res = hf ? kNRefRes - 1 : kNRefRes;
+  const int n_plain = kNRefRes, n_res = kNRefRes;      // per-layer forms: six launches without, six with a residual
   if (launches) *launches = n_plain + n_res;   // per refinement chunk
   if (flops) *flops = 2.0 * px * kC * kC * 9;
   // algorithmic HBM bytes per launch: read the 32-channel input once + write the output once, plus the

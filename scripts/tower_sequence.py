@@ -15,7 +15,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 ks = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows)
 seq = []
 for s, e, n in ks:
-    if "k_ref_conv_f16_v2" in n or "k_ref_conv_head_f16" in n or "k_refin_f16" in n or "k_ref_block_stream_f16" in n or "k_head_final_f16" in n:
+    if "k_ref_conv_f16_v2" in n or "k_refin_f16" in n or "k_ref_block_stream_f16" in n or "k_head_final_f16" in n:
         m = re.search(r"k_ref_conv_f16_v2<(\d+), (\d+), (true|false)", n)
         b = re.search(r"k_ref_block_stream_f16<(\d+), (\d+), (\d+)", n)
         if "k_refin" in n:

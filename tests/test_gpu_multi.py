@@ -165,18 +165,13 @@ np.save(sys.argv[3], disp)
 
 
 @pytest.mark.parametrize("env,exact", [({"SN_TOWER_STREAMS": "2"}, True), ({"SN_NO_OVERLAP": "1"}, True), ({"SN_REV": "0"}, True),
-                                       ({"SN_HEAD_FUSE": "0"}, False),
-                                       ({"SN_TOWER_STREAMS": "2", "SN_HEAD_FUSE": "0"}, False),
-                                       # round 3: the streamed blocks are bit-identical to the two-launch form, so every way
-                                       # of mixing them (none, dilation 1 / 2 only, all but the last block) changes nothing ...
-                                       ({"SN_FUSE": "0", "SN_HEAD_FUSE": "0"}, True), ({"SN_STREAM_DIL": "2", "SN_HEAD_FUSE": "0", "SN_STREAM_LAST": "0"}, True),
-                                       # ... except through the head: fused with the last conv it sums in another order
-                                       ({"SN_FUSE": "0"}, False), ({"SN_STREAM_LAST": "0"}, False), ({"SN_STREAM_WGS": "100"}, True),
+                                       # the streamed blocks are bit-identical to the two-launch form and the tail form to block +
+                                       # k_head_final_f16, so every way of mixing them changes nothing
+                                       ({"SN_FUSE": "0"}, True), ({"SN_STREAM_DIL": "2"}, True), ({"SN_TAIL_FUSE": "0"}, True),
+                                       ({"SN_TOWER_STREAMS": "2", "SN_TAIL_FUSE": "0"}, True), ({"SN_STREAM_WGS": "100"}, True),
+                                       ({"SN_STREAM_PRIORITY": "1"}, True),
                                        # aggregation layers / down-convs on the plain tensors (k_conv_x3s) instead of the zero-bordered ones
-                                       ({"SN_AGG_DMA": "0"}, True), ({"SN_DOWN_DMA": "0"}, True), ({"SN_AGG_DMA": "0", "SN_DOWN_DMA": "0"}, True),
-                                       # round 4: the tail form (last streamed block + head in one launch) computes the head with
-                                       # k_head_final_f16's own MFMA sequence and summation order: bit-identical to block + head
-                                       ({"SN_TAIL_FUSE": "0"}, True), ({"SN_STREAM_PRIORITY": "1"}, True)])
+                                       ({"SN_AGG_DMA": "0"}, True), ({"SN_DOWN_DMA": "0"}, True), ({"SN_AGG_DMA": "0", "SN_DOWN_DMA": "0"}, True)])
 def test_diagnostic_switches_run_the_same_network(model_factory, oracle, weights_blob, tmp_path, env, exact):
     """The library's diagnostic environment switches select other schedules / kernel pairings of the
     SAME arithmetic: stream layout switches must be bit-identical to the default, kernel pairings within the EPE bar."""
