@@ -15,11 +15,15 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int NM, int NV>
-__global__ __launch_bounds__(512, 1) void k_mix(float* out, int steps) {
+// FEAT bits (what else the real kernel does per super-step): 1 = conv1's waves stream 17 KB of x per step into an LDS ring by
+// LDS-DMA from a 236 MB tensor, counted vmcnt; 2 = conv2's waves store 16 KB of y per step (four 16-byte stores per lane);
+// 4 = conv1's waves write t (8 ds_write_b64 per wave), conv2's read the residual (8 ds_read_b64 per wave)
+template <int NM, int NV, int FEAT = 0>
+__global__ __launch_bounds__(512, 1) void k_mix(float* out, int steps, const uint4* xin = nullptr, uint4* yout = nullptr) {
   extern __shared__ __attribute__((aligned(16))) uint4 lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, role = wave >> 2;
-  for (int i = tid; i < 8192; i += 512) lds[i] = uint4{0x3c003c00u + i, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), role = wave >> 2;
+  for (int i = tid; i < 3072; i += 512) lds[i] = uint4{0x3c003c00u + i, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
   __syncthreads();
   half8 wf[18];
 #pragma unroll
@@ -34,7 +38,7 @@ __global__ __launch_bounds__(512, 1) void k_mix(float* out, int steps) {
   float v[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) v[r] = (float)(lane + r);
-  const uint4* bp = lds + (wave & 3) * 1024 + lane;
+  const uint4* bp = lds + (wave & 3) * 512 + lane;
   auto mfma_phase = [&](int q) {
     half8 b[2][3];
     auto fetch = [&](int batch, half8 (&dst)[3]) {
@@ -67,38 +71,84 @@ __global__ __launch_bounds__(512, 1) void k_mix(float* out, int steps) {
 #pragma unroll
     for (int r = 0; r < NV % 16; ++r) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[r]) : "v"(acc[0][r]), "v"(acc[1][(r + 3) & 15]));
   };
+  uint4* ring = lds + 3072;                                  // 6 groups x 1088 slots behind the B-fragment area
+  const size_t wg_base = (size_t)blockIdx.x * 60 * 1088;     // this workgroup's 60 groups of the source tensor
+  auto dma = [&](int q) {
+    if (FEAT & 1) {
+      const unsigned dst = (unsigned)(size_t)(const __attribute__((address_space(3))) void*)(ring + (q % 6) * 1088);
+      const char* src = reinterpret_cast<const char*>(xin + wg_base + (size_t)(q % 60) * 1088);
+      for (int k = 0; k < 5; ++k) {
+        const int i = (wave & 3) + 4 * k;
+        if (i < 17) {
+          unsigned keep;
+          const unsigned d2 = dst + (unsigned)i * 1024u, voff = (unsigned)(i * 64 + lane) * 16u;
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                       : "=&s"(keep) : "s"(d2), "v"(voff), "s"(src) : "memory");
+        }
+      }
+    }
+  };
   for (int q = 0; q < steps; ++q) {
     if (role == 0) {
+      dma(q + 2);
       mfma_phase(q);
       valu_phase();
+      if (FEAT & 4) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(lds + 2048 + (wave & 3) * 256 + (k & 3) * 64 + (lane & 31)) + (lane >> 5) * 8) = uint2{__float_as_uint(v[k]), __float_as_uint(v[k + 8])};
+      }
+      if (FEAT & 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     } else {
+      if (FEAT & 4) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(ring + ((q + 3) % 6) * 1088 + k * 66 + (lane & 31)) + (lane >> 5) * 8);
+          v[k] += __uint_as_float(r.x);
+        }
+      }
       valu_phase();
+      if (FEAT & 2) {
+        uint4* o = yout + ((size_t)blockIdx.x * 60 + (q % 60)) * 1024 + (wave & 3) * 256 + lane;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k * 64] = uint4{__float_as_uint(v[k]), __float_as_uint(v[k + 4]), __float_as_uint(v[k + 8]), __float_as_uint(v[k + 12])};
+      }
       mfma_phase(q);
     }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   float sacc = 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) sacc += v[r] + acc[0][r] + acc[1][r];
   if (sacc == 12345.678f) out[tid] = sacc;
 }
 
-template <int NM, int NV>
+template <int NM, int NV, int FEAT = 0>
 static double run(const char* name, int steps) {
-  auto kern = k_mix<NM, NV>;
-  const int lds = 128 * 1024;
+  auto kern = k_mix<NM, NV, FEAT>;
+  const int lds = (3072 + 6 * 1088 + 64) * 16;      // 154,624 bytes: the real kernel's footprint
+  static uint4 *xin = nullptr, *yout = nullptr;
+  if (!xin) {
+    hipMalloc(&xin, (size_t)256 * 60 * 1088 * 16 + 4096);
+    hipMalloc(&yout, (size_t)256 * 60 * 1024 * 16);
+    hipMemset(xin, 0x3c, (size_t)256 * 60 * 1088 * 16);
+  }
   hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   float* out;
   hipMalloc(&out, 4096);
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, 0, out, steps);
-  hipDeviceSynchronize();
+  hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, 0, out, steps, xin, yout);
+  if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) {
+    printf("%s: launch failed\n", name);
+    return 0;
+  }
   double best = 1e30;
   for (int rep = 0; rep < 5; ++rep) {
     hipEventRecord(e0);
-    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, 0, out, steps);
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, 0, out, steps, xin, yout);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
@@ -106,7 +156,7 @@ static double run(const char* name, int steps) {
     if (ms / 20 < best) best = ms / 20;
   }
   const double us_per_k = best * 1e3 / steps * 1000.0;
-  printf("%-28s NM=%2d NV=%3d : %8.1f us per 1000 super-steps\n", name, NM, NV, us_per_k);
+  printf("%-34s NM=%2d NV=%3d FEAT=%d : %8.1f us per 1000 super-steps\n", name, NM, NV, FEAT, us_per_k);
   hipFree(out);
   return us_per_k;
 }
@@ -121,5 +171,10 @@ int main() {
   printf("per 64 output pixels and wave: F(2,3) %.2fx, F(2x2,3x3) %.2fx the direct form's time (matrix part alone: %.2fx)\n", w1 / d, w2 / d,
          m / d);
   (void)v;
+  // what the rest of the real kernel's super-step adds to the direct mix (one feature at a time, then all)
+  run<36, 112, 1>("direct + x ring by LDS-DMA", steps);
+  run<36, 112, 2>("direct + y stores", steps);
+  run<36, 112, 4>("direct + t writes / residual reads", steps);
+  run<36, 112, 7>("direct + all three", steps);
   return 0;
 }
