@@ -10,7 +10,7 @@
 #include <thread>
 #include <vector>
 
-#include "stereonet_node.h"
+#include "bin_data.h"
 
 namespace hobot {
 namespace stereonet {

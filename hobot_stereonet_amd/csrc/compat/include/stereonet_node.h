@@ -23,17 +23,11 @@
 #include "hbm_img_msgs/msg/hbm_msg1080_p.hpp"
 
 #include "dnn_node/dnn_node.h"
+#include "bin_data.h"
 #include "preprocess.h"
 
 namespace hobot {
 namespace stereonet {
-
-// JPEG of the left eye that travels with a request from FeedImg to PostProcess.
-struct BinDataType {
-  std::vector<uint8_t> jpeg;
-  int w = 1280;
-  int h = 720;
-};
 
 // Per-request context handed through DnnNode::Run.
 struct StereonetNodeOutput : public hobot::dnn_node::DnnNodeOutput {

@@ -150,6 +150,17 @@ def test_encoder_threads_assemble_the_sliced_stream(hostlib, w, h, threads, slic
     assert np.abs(np.asarray(img.convert("YCbCr"), np.float32)[..., 0] - fr[:h, :W]).mean() < 6.0
 
 
+def test_encoder_threads_under_thread_sanitizer():
+    """`make tsan`: JpegPool + SubmitSlicedJpeg built with -fsanitize=thread, three feeder threads x 20 frames x 1 / 4 / 11
+    slices on six encoder threads; every stream equals the sequential encoder's and ThreadSanitizer reports nothing
+    (a report makes the binary exit non-zero)."""
+    r = subprocess.run(["make", "-C", COMPAT, "-s", "tsan"], capture_output=True, text=True, timeout=600)
+    if r.returncode != 0 and ("cannot find -ltsan" in r.stderr or "libtsan" in r.stderr):
+        pytest.skip("ThreadSanitizer runtime not installed")
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    assert r.stdout.count("0 mismatching streams of 60") == 3 and "WARNING: ThreadSanitizer" not in r.stderr
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("publish", [1, 0])
 def test_node_level_throughput_is_recorded(hostlib, weights_blob, tmp_path, publish):
