@@ -104,6 +104,7 @@ def load_library(path: Optional[str] = None):
     lib.sn_dbg_ref_conv_f16.argtypes = [vp, fp, ip, ip, fp, fp, ip, ip, fp, fp]
     lib.sn_dbg_ref_conv_f16x3.argtypes = [vp, fp, ip, ip, fp, fp, ip, ip, fp, fp]
     lib.sn_dbg_ref_block_f16.argtypes = [vp, fp, ip, ip, fp, fp, fp, fp, ip, fp]
+    lib.sn_dbg_ref_tail_f16.argtypes = [vp, ip, fp, ip, ip, fp, fp, fp, fp, fp, C.c_float, fp, ip, C.c_float, ip, ip, ip, fp, i32p]
     lib.sn_dbg_read.argtypes = [vp, C.c_char_p, fp, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.sn_dbg_copy_limited.argtypes = [vp, vp, C.c_size_t, ip, vp]
     lib.sn_depth_from_raw.argtypes = [vp, ip, i32p, C.c_float, C.c_float, fp, fp, ip, vp]
@@ -111,7 +112,7 @@ def load_library(path: Optional[str] = None):
                  "sn_infer_sbs_nv12", "sn_preprocess_sbs_nv12_batch", "sn_submit", "sn_submit_nv12", "sn_wait", "sn_synchronize", "sn_set_profiling",
                  "sn_get_stage_ms", "sn_get_dominant_kernel", "sn_mgpu_shard", "sn_mgpu_create", "sn_mgpu_destroy",
                  "sn_mgpu_get_info", "sn_mgpu_get_handle", "sn_mgpu_infer_batch", "sn_mgpu_infer_batch_device",
-                 "sn_mgpu_submit_device", "sn_mgpu_wait", "sn_mgpu_ring_init", "sn_mgpu_ring_submit", "sn_mgpu_ring_wait", "sn_dbg_conv2d", "sn_dbg_down0", "sn_dbg_refin", "sn_dbg_conv3d", "sn_dbg_ref_conv_f16", "sn_dbg_ref_conv_f16x3", "sn_dbg_ref_block_f16", "sn_dbg_read", "sn_dbg_copy_limited", "sn_depth_from_raw"):
+                 "sn_mgpu_submit_device", "sn_mgpu_wait", "sn_mgpu_ring_init", "sn_mgpu_ring_submit", "sn_mgpu_ring_wait", "sn_dbg_conv2d", "sn_dbg_down0", "sn_dbg_refin", "sn_dbg_conv3d", "sn_dbg_ref_conv_f16", "sn_dbg_ref_conv_f16x3", "sn_dbg_ref_block_f16", "sn_dbg_ref_tail_f16", "sn_dbg_read", "sn_dbg_copy_limited", "sn_depth_from_raw"):
         getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
@@ -256,7 +257,12 @@ class StereoNetHIP:
         """Parse()'s dequantisation + depth (parser.cpp:84-86) on the GPU: int32 (H,W) or (n,H,W) -> depth in metres
         (float32, inf where raw == 0) [, disparity px]; bit-identical to the host Parse."""
         r = np.ascontiguousarray(raw, dtype=np.int32)
+        # sn_depth_from_raw moves n * H * W elements of the MODEL's size: anything else would run past these arrays
+        if r.ndim not in (2, 3) or r.shape[-2:] != (self.height, self.width):
+            raise StereoNetError(-1, "depth_from_raw", f"raw shape {r.shape} != ([n,] {self.height}, {self.width})")
         n = 1 if r.ndim == 2 else r.shape[0]
+        if n < 1 or n > self.max_batch:
+            raise StereoNetError(-1, "depth_from_raw", f"{n} maps, the engine was created for 1..{self.max_batch}")
         depth = np.empty(r.shape, np.float32)
         disp = np.empty(r.shape, np.float32) if want_disp else None
         self._check(self._lib.sn_depth_from_raw(self._h, n, r.ctypes.data, focal_px, baseline_mm, depth.ctypes.data,
@@ -374,6 +380,25 @@ class StereoNetHIP:
                     "sn_dbg_ref_block_f16")
         return out
 
+    def dbg_ref_tail_f16(self, x, w1, b1, w2, b2, head_w, head_b, low, ups, dnorm, h_out, w_out, form):
+        """Last residual block + refinement head on x float32 (n, 32, hk, wk); low (n, hk/ups, wk/ups); form 0 = streamed
+        block + k_head_final_f16, 1 = the tail form (one launch).  -> (disp float32, raw int32), each (n, h_out, w_out)."""
+        a = [np.ascontiguousarray(v, np.float32) for v in (x, w1, b1, w2, b2, head_w, low)]
+        n, _, hk, wk = a[0].shape
+        assert a[6].shape == (n, hk // ups, wk // ups)
+        disp = np.empty((n, h_out, w_out), np.float32)
+        raw = np.empty((n, h_out, w_out), np.int32)
+        self._check(self._lib.sn_dbg_ref_tail_f16(self._h, n, a[0].ctypes.data, hk, wk, a[1].ctypes.data, a[2].ctypes.data,
+                                                  a[3].ctypes.data, a[4].ctypes.data, a[5].ctypes.data, float(head_b),
+                                                  a[6].ctypes.data, ups, float(dnorm), h_out, w_out, form, disp.ctypes.data,
+                                                  raw.ctypes.data), "sn_dbg_ref_tail_f16")
+        return disp, raw
+
+    def stream_priority_high(self) -> bool:
+        """True when the engine's pipeline streams were created with the device's highest priority (SN_STREAM_PRIORITY=1,
+        or sn_mgpu_create with more than one device)."""
+        return bool(self.dbg_read("stream_prio")[0])
+
     def dbg_read(self, what: str) -> np.ndarray:
         n = C.c_size_t()
         self._check(self._lib.sn_dbg_read(self._h, what.encode(), None, 0, C.byref(n)), "sn_dbg_read")
@@ -452,6 +477,17 @@ class StereoNetMultiGPU:
     def _check(self, rc: int, where: str):
         if rc != 0:
             raise StereoNetError(rc, where, self._lib.sn_mgpu_last_error(self._m).decode() if self._m else "")
+
+    def engine_stream_priority_high(self, k: int = 0) -> bool:
+        """True when shard k's engine runs its pipeline on high-priority streams (sn_mgpu_create chooses that itself whenever
+        more than one device takes part: its gather runs beside the engines)."""
+        h = C.c_void_p()
+        self._check(self._lib.sn_mgpu_get_handle(self._m, k, C.byref(h)), "sn_mgpu_get_handle")
+        v, n = np.empty(1, np.float32), C.c_size_t()
+        rc = self._lib.sn_dbg_read(h, b"stream_prio", v.ctypes.data, 1, C.byref(n))
+        if rc != 0:
+            raise StereoNetError(rc, "sn_dbg_read(stream_prio)")
+        return bool(v[0])
 
     def infer(self, in6: np.ndarray):
         """int8 (n,6,H,W) host array -> (disp float32 (n,H,W), raw int32 (n,H,W)); the host is the gather root."""

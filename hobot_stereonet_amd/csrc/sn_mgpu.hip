@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "../../include/stereonet_hip.h"
+#include "sn_internal.h"
 
 namespace {
 
@@ -33,7 +34,7 @@ struct Rccl {
   void* lib = nullptr;
   int (*CommInitAll)(void** comms, int ndev, const int* devlist) = nullptr;
   int (*CommDestroy)(void* comm) = nullptr;
-  int (*CommAbort)(void* comm) = nullptr;      // optional: frees a communicator whose exchange can no longer complete
+  int (*CommAbort)(void* comm) = nullptr;      // frees a communicator whose exchange can no longer complete
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
   int (*Send)(const void* buf, size_t count, int dtype, int peer, void* comm, hipStream_t st) = nullptr;
@@ -52,7 +53,10 @@ struct Rccl {
     GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
     Send = reinterpret_cast<decltype(Send)>(sym("ncclSend"));
     Recv = reinterpret_cast<decltype(Recv)>(sym("ncclRecv"));
-    return CommInitAll && CommDestroy && GroupStart && GroupEnd && Send && Recv;
+    // ncclCommAbort is REQUIRED: it is the only way to release an exchange whose other half never arrives (the error path of
+    // sn_mgpu_submit_device); ncclCommDestroy on such a communicator may block on the outstanding operation.  A library
+    // without it does not carry the gather (peer copies do).
+    return CommInitAll && CommDestroy && CommAbort && GroupStart && GroupEnd && Send && Recv;
   }
 };
 constexpr int kNcclInt8 = 0;      // ncclInt8 / ncclChar (rccl.h): the maps travel as bytes
@@ -276,7 +280,10 @@ int sn_mgpu_create(const char* model_file, const sn_config* cfg, const int* devi
     sn_config ck = c;
     ck.device = w->dev;
     ck.max_batch = m->per_dev;
-    rc = sn_create(model_file, &ck, &w->h);
+    // more than one device: a gather runs beside the engines on this library's own exchange streams — the engines'
+    // pipeline streams go to their own (high-priority) hardware queues so that it cannot serialise with the towers
+    // (-30 % for the root otherwise); the caller does not have to know about SN_STREAM_PRIORITY
+    rc = sn_create_prio(model_file, &ck, ndev > 1 ? 1 : -1, &w->h);
     if (rc != SN_OK) {
       const char* d = sn_last_error(nullptr);
       m->err = "sn_create on device " + std::to_string(w->dev) + ": " + sn_strerror(rc) + (d && *d ? std::string(": ") + d : std::string());
@@ -416,7 +423,8 @@ int sn_mgpu_submit_device(sn_mgpu* m, int n, const int8_t* const* in_per_device,
       return SN_ERR_DEVICE;
     }
     if (m->gather == 2) {     // one grouped exchange: root posts a recv per peer, every peer one send per map kind
-      bool ok = waited && m->rccl.GroupStart() == 0;
+      const bool started = waited && m->rccl.GroupStart() == 0;
+      bool ok = started;
       for (int kind = 0; kind < 2 && ok; ++kind) {
         char* root_buf = reinterpret_cast<char*>(kind == 0 ? (void*)out_i32_root : (void*)out_disp_root);
         const void* mine = kind == 0 ? (const void*)raw : (const void*)disp;
@@ -431,7 +439,7 @@ int sn_mgpu_submit_device(sn_mgpu* m, int n, const int8_t* const* in_per_device,
           ok = m->rccl.Send(mine, (size_t)cnt * HW * 4, kNcclInt8, 0, w->comm, w->st) == 0;
         }
       }
-      ok = (m->rccl.GroupEnd() == 0) && ok;
+      if (started) ok = (m->rccl.GroupEnd() == 0) && ok;        // never an unpaired GroupEnd
       // second agreement, AFTER the exchange is enqueued: a rank that failed inside the group leaves its peers with an
       // unmatched send / recv on their exchange streams, which a later hipStreamSynchronize would wait on forever.  If any
       // rank failed, every rank aborts its communicator (that releases the enqueued half) and peer copies carry the
@@ -440,8 +448,7 @@ int sn_mgpu_submit_device(sn_mgpu* m, int n, const int8_t* const* in_per_device,
       const int all2 = m->ndev > 1 ? m->agree.arrive_and_wait(mine2) : mine2;
       if (all2 != SN_OK) {
         if (w->comm) {
-          if (m->rccl.CommAbort) m->rccl.CommAbort(w->comm);
-          else m->rccl.CommDestroy(w->comm);
+          m->rccl.CommAbort(w->comm);        // (Rccl::load refuses a library without it)
           w->comm = nullptr;
         }
         if (k == 0) m->gather = 1;

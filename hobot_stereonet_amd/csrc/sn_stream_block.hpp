@@ -62,17 +62,6 @@
 #define SN_STAMP_WG(k) do { } while (0)
 #endif
 
-#ifndef SN_T_WRITE_B64
-// 1 (default) = conv1 writes t as four 8-byte half slots per segment; 0 = half exchange (v_permlane32_swap) + two
-// conflict-free ds_write_b128.  The 16-byte form removes the t-write half of the kernel's LDS bank conflicts but its eight
-// extra VALU instructions per wave and step cost more than the conflicts did: 155.6 vs 152.8 us per dilation-1 block,
-// 163.3 vs 159.7 (dilation 2), 2760 vs 2776 pairs/s end to end (A/B on one box, round 4).
-#define SN_T_WRITE_B64 1
-#endif
-#ifndef SN_TAIL_EXP
-#define SN_TAIL_EXP 0      // development: 1 = no last stage, 2 = no head MFMAs / P writes, 3 = no head epilogue at all (wrong results)
-#endif
-
 namespace sn {
 
 // HEAD_ = true: the LAST block of the tower with the refinement head folded in (see "Tail form" below).
@@ -391,7 +380,7 @@ __global__ __launch_bounds__(128 * NWR, NWR / 2) __attribute__((amdgpu_waves_per
         // Runs BEFORE this step's DMA group is issued: its two stores are then older than the group and the counted
         // wait below needs no extra term; the upsample taps come through scalar loads (lgkmcnt, not vmcnt).
         fin.step(q, 3, f0, f1, sc.hsub);
-        if (fin.live && fin.j >= 1 && SN_TAIL_EXP != 1) {
+        if (fin.live && fin.j >= 1) {
           if (fin.j == 1) {
             int py;
             decode_sp(fin.sp, fin_img, py, fin_x0);
@@ -436,7 +425,7 @@ __global__ __launch_bounds__(128 * NWR, NWR / 2) __attribute__((amdgpu_waves_per
         // the two low-resolution row windows of the NEXT super-step's last stage, by 4-byte LDS-DMA: issued before this
         // step's x group, so the counted wait at the end of the step (everything but the youngest group) covers them
         fin2.step(q, 2, f0, f1, sc.hsub);
-        if (fin2.live && fin2.j >= 1 && SN_TAIL_EXP != 1) {
+        if (fin2.live && fin2.j >= 1) {
           if (fin2.j == 1) {
             int py;
             decode_sp(fin2.sp, fin2_img, py, fin2_x0);
@@ -499,21 +488,12 @@ __global__ __launch_bounds__(128 * NWR, NWR / 2) __attribute__((amdgpu_waves_per
                 const unsigned u = lrelu_pack2(acc[s][4 * qd + 2 * hp], acc[s][4 * qd + 2 * hp + 1]);
                 pk[qd][hp] = (decltype(is_interior)::value || inside) ? u : 0u;
               }
-#if SN_T_WRITE_B64
+            // four 8-byte half slots per segment at a 16-byte stride.  (Whole 16-byte slots after a v_permlane32_swap half
+            // exchange remove this half of the kernel's LDS bank conflicts, but the eight extra VALU instructions per wave
+            // and step cost more than the conflicts did: 155.6 vs 152.8 us per dilation-1 block, round 4)
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd)
               *reinterpret_cast<uint2*>(reinterpret_cast<char*>(tw + qd * T::TW + s * 32) + gh * 8) = uint2{pk[qd][0], pk[qd][1]};
-#else
-            // half exchange between blocks (k, k + 2) as in conv2's store path: lane (j, gh) ends up with the whole 16-byte
-            // slots of blocks 2 gh and 2 gh + 1 -> two conflict-free ds_write_b128 instead of four 8-byte writes at a
-            // 16-byte stride, which use half of the banks (SQ_LDS_BANK_CONFLICT: 11-14 % of the LDS cycles of round 3)
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-              const auto r0 = __builtin_amdgcn_permlane32_swap(pk[k][0], pk[k + 2][0], false, false);
-              const auto r1 = __builtin_amdgcn_permlane32_swap(pk[k][1], pk[k + 2][1], false, false);
-              tw[(2 * gh + k) * T::TW + s * 32] = uint4{r0[0], r1[0], r0[1], r1[1]};
-            }
-#endif
           }
         };
         if (interior) write_t(std::true_type{});
@@ -558,8 +538,6 @@ __global__ __launch_bounds__(128 * NWR, NWR / 2) __attribute__((amdgpu_waves_per
         for (int qd = 0; qd < 4; ++qd) rres[s][qd] = uint2{0u, 0u};
     }
     int ep_img = 0, ep_py = 0, ep_x0 = 0;
-    float one = 1.0f;
-    asm volatile("" : "+v"(one));          // opaque: keeps the multiply so that hipcc selects v_fma_mix_f32 for the residual
     // after the half exchange below lane (j, gh) owns the whole 16-byte slots of channel blocks 2 gh and 2 gh + 1
     const unsigned lane_o = (unsigned)(cseg0 * 32 + j) * 16u + (unsigned)(2 * gh) * plane_b;
     f32x16 acc[T::SPW];
@@ -582,8 +560,7 @@ __global__ __launch_bounds__(128 * NWR, NWR / 2) __attribute__((amdgpu_waves_per
         if (ep.j == 1) decode_sp(ep.sp, ep_img, ep_py, ep_x0);
         const int sub = ep.v0 - HS - 2 + R * (ep.j - 1) + rowW;
         const int row = sub * DIL + ep_py;
-        if constexpr (HEAD && SN_TAIL_EXP == 3) {
-        } else if constexpr (HEAD) {
+        if constexpr (HEAD) {
           // ---- tail form: y (rounded to fp16 exactly as the tensor would have held it, zero outside the image) goes
           // straight into the head's MFMAs as the B operand; P[tap][pixel] -> the P ring; nothing is stored ----
           const bool row_ok = row >= 0 && row < g.H;
@@ -617,10 +594,6 @@ __global__ __launch_bounds__(128 * NWR, NWR / 2) __attribute__((amdgpu_waves_per
               a0[r] = 0.f;
               a1[r] = 0.f;
             }
-            if (SN_TAIL_EXP == 2) {
-              if (pk[0][0] == 0x12345678u) pring[lane] = (float)(pk[0][1] + pk[1][0] + pk[1][1] + pk[2][0] + pk[2][1] + pk[3][0] + pk[3][1]);
-              continue;
-            }
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
               const auto r0 = __builtin_amdgcn_permlane32_swap(pk[2 * kk][0], pk[2 * kk + 1][0], false, false);
@@ -647,11 +620,7 @@ __global__ __launch_bounds__(128 * NWR, NWR / 2) __attribute__((amdgpu_waves_per
             unsigned pk[4][2];               // [channel block][channels 4 gh + {0,1} | {2,3}] as packed fp16 pairs
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
-#if defined(SN_STREAM_EXP) && SN_STREAM_EXP == 2
-              const half4 rv = half4{(_Float16)one, (_Float16)one, (_Float16)one, (_Float16)one};      // experiment: no residual read
-#else
               const half4 rv = *reinterpret_cast<const half4*>(reinterpret_cast<const char*>(xrow + qd * T::XW + s * 32) + gh * 8);
-#endif
               const uint2 rw2 = *reinterpret_cast<const uint2*>(&rv);
               pk[qd][0] = lrelu_pack2(res_add<0>(rw2.x, acc[s][4 * qd]), res_add<1>(rw2.x, acc[s][4 * qd + 1]));
               pk[qd][1] = lrelu_pack2(res_add<0>(rw2.y, acc[s][4 * qd + 2]), res_add<1>(rw2.y, acc[s][4 * qd + 3]));
@@ -668,11 +637,7 @@ __global__ __launch_bounds__(128 * NWR, NWR / 2) __attribute__((amdgpu_waves_per
               sl[k] = uint4{r0[0], r1[0], r0[1], r1[1]};       // [own channels 0-3 | partner's 4-7] of block 2 gh + k
             }
             const int c = (cseg0 + s) * 32 + j;
-#if defined(SN_STREAM_EXP) && SN_STREAM_EXP == 1
-            if (c < T::OW && ep_x0 + c < g.W && sl[0].x == 0x12345678u) {      // experiment: (almost) never store
-#else
             if (c < T::OW && ep_x0 + c < g.W) {
-#endif
 #pragma unroll
               for (int k = 0; k < 2; ++k) {
                 char* o = reinterpret_cast<char*>(yout) + (ob + (unsigned)k * plane_b + (unsigned)s * 512u);     // uniform

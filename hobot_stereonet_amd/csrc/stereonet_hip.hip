@@ -19,7 +19,12 @@
 #include <unordered_map>
 #include <vector>
 
+#ifndef SN_DIAGNOSTICS
+#define SN_DIAGNOSTICS 0      // 1: the precision-ablation switches of scripts/lowres_ablation.py (never in the shipping library)
+#endif
+
 #include "../../include/stereonet_hip.h"
+#include "sn_internal.h"
 #include "sn_kernels.hpp"
 
 namespace {
@@ -160,11 +165,16 @@ struct sn_handle {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_tow_join[kMaxTowerStreams] = {}, ev_piece[kMaxPieceEvents] = {};
   bool overlap = true;
   int tower_streams = kMaxTowerStreams;
-  unsigned ablate_x = 0;     // SN_ABLATE_X mask (diagnostic): layers whose input tensor gets its lo slots zeroed
+#if SN_DIAGNOSTICS
+  unsigned ablate_x = 0;     // SN_ABLATE_X mask (diagnostic build only): layers whose input tensor gets its lo slots zeroed
+#else
+  static constexpr unsigned ablate_x = 0;      // the shipping library has no ablation code: every test of it folds away
+#endif
   bool tail_fuse = true;     // the streamed last block carries the head (tail form); SN_TAIL_FUSE=0: block + k_head_final_f16
   int fuse_mode = 4;         // SN_FUSE: 4 = streaming fused blocks (default), 0 = two launches per block
   unsigned* dump = nullptr;  // 2 KB device scratch: where lanes without an output pixel store (fused head)
   bool use_graphs = true;    // hipGraph replay for the async single-pair path (SN_NO_GRAPH disables)
+  bool stream_prio = false;  // the pipeline streams were created with the device's highest priority (sn_create_prio)
   ConvLayer down[kNDown], fres[kNFeatRes][2], fout, agg[kNAgg];
   Down0F16 down0;
   HeadLayer aout;
@@ -423,7 +433,9 @@ hipError_t launch_conv_x3s(hipStream_t st, const ConvLayer& L, const Loader& ld,
   return hipGetLastError();
 }
 
-// ---- precision ablation of the low-resolution branch (diagnostic; scripts/lowres_ablation.py) ------------------------
+// ---- precision ablation of the low-resolution branch (scripts/lowres_ablation.py) -------------------------------------
+// DIAGNOSTIC BUILD ONLY (-DSN_DIAGNOSTICS=1: `python -m hobot_stereonet_amd.build --diag` -> libstereonet_hip_diag.so, which the
+// script loads through STEREONET_HIP_LIB); the shipping library ignores both variables.
 // The split-operand layers evaluate x*w as xh*wh + (xh*wl + xl*wh) / 2048 (three fp16 MFMAs).  What a cheaper form of a
 // layer would compute is reproduced exactly with zeroed operands (an MFMA with a zero operand adds exact zeros):
 //   SN_ABLATE_W=<layers>  the layer's weights rounded to fp16: its lo A-fragments are uploaded as zeros  (drops xh*wl)
@@ -433,6 +445,10 @@ hipError_t launch_conv_x3s(hipStream_t st, const ConvLayer& L, const Loader& ld,
 //                         block's residual input, so that entry is an upper bound)
 // <layers>: comma-separated names out of down1..down3, f0..f12 (the thirteen 3x3 feature convs), agg0..agg3, or "all".
 enum { kAblDown = 0, kAblFeat = 3, kAblAgg = 16, kAblCount = 20 };
+#if !SN_DIAGNOSTICS
+inline unsigned ablate_mask(const char*) { return 0u; }
+inline hipError_t zero_lo_slots(hipStream_t, float*, int, size_t) { return hipSuccess; }
+#else
 unsigned ablate_mask(const char* var) {
   const char* e = getenv(var);
   if (!e || !*e) return 0u;
@@ -466,6 +482,7 @@ inline hipError_t zero_lo_slots(hipStream_t st, float* tensor, int nimg, size_t 
   hipLaunchKernelGGL(k_zero_lo_slots, dim3(1024), dim3(256), 0, st, reinterpret_cast<uint4*>(tensor), hw, (size_t)nimg * 4);
   return hipGetLastError();
 }
+#endif      // SN_DIAGNOSTICS
 
 // SN_AGG_DMA=0: aggregation layers on the plain split-slot volumes (k_conv_x3s) instead of the zero-bordered ones
 bool agg_dma_enabled() {
@@ -1537,6 +1554,12 @@ static int create_fail(int code, const char* what) {
 const char* sn_last_error(const sn_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
 int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
+  return sn_create_prio(model_file, cfg, -1, out);
+}
+
+// stream_prio: 1 = pipeline streams at the device's highest priority, 0 = default priority, -1 = SN_STREAM_PRIORITY decides
+// (unset: default).  An explicit SN_STREAM_PRIORITY always wins, so the A/B switch stays usable for every caller.
+int sn_create_prio(const char* model_file, const sn_config* cfg, int stream_prio, sn_handle** out) {
   if (!model_file || !out) return SN_ERR_ARG;
   *out = nullptr;
   FILE* f = fopen(model_file, "rb");
@@ -1670,16 +1693,20 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
     if (hipEventCreate(&e) != hipSuccess) return fail(SN_ERR_DEVICE);
   // (Disjoint CU sets for the pipeline streams through hipExtStreamCreateWithCUMask were measured and dropped:
   // 1940 pairs/s shared vs 1700 / 1680 / 1510 with 64 / 96 / 128 CUs split off for the low-resolution branch.)
-  // SN_STREAM_PRIORITY=1: the pipeline streams are created with the device's highest stream priority.  HIP multiplexes
-  // streams onto GPU_MAX_HW_QUEUES (4) hardware queues PER PRIORITY LEVEL, and two streams that share a hardware queue
-  // run in order: a caller's other streams (a communication library's receive kernels on the gather root, copy streams)
-  // can land on the tower's queue and serialise with it.  High-priority streams draw from their own queues.
+  // High-priority pipeline streams (stream_prio = 1: sn_mgpu_create for its own exchange streams when more than one
+  // device takes part; SN_STREAM_PRIORITY=1 / 0 forces it on / off for any caller).  HIP multiplexes streams onto
+  // GPU_MAX_HW_QUEUES (4) hardware queues PER PRIORITY LEVEL, and two streams that share a hardware queue run in order: a
+  // caller's other streams (a communication library's receive kernels on the gather root, copy streams) can land on the
+  // tower's queue and serialise with it.  High-priority streams draw from their own queues.  Not the default for a
+  // single engine: the host-to-host paths measured 30 % slower with it.
   int prio = 0;
   {
     int least = 0, greatest = 0;
     const char* e = getenv("SN_STREAM_PRIORITY");
-    if (e && atoi(e) == 1 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess) prio = greatest;
+    const bool want = (e && *e) ? atoi(e) == 1 : stream_prio == 1;
+    if (want && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess) prio = greatest;
   }
+  h->stream_prio = prio != 0;
   auto mk_stream = [&](hipStream_t* st) {
     return prio != 0 ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio) : hipStreamCreateWithFlags(st, hipStreamNonBlocking);
   };
@@ -1702,7 +1729,9 @@ int sn_create(const char* model_file, const sn_config* cfg, sn_handle** out) {
   BlobWalker bw{blob.data()};
   const bool low_x3 = h->precision != SN_PREC_FP32;     // fp16 modes: low-resolution layers on split fp16 operands
   const unsigned abl_w = ablate_mask("SN_ABLATE_W");
+#if SN_DIAGNOSTICS
   h->ablate_x = ablate_mask("SN_ABLATE_X");
+#endif
   int feat_idx = 0;
   for (int i = 0; i < kNDown; ++i) {
     const HostLayer hl_ = bw.next(kC, i == 0 ? 3 : kC, 25);
@@ -2430,6 +2459,7 @@ int sn_dbg_conv3d(sn_handle* h, const float* in, int d, int h_px, int w, const f
         return wt[(((size_t)co * kC + (c & 31)) * 3 + (c >> 5)) * 9 + tap];
       }, &L)))
     return rc;
+  ds.track(L.wx3);        // allocated by upload_x3 just now (the track above saw a null pointer)
   const size_t plane = (size_t)h_px * w, n = (size_t)kC * d * plane;
   // caller layout [ci][d][h][w] (PyTorch) <-> device layout [d][ci][h][w]
   std::vector<float> tmp(n);
@@ -2685,6 +2715,73 @@ int sn_dbg_ref_block_f16(sn_handle* h, const float* in, int h_px, int w, const f
   return SN_OK;
 }
 
+int sn_dbg_ref_tail_f16(sn_handle* h, int n, const float* in, int hk, int wk, const float* w1, const float* b1, const float* w2,
+                        const float* b2, const float* head_w, float head_b, const float* low, int ups, float dnorm, int h_out,
+                        int w_out, int form, float* out_disp, int32_t* out_raw) {
+  DevScope ds;
+  if (!h || !in || !w1 || !b1 || !w2 || !b2 || !head_w || !low || !out_disp || !out_raw) return SN_ERR_ARG;
+  if (n <= 0 || hk <= 0 || wk <= 0 || h_out <= 0 || w_out <= 0 || h_out > hk || w_out > wk || (ups != 16 && ups != 2) ||
+      hk % ups || wk % ups || (form != 0 && form != 1) || !(dnorm > 0.f))
+    return SN_ERR_ARG;
+  if (h->precision != SN_PREC_F16) {
+    set_err(h, "sn_dbg_ref_tail_f16 needs an engine created with SN_PREC_F16");
+    return SN_ERR_ARG;
+  }
+  int rc = check_device(h);
+  if (rc) return rc;
+  const RefGeom g = make_ref_geom(hk, wk);
+  const size_t per = ref16_slots(g, 1), slots = ref16_slots(g, n);
+  if ((slots + ref_slack(g) + ref_front(g)) * 16 >= ((size_t)1 << 32)) return SN_ERR_ARG;      // 32-bit byte offsets inside a tensor
+  std::vector<_Float16> hin(slots * 8, (_Float16)0.f);
+  for (int i = 0; i < n; ++i)
+    for (int c = 0; c < kC; ++c)
+      for (int y = 0; y < hk; ++y) {
+        const float* src = in + (((size_t)i * kC + c) * hk + y) * wk;
+        _Float16* dst = &hin[(i * per + (((size_t)(c >> 3)) * g.Hs + y + kRefPad) * g.Ws + kRefPad) * 8 + (c & 7)];
+        for (int x = 0; x < wk; ++x) dst[(size_t)x * 8] = (_Float16)src[x];
+      }
+  RefLayerF16 L1, L2;
+  HeadLayer hd;
+  if ((rc = upload_ref_f16(h, HostLayer{w1, b1, kC, kC, 9}, &L1))) return rc;
+  ds.track(L1.bias); ds.track(L1.wfrag);
+  if ((rc = upload_ref_f16(h, HostLayer{w2, b2, kC, kC, 9}, &L2))) return rc;
+  ds.track(L2.bias); ds.track(L2.wfrag);
+  if ((rc = upload_head(h, HostLayer{head_w, &head_b, 1, kC, 9}, &hd))) return rc;
+  ds.track(hd.w);
+  uint4 *da = nullptr, *db = nullptr, *da_raw = nullptr, *db_raw = nullptr;
+  HIP_TRY(h, alloc_ref16(g, slots + ref_slack(g), &da_raw, &da));
+  ds.track(da_raw);
+  HIP_TRY(h, alloc_ref16(g, slots + ref_slack(g), &db_raw, &db));
+  ds.track(db_raw);
+  HIP_TRY(h, hipMemcpy(da, hin.data(), slots * 16, hipMemcpyHostToDevice));
+  const int sh = hk / ups, sw = wk / ups;
+  const size_t nlow = (size_t)n * sh * sw, nout = (size_t)n * h_out * w_out;
+  float *dlow = nullptr, *dd = nullptr;
+  int32_t* dr = nullptr;
+  HIP_TRY(h, dalloc(&dlow, nlow));
+  ds.track(dlow);
+  HIP_TRY(h, dalloc(&dd, nout));
+  ds.track(dd);
+  HIP_TRY(h, dalloc(&dr, nout));
+  ds.track(dr);
+  HIP_TRY(h, hipMemcpy(dlow, low, nlow * 4, hipMemcpyHostToDevice));
+  HIP_TRY(h, memset_now(dd, 0xff, nout * 4));        // NaN / -1: a pixel the kernel does not write shows up
+  HIP_TRY(h, memset_now(dr, 0xff, nout * 4));
+  const float inv_q = (float)(1.0 / (kWireFactor * (double)kOutScale));
+  const UpScale us{1.0f / (float)ups, (float)ups};
+  if (form == 1) {
+    StreamHeadArgs ha{hd.w, dlow, dd, dr, hd.bias, dnorm, inv_q, sh, sw, h_out, w_out, us};
+    HIP_TRY(h, ref_block_stream_tail(h->stream, L1, L2, g, h->num_cu, da, n, h->dump, ha));
+  } else {
+    HIP_TRY(h, ref_block_stream(h->stream, L1, L2, g, h->num_cu, 1, da, db, n, h->dump));
+    HIP_TRY(h, launch_head_final_f16(h->stream, false, db, 0, g, hd.w, hd.bias, dlow, sh, sw, h_out, w_out, dnorm, inv_q, us, dd, dr, n));
+  }
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, hipMemcpy(out_disp, dd, nout * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(h, hipMemcpy(out_raw, dr, nout * 4, hipMemcpyDeviceToHost));
+  return SN_OK;
+}
+
 // Parse's arithmetic per element (parser.cpp:84-86): the product f * B is a float, everything after it is double
 __global__ __launch_bounds__(256) void k_depth_from_raw(const int32_t* __restrict__ raw, size_t n, float scale, float fB,
                                                         float* __restrict__ depth, float* __restrict__ disp) {
@@ -2752,6 +2849,11 @@ int sn_dbg_read(sn_handle* h, const char* what, float* dst, size_t cap, size_t* 
   const size_t hw = (size_t)h->hl * h->wl;
   const float* src = nullptr;
   size_t cnt = 0;
+  if (!strcmp(what, "stream_prio")) {      // host state: 1 = the pipeline streams were created with the highest priority
+    *n = 1;
+    if (dst && cap >= 1) dst[0] = h->stream_prio ? 1.f : 0.f;
+    return (dst && cap < 1) ? SN_ERR_ARG : SN_OK;
+  }
   if (!strcmp(what, "feat_l")) { src = h->ws.feat; cnt = kC * hw; }
   else if (!strcmp(what, "feat_r")) { src = h->ws.feat + kC * hw; cnt = kC * hw; }
   else if (!strcmp(what, "cost")) { src = h->ws.cost; cnt = h->Dl * hw; }

@@ -59,7 +59,15 @@ class AsyncGather:
     def __init__(self, local: torch.Tensor, dst: int = 0, bufs: Optional[List[torch.Tensor]] = None):
         """bufs: rank `dst`'s receive list (world tensors shaped like `local`), allocated ONCE by a caller that gathers
         every step (alloc_root_buffers) — world x 236 MB at the metric's shard size is not something to allocate per
-        step; None allocates a fresh list (one-shot callers)."""
+        step; None allocates a fresh list (one-shot callers).
+
+        Aliasing contract of `bufs`: wait() returns the caller's OWN list, so the result of one gather is overwritten by
+        the next gather into the same list — nothing orders that write behind consumers of the previous result.  A caller
+        that keeps results across steps gives every gather in flight its own list (bench.py: one per buffer set) and is
+        done with a list's contents before it starts the next gather into it.
+        Staged mode (gloo with device tensors) gathers HOST copies: device-resident `bufs` cannot receive them, so passing
+        them raises instead of being dropped silently; host-resident `bufs` (pinned or not) are used as the receive list
+        and wait() returns fresh device copies of them."""
         world, rank = dist.get_world_size(), dist.get_rank()
         self.device = local.device
         self.staged = local.is_cuda and dist.get_backend() == "gloo"
@@ -68,9 +76,10 @@ class AsyncGather:
             send = send.cpu()                 # waits for the producing stream
         if rank != dst:
             self.bufs = None
-        elif bufs is not None and not self.staged:
+        elif bufs is not None:
             if len(bufs) != world or any(b.shape != send.shape or b.dtype != send.dtype or b.device != send.device for b in bufs):
-                raise ValueError("preallocated gather buffers do not match the shard")
+                raise ValueError("preallocated gather buffers do not match the shard" +
+                                 (" (staged gloo gather of device tensors: the receive list must live in host memory)" if self.staged else ""))
             self.bufs = bufs
         else:
             self.bufs = [torch.empty_like(send) for _ in range(world)]
@@ -78,10 +87,13 @@ class AsyncGather:
 
     @staticmethod
     def alloc_root_buffers(local: torch.Tensor, dst: int = 0) -> Optional[List[torch.Tensor]]:
-        """The receive list of one gather on rank `dst` (None on the other ranks)."""
+        """The receive list of one gather on rank `dst` (None on the other ranks): on the shard's device, or in host
+        memory when the gather will be staged (gloo with device tensors)."""
         if dist.get_rank() != dst:
             return None
-        return [torch.empty_like(local) for _ in range(dist.get_world_size())]
+        staged = local.is_cuda and dist.get_backend() == "gloo"
+        dev = torch.device("cpu") if staged else local.device
+        return [torch.empty(local.shape, dtype=local.dtype, device=dev) for _ in range(dist.get_world_size())]
 
     def wait(self):
         if self.work is not None:

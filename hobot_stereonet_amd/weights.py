@@ -31,9 +31,16 @@ MAGIC = b"SNW1"
 HEADER_BYTES = 80
 
 
-def synthetic(seed: int = 0, levels: int = 1) -> np.ndarray:
+def synthetic(seed: int = 0, levels: int = 1, head_gain: float = 1.0, act_scale: float = 1.0) -> np.ndarray:
     """Seeded random weights, flat float32 blob in canonical order.  The first spec.param_count() values do not
-    depend on `levels` (a multi blob starts with the single blob of the same seed)."""
+    depend on `levels` (a multi blob starts with the single blob of the same seed).
+
+    head_gain / act_scale span the envelope in which the precision modes are characterised (scripts/epe_sensitivity.py,
+    profiles/r05_epe_sensitivity.txt): head_gain multiplies the refinement heads (`ref*.out`, weights and bias), i.e. the
+    residual D * r every refinement level adds — 1 gives ~0.7 px mean |D r| at D = 192, 8 gives ~6 px; act_scale multiplies
+    the first feature layer (`feat.down0`), which scales every activation of the low-resolution branch and with it the
+    matching costs: the soft-argmin goes from flat (0.5) to near one-hot (2).  Both default to 1: the blob every other
+    test and the bench use."""
     rng = np.random.default_rng(seed)
     parts = []
     he = lambda fan_in: np.sqrt(2.0 / (1.0 + spec.LRELU_SLOPE ** 2) / fan_in)
@@ -49,6 +56,10 @@ def synthetic(seed: int = 0, levels: int = 1) -> np.ndarray:
             bias_std = 0.0005
         w = rng.standard_normal(l.w_numel).astype(np.float32) * np.float32(std)
         b = (rng.standard_normal(l.b_numel) * bias_std).astype(np.float32)
+        gain = head_gain if (l.name.startswith("ref") and l.name.endswith(".out")) else act_scale if l.name == "feat.down0" else 1.0
+        if gain != 1.0:
+            w = w * np.float32(gain)
+            b = b * np.float32(gain)
         parts.append(w)
         parts.append(b)
     blob = np.concatenate(parts).astype(np.float32)

@@ -248,6 +248,14 @@ int sn_dbg_ref_conv_f16x3(sn_handle *h, const float *in, int h_px, int w, const 
  * kernel the pipeline runs by default (every dilation). */
 int sn_dbg_ref_block_f16(sn_handle *h, const float *in, int h_px, int w, const float *w1, const float *b1,
                          const float *w2, const float *b2, int dil, float *out);
+/* The LAST residual block of the fp16 tower followed by the refinement head (conv 3x3 32 -> 1, disp = relu(up + D r), wire
+ * quantisation) on n images: fp32 host tensors in [n][32][hk][wk] (the level's padded activation, rounded to fp16 by the hook),
+ * low [n][hk / ups][wk / ups] (the map the level starts from; ups = 16: soft-argmin map, 2: the level below), head_w [32][9].
+ * form 0 = streamed block + k_head_final_f16 (two launches), 1 = the tail form the pipeline runs (one launch, y never
+ * written); out_disp / out_raw [n][h_out][w_out], h_out <= hk, w_out <= wk.  The two forms must agree bit for bit. */
+int sn_dbg_ref_tail_f16(sn_handle *h, int n, const float *in, int hk, int wk, const float *w1, const float *b1,
+                        const float *w2, const float *b2, const float *head_w, float head_b, const float *low, int ups,
+                        float dnorm, int h_out, int w_out, int form, float *out_disp, int32_t *out_raw);
 /* intermediates of the most recent batch-1 inference: "feat_l" / "feat_r" [32][hl][wl],
  * "cost" [Dl][hl][wl], "disp_low" [hl][wl], and for a hierarchical model "level1" .. "level3" (the map of that
  * refinement level, [Hp/2^k][Wp/2^k]); returns the element count in *n (dst may be NULL to query). */

@@ -21,7 +21,12 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 os.environ["SN_AGG_DMA"] = "0"          # plain split-slot layouts throughout (bit-identical to the zero-bordered ones), so
 os.environ["SN_DOWN_DMA"] = "0"         # that every row of the table runs the same kernels
 import oracle_py  # noqa: E402
-from hobot_stereonet_amd import api, synth, weights  # noqa: E402
+from hobot_stereonet_amd import api, build as snbuild, synth, weights  # noqa: E402
+
+# the ablation switches exist in the diagnostic build only (-DSN_DIAGNOSTICS=1), never in the shipping library
+if not os.path.exists(snbuild.LIB_DIAG) or os.path.getmtime(snbuild.LIB_DIAG) < os.path.getmtime(snbuild.LIB):
+    snbuild.build_diag()
+os.environ["STEREONET_HIP_LIB"] = snbuild.LIB_DIAG
 
 LAYERS = ["down1", "down2", "down3"] + [f"f{i}" for i in range(13)] + [f"agg{i}" for i in range(4)]
 quick = "--quick" in sys.argv

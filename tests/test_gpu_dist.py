@@ -14,8 +14,11 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 BENCH = os.path.join(ROOT, "bench.py")
 
 
-def _run(extra, timeout=1200):
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+def _run(extra, timeout=1200, env=None, drop=()):
+    skip = ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT") + tuple(drop)
+    base = {k: v for k, v in os.environ.items() if k not in skip}
+    base.update(env or {})
+    env = base
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     r = subprocess.run([sys.executable, BENCH] + extra, capture_output=True, text=True, cwd=ROOT, timeout=timeout, env=env)
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
@@ -102,6 +105,28 @@ def test_stream_mode_two_ranks_every_rank_verifies():
     assert r.returncode == 0, r.stderr[-3000:]
     d = lines[0]
     assert d["n_gpus"] == 2 and d["verified"] is True and "all 2 ranks" in d["verification"]
+
+
+@pytest.mark.gpu
+def test_multi_rank_stream_mode_runs_on_default_priority_streams():
+    """bench.py raises the engine's stream priority only where a gather runs beside it.  The sustained-stream mode has none
+    (ranks stream independently), and high-priority pipeline streams cost the host-to-host path 30 %: two
+    ranks on one GPU must report default-priority streams and the rate they reach with the variable forced off; the gather
+    mode reports high-priority streams."""
+    base = ["--gpus", "2", "--dist-backend", "gloo", "--device-map", "0,0", "--batch", "4", "--no-cpu-baseline"]
+    vals = {}
+    for tag, env in (("unset", {}), ("forced_off", {"SN_STREAM_PRIORITY": "0"})):
+        r, lines = _run(base + ["--config", "c5", "--stream", "2"], env=env, drop=("SN_STREAM_PRIORITY",))
+        assert r.returncode == 0, r.stderr[-3000:]
+        d = lines[0]
+        assert d["n_gpus"] == 2 and d["verified"] is True
+        assert d["config"]["stream_priority_high"] is False, tag
+        vals[tag] = d["value"]
+    print(f"two ranks on one GPU, stream mode: {vals}")
+    assert abs(vals["unset"] - vals["forced_off"]) < 0.10 * vals["forced_off"], vals
+    r, lines = _run(base + ["--steps", "2", "--warmup", "1", "--no-end-to-end"], drop=("SN_STREAM_PRIORITY",))
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert lines[0]["config"]["stream_priority_high"] is True
 
 
 @pytest.mark.gpu

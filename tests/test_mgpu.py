@@ -132,6 +132,9 @@ def test_two_shards_on_one_device_through_the_worker_threads(model_factory, monk
         disp_y, raw_y = eng.infer(ys)
     with api.StereoNetMultiGPU(model_factory(w, h, d), devices=[0, 0], max_batch=n, precision=api.PREC_F16) as m:
         assert m.ndev == 2 and m.per_device_batch == 3 and m.gather_kind == 1      # duplicates: peer copies, not RCCL
+        # more than one shard: the library itself puts the engines' pipelines on high-priority streams (its gather runs
+        # beside them); the caller does not have to know about SN_STREAM_PRIORITY
+        assert m.engine_stream_priority_high(0) and m.engine_stream_priority_high(1)
         disp, raw = m.infer(xs)                                                    # host form
         assert (raw == raw_x).all() and (disp == disp_x).all()
         dev = torch.device("cuda", 0)
@@ -161,6 +164,25 @@ def test_two_shards_on_one_device_through_the_worker_threads(model_factory, monk
             m.infer_device(n, [tx.data_ptr(), 0], out[0][0].data_ptr(), out[0][1].data_ptr())
         m.infer_device(n, ptrs(ty), out[0][0].data_ptr(), out[0][1].data_ptr())    # and the object still works
         assert (out[0][0].cpu().numpy() == raw_y).all()
+
+
+@pytest.mark.gpu
+def test_stream_priority_is_chosen_by_the_library(model_factory, monkeypatch):
+    """One engine / one shard: default priority (the host-to-host paths are 30 % slower on high-priority streams, DESIGN.md
+    §7); SN_STREAM_PRIORITY=1 / 0 force it either way, also against sn_mgpu_create's own choice."""
+    monkeypatch.delenv("SN_STREAM_PRIORITY", raising=False)
+    model = model_factory(96, 64, 48)
+    with api.StereoNetHIP(model) as eng:
+        assert eng.stream_priority_high() is False
+    with api.StereoNetMultiGPU(model, devices=[0], max_batch=1) as m:
+        assert m.engine_stream_priority_high(0) is False
+    monkeypatch.setenv("SN_STREAM_PRIORITY", "1")
+    with api.StereoNetHIP(model) as eng:
+        assert eng.stream_priority_high() is True
+    monkeypatch.setenv("SN_STREAM_PRIORITY", "0")
+    monkeypatch.setenv("SN_MGPU_ALLOW_DUP", "1")
+    with api.StereoNetMultiGPU(model, devices=[0, 0], max_batch=2) as m:
+        assert m.engine_stream_priority_high(0) is False and m.engine_stream_priority_high(1) is False
 
 
 @pytest.mark.gpu
