@@ -99,6 +99,9 @@ def load_library(path: Optional[str] = None):
     lib.sn_mgpu_last_error.argtypes = [vp]
     lib.sn_dbg_conv2d.argtypes = [vp, fp, ip, ip, ip, fp, fp, ip, ip, ip, ip, fp, fp]
     lib.sn_dbg_down0.argtypes = [vp, i8p, ip, ip, fp, fp, ip, fp]
+    lib.sn_dbg_compose_down01.argtypes = [fp, fp, fp, fp, fp, fp]
+    lib.sn_dbg_round_kernels_f16.argtypes = [fp, ip, fp]
+    lib.sn_dbg_down01.argtypes = [vp, i8p, ip, ip, fp, fp, fp, fp, fp]
     lib.sn_dbg_refin.argtypes = [vp, fp, i8p, ip, ip, ip, fp, fp, ip, fp]
     lib.sn_dbg_conv3d.argtypes = [vp, fp, ip, ip, ip, fp, fp, ip, fp]
     lib.sn_dbg_ref_conv_f16.argtypes = [vp, fp, ip, ip, fp, fp, ip, ip, fp, fp]
@@ -112,10 +115,36 @@ def load_library(path: Optional[str] = None):
                  "sn_infer_sbs_nv12", "sn_preprocess_sbs_nv12_batch", "sn_submit", "sn_submit_nv12", "sn_wait", "sn_synchronize", "sn_set_profiling",
                  "sn_get_stage_ms", "sn_get_dominant_kernel", "sn_mgpu_shard", "sn_mgpu_create", "sn_mgpu_destroy",
                  "sn_mgpu_get_info", "sn_mgpu_get_handle", "sn_mgpu_infer_batch", "sn_mgpu_infer_batch_device",
-                 "sn_mgpu_submit_device", "sn_mgpu_wait", "sn_mgpu_ring_init", "sn_mgpu_ring_submit", "sn_mgpu_ring_wait", "sn_dbg_conv2d", "sn_dbg_down0", "sn_dbg_refin", "sn_dbg_conv3d", "sn_dbg_ref_conv_f16", "sn_dbg_ref_conv_f16x3", "sn_dbg_ref_block_f16", "sn_dbg_ref_tail_f16", "sn_dbg_read", "sn_dbg_copy_limited", "sn_depth_from_raw"):
+                 "sn_mgpu_submit_device", "sn_mgpu_wait", "sn_mgpu_ring_init", "sn_mgpu_ring_submit", "sn_mgpu_ring_wait", "sn_dbg_conv2d", "sn_dbg_down0", "sn_dbg_compose_down01", "sn_dbg_round_kernels_f16", "sn_dbg_down01", "sn_dbg_refin", "sn_dbg_conv3d", "sn_dbg_ref_conv_f16", "sn_dbg_ref_conv_f16x3", "sn_dbg_ref_block_f16", "sn_dbg_ref_tail_f16", "sn_dbg_read", "sn_dbg_copy_limited", "sn_depth_from_raw"):
         getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
+
+
+def round_kernels_f16(w):
+    """The fp16 rounding SN_PREC_F16 applies to its tower's 3x3 weights at model load (host only): w (..., 3, 3) float32 ->
+    same shape, fp16-representable float32, the sum of every kernel's nine rounding errors minimised."""
+    a = np.ascontiguousarray(w, np.float32)
+    assert a.shape[-2:] == (3, 3)
+    out = np.empty_like(a)
+    rc = load_library().sn_dbg_round_kernels_f16(a.ctypes.data, a.size // 9, out.ctypes.data)
+    if rc:
+        raise StereoNetError(f"sn_dbg_round_kernels_f16: {error_string(rc)}")
+    return out
+
+
+def compose_down01(w0, b0, w1, b1):
+    """Host-side fold of the first two down-convs (no device needed): -> (weff (9,32,3,13,13), beff (9,32)) float32;
+    class = 3 * row class + column class, each {first, inner, last} row / column of the quarter-resolution map."""
+    w0, b0, w1, b1 = (np.ascontiguousarray(a, np.float32) for a in (w0, b0, w1, b1))
+    assert w0.shape == (32, 3, 5, 5) and w1.shape == (32, 32, 5, 5) and b0.shape == (32,) and b1.shape == (32,)
+    weff = np.empty((9, 32, 3, 13, 13), np.float32)
+    beff = np.empty((9, 32), np.float32)
+    rc = load_library().sn_dbg_compose_down01(w0.ctypes.data, b0.ctypes.data, w1.ctypes.data, b1.ctypes.data,
+                                              weff.ctypes.data, beff.ctypes.data)
+    if rc:
+        raise StereoNetError(f"sn_dbg_compose_down01: {error_string(rc)}")
+    return weff, beff
 
 
 def error_string(code: int) -> str:
@@ -292,7 +321,8 @@ class StereoNetHIP:
 
     # -- parity hooks --------------------------------------------------------------------------------
     def dbg_conv2d(self, x, wt, bias, k, stride=1, dil=1, lrelu=False, residual=None, x3=False, slots=False, tower32=False, dma=False):
-        """dma (5x5 stride 2 with x3 and slots): k_down_x3s_dma on zero-bordered tensors; the hook also checks the borders"""
+        """dma (with x3 and slots): the kernel of the zero-bordered tensors — k_down_x3s_dma (5x5 stride 2) or
+        k_feat_x3s_dma (3x3, also with a residual); the hook also checks that the borders stay zero"""
         x = np.ascontiguousarray(x, np.float32)
         wt = np.ascontiguousarray(wt, np.float32)
         bias = np.ascontiguousarray(bias, np.float32)
@@ -316,6 +346,19 @@ class StereoNetHIP:
         out = np.empty((2, 32, ho, wo), np.float32)
         self._check(self._lib.sn_dbg_down0(self._h, x.ctypes.data, h, w, wt.ctypes.data, bias.ctypes.data, tc,
                                            out.ctypes.data), "sn_dbg_down0")
+        return out
+
+    def dbg_down01(self, in6, w0, b0, w1, b1):
+        """in6 int8 (6,h,w) -> float32 (2, 32, ho, wo), ho/wo = ceil16/4: the first two down-convs of both eyes as the
+        folded 13x13 stride-4 convolution (k_down01_f16 + k_down01_border)."""
+        x = np.ascontiguousarray(in6, np.int8)
+        w0, b0, w1, b1 = (np.ascontiguousarray(a, np.float32) for a in (w0, b0, w1, b1))
+        assert w0.shape == (32, 3, 5, 5) and w1.shape == (32, 32, 5, 5) and b0.shape == (32,) and b1.shape == (32,)
+        _, h, w = x.shape
+        ho, wo = (h + 15) // 16 * 4, (w + 15) // 16 * 4
+        out = np.empty((2, 32, ho, wo), np.float32)
+        self._check(self._lib.sn_dbg_down01(self._h, x.ctypes.data, h, w, w0.ctypes.data, b0.ctypes.data, w1.ctypes.data,
+                                            b1.ctypes.data, out.ctypes.data), "sn_dbg_down01")
         return out
 
     def dbg_refin(self, disp_low, in6, dmax, wt, bias, split=False):

@@ -98,8 +98,18 @@ struct AggDma {
   static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
 };
 
-template <bool OUTSLOT>
+// HEADP (the LAST aggregation layer, with OUTSLOT = false): the 3x3x3 32 -> 1 output conv of the aggregation network
+// starts here.  Its contraction over the 32 channels runs on the matrix core with the 27 TAPS as the M dimension, straight
+// from the finished sums of a segment:  P[tap][pixel] = sum_c w[c][tap] * y[c][pixel],  y = lrelu(layer output) split
+// hi / lo (the B operand, formed from the accumulator layout by one half exchange as in the tower's tail form), w split
+// hi / lo (a.res = the four A fragments [K-step][hi | lo][lane], upload_agg_head_frag) — three MFMAs per K-step, six per
+// segment.  The kernel then writes P [n Dl][27][H][W] fp32 instead of y [n Dl][32][H][W]; k_softargmin_p sums the 27
+// shifted values per (d, pixel) — every P element is read exactly once — and does the soft-argmin.  k_head_softargmin
+// re-read the 32-channel volume at 2.7x its size in fabric traffic for 864 FMAs per (d, pixel).
+template <bool OUTSLOT, bool HEADP = false>
 __global__ __launch_bounds__(256, 1) void k_agg_x3s_dma(ConvArgs a, const uint4* __restrict__ vin, VolPad g) {
+  static_assert(!(OUTSLOT && HEADP), "the head's partial sums are an fp32 tensor");
+  constexpr int OCH = HEADP ? 27 : kC;          // planes per (n, d) image of the fp32 output
   using T = AggDma::T;
   constexpr int BUF = AggDma::BUF, KW = AggDma::KW;
   extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
@@ -123,6 +133,16 @@ __global__ __launch_bounds__(256, 1) void k_agg_x3s_dma(ConvArgs a, const uint4*
     }
 #pragma unroll
     for (int k = 0; k < T::NK; ++k) asm volatile("" : "+a"(wh[k]), "+a"(wl[k]));
+  }
+  half8 hd_h[HEADP ? 2 : 1], hd_l[HEADP ? 2 : 1];      // HEADP: A fragments of the output conv (taps as M), K-steps 0, 1
+  if (HEADP) {
+    const uint4* hs = reinterpret_cast<const uint4*>(a.res) + lane;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const uint4 x = hs[(2 * kk) * 64], y = hs[(2 * kk + 1) * 64];
+      hd_h[HEADP ? kk : 0] = *reinterpret_cast<const half8*>(&x);
+      hd_l[HEADP ? kk : 0] = *reinterpret_cast<const half8*>(&y);
+    }
   }
   // pixel of the segment that lane j computes (rotated columns: k_conv_x3s)
   constexpr int ROT = T::PITCH % 16;
@@ -210,10 +230,10 @@ __global__ __launch_bounds__(256, 1) void k_agg_x3s_dma(ConvArgs a, const uint4*
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int r = 4 * q + e;
-        const int co = (r & 3) + 8 * (r >> 2) + 4 * gh;
+        const int co = (r & 3) + 8 * (r >> 2) + 4 * gh;       // HEADP: the tap index (rows 27..31 of P are padding)
         float v = fin[r];
-        if (a.lrelu) v = v > 0.f ? v : v * kSlope;
-        if (d_in) reinterpret_cast<float*>(d_base)[(size_t)d_off + (size_t)co * plane_o] = v;
+        if (!HEADP && a.lrelu) v = v > 0.f ? v : v * kSlope;  // (HEADP activated before the contraction)
+        if (d_in && co < OCH) reinterpret_cast<float*>(d_base)[(size_t)d_off + (size_t)co * plane_o] = v;
       }
     }
   };
@@ -286,6 +306,47 @@ __global__ __launch_bounds__(256, 1) void k_agg_x3s_dma(ConvArgs a, const uint4*
         const int co = (r & 3) + 8 * (r >> 2) + 4 * gh;
         fin[r] = acc0[0][r] + acc1[0][r] * kSplitInv + src[r * 64] + s_bias[OUTSLOT ? 8 * (r >> 2) + 4 * gh + (r & 3) : co];
       }
+      if (HEADP) {
+        // y = lrelu(sum) as hi / lo fp16 pairs: pk[q][hp] = channels 8 q + 4 gh + 2 hp, + 1 of this lane's pixel
+        unsigned pkh[4][2], pkl[4][2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int hp = 0; hp < 2; ++hp) {
+            float v0 = fin[4 * q + 2 * hp], v1 = fin[4 * q + 2 * hp + 1];
+            if (a.lrelu) {
+              v0 = v0 > 0.f ? v0 : v0 * kSlope;
+              v1 = v1 > 0.f ? v1 : v1 * kSlope;
+            }
+            typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+            half2v h, l;
+            h[0] = (_Float16)v0;
+            h[1] = (_Float16)v1;
+            l[0] = (_Float16)((v0 - (float)h[0]) * kSplitScale);
+            l[1] = (_Float16)((v1 - (float)h[1]) * kSplitScale);
+            pkh[q][hp] = *reinterpret_cast<const unsigned*>(&h);
+            pkl[q][hp] = *reinterpret_cast<const unsigned*>(&l);
+          }
+        f32x16 p0, p1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p0[r] = p1[r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          // half exchange (lanes 32-63 of the first operand <-> lanes 0-31 of the second): lane (j, g) ends up with the
+          // whole 8-channel block 2 kk + g of its pixel = K-step kk's B operand
+          const auto h0 = __builtin_amdgcn_permlane32_swap(pkh[2 * kk][0], pkh[2 * kk + 1][0], false, false);
+          const auto h1 = __builtin_amdgcn_permlane32_swap(pkh[2 * kk][1], pkh[2 * kk + 1][1], false, false);
+          const auto l0 = __builtin_amdgcn_permlane32_swap(pkl[2 * kk][0], pkl[2 * kk + 1][0], false, false);
+          const auto l1 = __builtin_amdgcn_permlane32_swap(pkl[2 * kk][1], pkl[2 * kk + 1][1], false, false);
+          const uint4 sh = uint4{h0[0], h1[0], h0[1], h1[1]}, sl = uint4{l0[0], l1[0], l0[1], l1[1]};
+          const half8 xh = *reinterpret_cast<const half8*>(&sh), xl = *reinterpret_cast<const half8*>(&sl);
+          p0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(hd_h[HEADP ? kk : 0], xh, p0, 0, 0, 0);
+          p1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(hd_l[HEADP ? kk : 0], xh, p1, 0, 0, 0);
+          p1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(hd_h[HEADP ? kk : 0], xl, p1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) fin[r] = p0[r] + p1[r] * kSplitInv;      // row = tap (r & 3) + 8 (r >> 2) + 4 gh
+      }
       const int e_seg = pset * 2 + khalf;
       const int e_y = c_ty * 8 + e_seg * 2 + pr;
       const int e_x = c_tx * 16 + pc;
@@ -297,7 +358,7 @@ __global__ __launch_bounds__(256, 1) void k_agg_x3s_dma(ConvArgs a, const uint4*
         d_base = reinterpret_cast<char*>(a.out) + P * 8 * phw * 16;
         d_off = ((unsigned)(e_y + 1) * (unsigned)g.PW + (unsigned)(e_x + 1)) * 16u + gh * 8u;
       } else {
-        d_base = reinterpret_cast<char*>(a.out + (size_t)c_img * kC * plane_o);
+        d_base = reinterpret_cast<char*>(a.out + (size_t)c_img * OCH * plane_o);
         d_off = (unsigned)e_y * (unsigned)a.Wo + (unsigned)e_x;
       }
     }

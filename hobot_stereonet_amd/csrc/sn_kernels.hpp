@@ -1090,6 +1090,77 @@ __global__ __launch_bounds__(64 * kSamWaves) void k_head_softargmin(const float*
 }
 
 // ------------------------------------------------------------------------------------------
+// K6 on the partial sums of the last aggregation layer (k_agg_x3s_dma<false, true>, sn_agg_dma.hpp):
+//   P[n d'][tap][y'][x'] = sum_c w[c][tap] * vol[n][d'][c][y'][x'],  tap = dz*9 + ky*3 + kx
+//   cost[d][y][x]        = b + sum_{dz, ky, kx} P[n (d + dz - 1)][tap][y + ky - 1][x + kx - 1]      (0 outside the volume)
+//   disp                 = sum_d d * softmax_d(-cost)
+// Workgroup = Dl waves x 64 consecutive pixels: wave d sums the 27 shifted values of plane d (every load a 256-byte run of
+// one P image; each element of P is read by exactly one (d, pixel)), the Dl costs of a pixel meet in LDS and wave 0 does
+// the soft-argmin exactly as k_head_softargmin does.
+// ------------------------------------------------------------------------------------------
+template <int DLMAX>
+__global__ __launch_bounds__(64 * DLMAX) void k_softargmin_p(const float* __restrict__ P,      // [n][Dl][27][H][W]
+                                                          float bias, int Dl, int H, int W, int npix_total,
+                                                          float* __restrict__ disp_low,     // [n][H][W]
+                                                          float* __restrict__ cost_out) {   // nullable [n][Dl][H][W]
+  __shared__ float s_cost[DLMAX][64];
+  const int lane = threadIdx.x & 63;
+  const int d = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);        // this wave's plane (blockDim = 64 * Dl)
+  const int gp = blockIdx.x * 64 + lane;
+  const int plane = H * W;
+  const bool live = gp < npix_total;
+  const int n = live ? gp / plane : 0;
+  const int pix = live ? gp - n * plane : 0;
+  const int y = pix / W, x = pix - y * W;
+  float c = bias;
+#pragma unroll
+  for (int dz = 0; dz < 3; ++dz) {
+    const int dp = d + dz - 1;
+    if (dp < 0 || dp >= Dl) continue;             // wave-uniform
+    const float* src = P + ((size_t)n * Dl + dp) * 27 * plane + (size_t)dz * 9 * plane;
+    float v[9];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int yy = y + ky - 1, xx = x + kx - 1;
+        const bool ok = live && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+        v[ky * 3 + kx] = ok ? src[(size_t)(ky * 3 + kx) * plane + yy * W + xx] : 0.f;
+      }
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) s += v[t];
+    c += s;
+  }
+  s_cost[d][lane] = c;
+  __syncthreads();
+  if (d != 0) return;
+  float cost[DLMAX];
+#pragma unroll
+  for (int k = 0; k < DLMAX; ++k) cost[k] = k < Dl ? s_cost[k][lane] : 0.f;
+  float m = -cost[0];
+#pragma unroll
+  for (int k = 1; k < DLMAX; ++k)
+    if (k < Dl) m = fmaxf(m, -cost[k]);
+  float se = 0.f, sd = 0.f;
+#pragma unroll
+  for (int k = 0; k < DLMAX; ++k)
+    if (k < Dl) {
+      const float e = expf(-cost[k] - m);
+      se += e;
+      sd = fmaf((float)k, e, sd);
+    }
+  if (live) {
+    disp_low[gp] = sd / se;
+    if (cost_out) {
+#pragma unroll
+      for (int k = 0; k < DLMAX; ++k)
+        if (k < Dl) cost_out[((size_t)n * Dl + k) * plane + pix] = cost[k];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // K8: refinement head 3x3 conv 32->1, disp = relu(up + D*r), float + wire int32 outputs.
 //   raw = rint(disp * inv_q), inv_q = 1/(D*scale)   (stereonet_node.cpp:282-288: the consumer
 //   multiplies raw by scale*16*12).  One thread per output pixel, lanes along x (coalesced).
@@ -2139,3 +2210,5 @@ __global__ __launch_bounds__(256) void k_head_final_f16(const uint4* __restrict_
 #include "sn_stream_block.hpp"
 #include "sn_tower_f32.hpp"
 #include "sn_agg_dma.hpp"
+#include "sn_down01.hpp"
+#include "sn_feat_dma.hpp"

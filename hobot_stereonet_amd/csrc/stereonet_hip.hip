@@ -10,6 +10,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <cmath>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -80,6 +81,11 @@ struct Down0F16 {           // first down-conv on the fp16 MFMA (k_down0_f16): 8
   uint4* wfrag = nullptr;   // device [8][2][64] slots
 };
 
+struct Down01W {            // down-convs 0 and 1 folded into one 13x13 stride-4 conv (sn_down01.hpp): nine weight classes
+  uint4* wfrag = nullptr;   // device [9][39][2][64] slots
+  float* bias = nullptr;    // device [9][32]
+};
+
 struct RefLayerF16 {        // fp16 tower layer: 18 MFMA A-fragments + fp32 bias
   uint4* wfrag = nullptr;   // device [9][2][64] slots
   float* bias = nullptr;
@@ -88,6 +94,7 @@ struct RefLayerF16 {        // fp16 tower layer: 18 MFMA A-fragments + fp32 bias
 struct HeadLayer {          // C -> 1 layers (VALU kernels)
   float* w = nullptr;       // device [32][taps]
   float bias = 0.f;
+  uint4* pfrag = nullptr;   // agg.out only, fp16 modes: split A fragments of the taps-as-M contraction [2][hi|lo][64] (k_agg_x3s_dma HEADP)
 };
 
 constexpr int kMaxLevels = 4, kMultiLevels = 4;              // hierarchical refinement: 1/8, 1/4, 1/2, 1
@@ -102,6 +109,7 @@ struct Workspace {          // activations for up to `nb` pairs
   float* feat = nullptr;
   float* vol[2] = {nullptr, nullptr};
   uint4* volp[2] = {nullptr, nullptr};
+  uint4* lowp[2] = {nullptr, nullptr};            // zero-bordered (x, t) of the 3x3 feature layers (fp16 modes, FeatPad)
   uint4* downp[3] = {nullptr, nullptr, nullptr};   // zero-bordered inputs of down-convs 1..3 (fp16 modes, DownDma)   // zero-bordered split-slot volumes of the aggregation layers (fp16 modes, VolPad)
   float* cost = nullptr;     // [nb][Dl][hl][wl] (debug / parity)
   float* disp_low = nullptr;
@@ -177,6 +185,8 @@ struct sn_handle {
   bool stream_prio = false;  // the pipeline streams were created with the device's highest priority (sn_create_prio)
   ConvLayer down[kNDown], fres[kNFeatRes][2], fout, agg[kNAgg];
   Down0F16 down0;
+  Down01W down01;            // fp16 modes, unless SN_DOWN01=0
+  bool fold_down01 = false;
   HeadLayer aout;
   // refinement towers: tw[0] = full resolution (the only one of a single-scale model); a hierarchical ("multi") model
   // has levels = kMultiLevels towers, tw[k] working at 1/2^k resolution
@@ -398,6 +408,45 @@ hipError_t launch_down0_f16(hipStream_t st, const Down0F16& L, const float* bias
 template <class K>
 hipError_t ensure_lds_attr(K kern, int bytes);
 
+// SN_DOWN01=0 restores k_down0_f16 + k_down_x3s_dma for the first two down-convs (parity switch)
+bool down01_enabled() {
+  static const bool on = !(getenv("SN_DOWN01") != nullptr && atoi(getenv("SN_DOWN01")) == 0);
+  return on;
+}
+
+int upload_down01(sn_handle* h, const HostLayer& l0, const HostLayer& l1, Down01W* out) {
+  std::vector<double> weff, beff;
+  compose_down01(l0.w, l0.b, l1.w, l1.b, weff, beff);
+  std::vector<_Float16> pk;
+  pack_down01(weff, pk);
+  std::vector<float> bf(beff.begin(), beff.end());
+  HIP_TRY(h, dalloc(&out->wfrag, pk.size() / 8));
+  HIP_TRY(h, dalloc(&out->bias, bf.size()));
+  HIP_TRY(h, hipMemcpy(out->wfrag, pk.data(), pk.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+  HIP_TRY(h, hipMemcpy(out->bias, bf.data(), bf.size() * sizeof(float), hipMemcpyHostToDevice));
+  return SN_OK;
+}
+
+// in6: int8 model input of the piece; out: split-slot tensor of the quarter-resolution map in geometry `og`
+hipError_t launch_down01(hipStream_t st, const Down01W& L, const int8_t* in6, int H, int W, int nimg, int Ho, int Wo,
+                         uint4* out, const SlotGeom& og, int num_cu) {
+  using T = Down01;
+  hipError_t e = ensure_lds_attr(k_down01_f16, T::LDS_BYTES);
+  if (e != hipSuccess) return e;
+  const int tiles_x = (Wo + T::TC - 1) / T::TC, tiles_y = (Ho + T::TR - 1) / T::TR;
+  const int total = tiles_x * tiles_y * nimg;
+  int blocks = num_cu / 8 * 8;                    // one workgroup per CU (register budget), whole XCD bands
+  while (blocks > 8 && blocks / 8 > (total + 7) / 8) blocks -= 8;
+  const int al4 = (W % 4 == 0) && (reinterpret_cast<uintptr_t>(in6) % 4 == 0);
+  hipLaunchKernelGGL(k_down01_f16, dim3(blocks), dim3(256), T::LDS_BYTES, st, in6, H, W,
+                     L.wfrag + (size_t)T::INNER * T::NK * 2 * 64, L.bias + T::INNER * kC, out, Ho, Wo, tiles_x, tiles_y, nimg,
+                     al4, og.PH, og.PW, og.py, og.px);
+  const int per_img = 4 + 2 * ((Wo - 2 + 31) / 32) + 2 * ((Ho - 2 + 31) / 32);
+  hipLaunchKernelGGL(k_down01_border, dim3((per_img * nimg + 3) / 4), dim3(256), 0, st, in6, H, W, L.wfrag, L.bias, out, Ho, Wo,
+                     nimg, og.PH, og.PW, og.py, og.px);
+  return hipGetLastError();
+}
+
 // weights-stationary split-operand conv on split-slot tensors: persistent grid of MINB workgroups per CU
 template <int KS, int STRIDE, int VCH, int TR, int TC, int SEGW, int MINB, bool OUTSLOT, class Loader, bool HASRES = false>
 hipError_t launch_conv_x3s(hipStream_t st, const ConvLayer& L, const Loader& ld, int nimg, int Ho, int Wo, float* out,
@@ -496,14 +545,17 @@ bool agg_dma_enabled() {
 VolPad vol_pad(int Dl, int hl, int wl) { return VolPad{Dl, hl, wl, VolPad::ph(hl), VolPad::pw(wl)}; }
 
 // 3x3x3 aggregation layer on zero-bordered split-slot volumes (sn_agg_dma.hpp): one persistent workgroup per CU
-template <bool OUTSLOT>
+// head_frag != nullptr (OUTSLOT = false): the layer ends in the output conv's taps-as-M contraction and writes its partial
+// sums P [npairs Dl][27][H][W] instead of the activated volume (k_agg_x3s_dma HEADP)
+template <bool OUTSLOT, bool HEADP = false>
 hipError_t launch_agg_dma(hipStream_t st, const ConvLayer& L, const uint4* vin, const VolPad& g, int npairs, void* out,
-                          bool lrelu, int num_cu) {
+                          bool lrelu, int num_cu, const uint4* head_frag = nullptr) {
   ConvArgs a{};
   a.wpk = reinterpret_cast<const float*>(L.wx3);
   a.bias = L.bias;
   a.out = reinterpret_cast<float*>(out);
-  a.res = nullptr;
+  a.res = reinterpret_cast<const float*>(head_frag);
+  if (HEADP != (head_frag != nullptr)) return hipErrorInvalidValue;
   a.nimg = npairs * g.Dl;
   a.cin_pad = L.cin_pad;
   a.Ho = g.H;
@@ -513,7 +565,7 @@ hipError_t launch_agg_dma(hipStream_t st, const ConvLayer& L, const uint4* vin, 
   a.lrelu = lrelu ? 1 : 0;
   a.tiles_x = (g.W + 15) / 16;
   a.tiles_y = (g.H + 7) / 8;
-  auto kern = k_agg_x3s_dma<OUTSLOT>;
+  auto kern = k_agg_x3s_dma<OUTSLOT, HEADP>;
   hipError_t e = ensure_lds_attr(kern, (int)AggDma::LDS_BYTES);
   if (e != hipSuccess) return e;
   const int total = a.tiles_x * a.tiles_y * a.nimg;
@@ -521,6 +573,47 @@ hipError_t launch_agg_dma(hipStream_t st, const ConvLayer& L, const uint4* vin, 
   if (blocks > (total + 7) / 8 * 8) blocks = (total + 7) / 8 * 8;
   blocks = (blocks + 7) / 8 * 8;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), AggDma::LDS_BYTES, st, a, vin, g);
+  return hipGetLastError();
+}
+
+// SN_FEAT_DMA=0: the 3x3 feature layers on the plain split-slot tensors (k_conv_x3s) instead of the zero-bordered ones
+bool feat_dma_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("SN_FEAT_DMA");
+    return !(e && *e == '0') && ablate_mask("SN_ABLATE_X") == 0;
+  }();
+  return on;
+}
+
+FeatPad feat_pad(int H, int W) { return FeatPad{H, W, FeatPad::ph(H), FeatPad::pw(W)}; }
+
+// 3x3 32->32 feature layer on zero-bordered split-slot tensors (sn_feat_dma.hpp): two persistent workgroups per CU.
+// out / res: FeatPad tensors (OUTSLOT) or fp32 NCHW.
+template <bool OUTSLOT, bool HASRES>
+hipError_t launch_feat_dma(hipStream_t st, const ConvLayer& L, const uint4* vin, const FeatPad& g, int nimg, void* out,
+                           const void* res, bool lrelu, int num_cu) {
+  ConvArgs a{};
+  a.wpk = reinterpret_cast<const float*>(L.wx3);
+  a.bias = L.bias;
+  a.out = reinterpret_cast<float*>(out);
+  a.res = reinterpret_cast<const float*>(res);
+  a.nimg = nimg;
+  a.cin_pad = L.cin_pad;
+  a.Ho = g.H;
+  a.Wo = g.W;
+  a.dil = 1;
+  a.pad = 1;
+  a.lrelu = lrelu ? 1 : 0;
+  a.tiles_x = (g.W + 15) / 16;
+  a.tiles_y = (g.H + 7) / 8;
+  auto kern = k_feat_x3s_dma<OUTSLOT, HASRES>;
+  hipError_t e = ensure_lds_attr(kern, (int)FeatDma::LDS_BYTES);
+  if (e != hipSuccess) return e;
+  const int total = a.tiles_x * a.tiles_y * a.nimg;
+  int blocks = 2 * num_cu;
+  if (blocks > (total + 7) / 8 * 8) blocks = (total + 7) / 8 * 8;
+  blocks = (blocks + 7) / 8 * 8;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), FeatDma::LDS_BYTES, st, a, vin, g);
   return hipGetLastError();
 }
 
@@ -568,6 +661,32 @@ int upload_head(sn_handle* h, const HostLayer& l, HeadLayer* out) {   // [1][32]
   HIP_TRY(h, hipMemcpy(out->w, l.w, (size_t)kC * l.taps * sizeof(float), hipMemcpyHostToDevice));
   out->bias = l.b[0];
   return SN_OK;
+}
+
+// agg.out as the A operand of P[tap][pixel] = sum_c w[c][tap] y[c][pixel] (k_agg_x3s_dma<false, true>): row m = tap
+// (27 of 32 rows), K-step kk = channels 16 kk .. 16 kk + 15, lane (m, g) holds channels 16 kk + 8 g + e; hi / lo split
+int upload_agg_head_frag(sn_handle* h, const HostLayer& l, HeadLayer* out) {
+  std::vector<_Float16> pk((size_t)2 * 2 * 64 * 8, (_Float16)0.f);
+  for (int kk = 0; kk < 2; ++kk)
+    for (int lane = 0; lane < 64; ++lane)
+      for (int e = 0; e < 8; ++e) {
+        const int m = lane & 31, c = 16 * kk + 8 * (lane >> 5) + e;
+        if (m >= 27) continue;
+        const float w = l.w[(size_t)c * 27 + m];
+        const _Float16 hi = (_Float16)w;
+        const size_t base = ((size_t)(2 * kk) * 64 + lane) * 8 + e;
+        pk[base] = hi;
+        pk[base + 64 * 8] = (_Float16)((w - (float)hi) * kSplitScale);
+      }
+  HIP_TRY(h, dalloc(&out->pfrag, pk.size() / 8));
+  HIP_TRY(h, hipMemcpy(out->pfrag, pk.data(), pk.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+  return SN_OK;
+}
+
+// SN_HEAD_FOLD=0: the last aggregation layer writes its 32-channel volume and k_head_softargmin contracts it (parity switch)
+bool head_fold_enabled() {
+  static const bool on = !(getenv("SN_HEAD_FOLD") != nullptr && atoi(getenv("SN_HEAD_FOLD")) == 0);
+  return on;
 }
 
 // Raise a kernel's dynamic-LDS limit once per (kernel, device) — not per launch: launches may happen inside a
@@ -738,14 +857,86 @@ hipError_t alloc_ref16(const RefGeom& g, size_t tensor_and_slack_slots, uint4** 
 }
 
 // [co][ci][ky][kx] fp32 -> wfrag[tap][kk][lane][e] fp16 = w[co = lane&31][ci = 16kk + 8(lane>>5) + e][tap]
+// ---- fp16 weights of the tower (SN_PREC_F16): sum-preserving rounding of every 3x3 kernel ----------------------------
+// Rounding each weight to nearest leaves every (cout, cin) kernel with a sum error of ~sqrt(9) half-ulps.  The tower's
+// activations are LeakyReLU outputs: positive mean, and smooth wherever the image is — so a kernel's response to them is
+// mostly (sum of its taps) x (local mean), and the sum errors of the 32 x 32 x 12 kernels add up COHERENTLY over the whole
+// image into an offset of the refinement residual: 2.4e-4 ... 1.1e-3 px at D = 192 depending on the weight draw and the
+// image content, the largest single term of the mode's error (scripts/f16_error_sources.py,
+// profiles/r05_f16_error_sources.txt).  Here each kernel's nine taps are rounded down or up (never further than the two
+// neighbouring fp16 numbers) in the combination, out of the 512, whose SUM of errors is smallest: the offset disappears
+// (< 2e-5 px in the same experiment), at the price of individual tap errors of up to one ulp instead of half — which only
+// the high-frequency part of the activations sees.  Costs nothing at run time, needs no calibration data; weights that
+// are exact in fp16 stay as they are.  SN_W_ROUND=rne restores round-to-nearest (A/B switch).
+inline _Float16 f16_neighbour(_Float16 hval, bool up) {
+  uint16_t b;
+  memcpy(&b, &hval, 2);
+  if (up) {
+    if (b == 0x8000) b = 0x0001;
+    else if (b & 0x8000) b -= 1;
+    else b += 1;
+  } else {
+    if (b == 0x0000) b = 0x8001;
+    else if (b & 0x8000) b += 1;
+    else b -= 1;
+  }
+  _Float16 r;
+  memcpy(&r, &b, 2);
+  return r;
+}
+
+// w[9] -> q[9]: q[t] is one of the two fp16 numbers enclosing w[t]
+void round_kernel_sum_preserving(const float* w, _Float16* q) {
+  double lo[9], hi[9];
+  _Float16 hlo[9], hhi[9];
+  for (int t = 0; t < 9; ++t) {
+    const _Float16 n = (_Float16)w[t];
+    const double nd = (double)n, wd = (double)w[t];
+    hlo[t] = nd <= wd ? n : f16_neighbour(n, false);
+    hhi[t] = nd >= wd ? n : f16_neighbour(n, true);
+    lo[t] = (double)hlo[t] - wd;        // <= 0
+    hi[t] = (double)hhi[t] - wd;        // >= 0
+  }
+  int best = 0;
+  double best_score = 1e300;
+  for (int m = 0; m < 512; ++m) {
+    double sum = 0, sq = 0;
+    for (int t = 0; t < 9; ++t) {
+      const double e = (m >> t) & 1 ? hi[t] : lo[t];
+      sum += e;
+      sq += e * e;
+    }
+    const double score = std::fabs(sum) + 1e-3 * std::sqrt(sq);      // sum first; among (near-)ties the smallest errors
+    if (score < best_score) {
+      best_score = score;
+      best = m;
+    }
+  }
+  for (int t = 0; t < 9; ++t) q[t] = (best >> t) & 1 ? hhi[t] : hlo[t];
+}
+
+bool w_round_sum_preserving() {      // read at every sn_create (not cached): scripts/epe_sensitivity.py compares the two in one process
+  const char* e = getenv("SN_W_ROUND");
+  return !(e && strcmp(e, "rne") == 0);
+}
+
 int upload_ref_f16(sn_handle* h, const HostLayer& l, RefLayerF16* out) {
+  std::vector<_Float16> q((size_t)kC * kC * 9);
+  const bool sp = w_round_sum_preserving();
+  for (size_t k = 0; k < (size_t)kC * kC; ++k) {
+    if (sp) {
+      round_kernel_sum_preserving(l.w + k * 9, &q[k * 9]);
+    } else {
+      for (int t = 0; t < 9; ++t) q[k * 9 + t] = (_Float16)l.w[k * 9 + t];
+    }
+  }
   std::vector<_Float16> pk((size_t)18 * 64 * 8);
   for (int tap = 0; tap < 9; ++tap)
     for (int kk = 0; kk < 2; ++kk)
       for (int lane = 0; lane < 64; ++lane)
         for (int e = 0; e < 8; ++e) {
           const int co = lane & 31, ci = 16 * kk + 8 * (lane >> 5) + e;
-          pk[(((size_t)tap * 2 + kk) * 64 + lane) * 8 + e] = (_Float16)l.w[((size_t)co * kC + ci) * 9 + tap];
+          pk[(((size_t)tap * 2 + kk) * 64 + lane) * 8 + e] = q[((size_t)co * kC + ci) * 9 + tap];
         }
   HIP_TRY(h, dalloc(&out->wfrag, (size_t)18 * 64));
   HIP_TRY(h, dalloc(&out->bias, kC));
@@ -995,14 +1186,23 @@ int alloc_ws(sn_handle* h, Workspace* ws, int nb, int rb, int ns) {
     downp_bytes[k] = (size_t)2 * pb * 8 * g.PH * g.PW * sizeof(uint4);
     padded_down = downp_bytes[k] < ((size_t)1 << 32);
   }
-  for (int k = 0; k < 3 && !padded_down; ++k)
+  const int k_first = h->fold_down01 ? 1 : 0;       // folded down-convs 0 + 1: the half-resolution tensor never exists
+  for (int k = k_first; k < 3 && !padded_down; ++k)
     HIP_TRY(h, dalloc(&ws->down[k], (size_t)2 * pb * kC * (HWp >> (2 * (k + 1)))));
   for (int k = 0; k < 3; ++k) HIP_TRY(h, dalloc(&ws->low[k], (size_t)2 * pb * kC * hw));
   HIP_TRY(h, dalloc(&ws->feat, (size_t)2 * pb * kC * hw));
   for (int k = 0; k < 2; ++k) HIP_TRY(h, dalloc(&ws->vol[k], (size_t)pb * h->Dl * kC * hw));
-  for (int k = 0; k < 3 && padded_down; ++k) {
+  for (int k = k_first; k < 3 && padded_down; ++k) {
     HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&ws->downp[k]), downp_bytes[k]));
     HIP_TRY(h, memset_now(ws->downp[k], 0, downp_bytes[k]));   // the borders stay zero: kernels write image pixels only
+  }
+  if (padded_down && feat_dma_enabled()) {       // (the last down-conv writes straight into the bordered layout)
+    const FeatPad g = feat_pad(h->hl, h->wl);
+    const size_t bytes = (size_t)2 * pb * g.img_slots() * sizeof(uint4);
+    for (int k = 0; k < 2 && bytes < ((size_t)1 << 32); ++k) {
+      HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&ws->lowp[k]), bytes));
+      HIP_TRY(h, memset_now(ws->lowp[k], 0, bytes));       // the borders stay zero: kernels write image pixels only
+    }
   }
   if (h->precision != SN_PREC_FP32 && agg_dma_enabled()) {
     const VolPad g = vol_pad(h->Dl, h->hl, h->wl);
@@ -1064,6 +1264,7 @@ void free_ws(Workspace* ws) {
   for (auto p : ws->vol) hipFree(p);
   for (auto p : ws->volp) hipFree(p);
   for (auto p : ws->downp) hipFree(p);
+  for (auto p : ws->lowp) hipFree(p);
   hipFree(ws->cost);
   hipFree(ws->disp_low);
   for (auto p : ws->ref) hipFree(p);
@@ -1094,23 +1295,33 @@ int lowres_slots(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, con
   const int8_t* in = in6 + (size_t)p0 * 6 * HW;
   const int ncu = h->num_cu, ni = 2 * m;
   auto U4 = [](float* p) { return reinterpret_cast<const uint4*>(p); };
-  if (ws.downp[0] != nullptr) {       // zero-bordered tensors between the down-convs, LDS-DMA kernel
+  if (ws.downp[1] != nullptr) {       // zero-bordered tensors between the down-convs, LDS-DMA kernel
     SlotGeom gin[3];
     for (int i = 0; i < 3; ++i) gin[i] = down_in_geom(Hp >> (i + 2), Wp >> (i + 2));
-    HIP_TRY(h, launch_down0_f16(st, h->down0, h->down[0].bias, in, h->H, h->W, ni, Hp / 2, Wp / 2,
-                                reinterpret_cast<float*>(ws.downp[0]), ncu, &gin[0]));
-    for (int i = 0; i < 3; ++i) {
+    if (h->fold_down01)      // down-convs 0 and 1 as one 13x13 stride-4 conv straight from the int8 input (sn_down01.hpp)
+      HIP_TRY(h, launch_down01(st, h->down01, in, h->H, h->W, ni, Hp / 4, Wp / 4, ws.downp[1], gin[1], ncu));
+    else
+      HIP_TRY(h, launch_down0_f16(st, h->down0, h->down[0].bias, in, h->H, h->W, ni, Hp / 2, Wp / 2,
+                                  reinterpret_cast<float*>(ws.downp[0]), ncu, &gin[0]));
+    for (int i = h->fold_down01 ? 1 : 0; i < 3; ++i) {
       const int Ho = Hp >> (i + 2), Wo = Wp >> (i + 2);
       const SlotGeom plain{Ho, Wo, 0, 0};
-      HIP_TRY(h, launch_down_dma(st, h->down[i + 1], ws.downp[i], ni, Ho, Wo, i < 2 ? (void*)ws.downp[i + 1] : (void*)ws.low[0],
-                                 i < 2 ? gin[i + 1] : plain, false, ncu));
+      const FeatPad fp = feat_pad(hl, wl);
+      const SlotGeom bordered{fp.PH, fp.PW, 1, 1};           // the feature layers' zero-bordered layout (sn_feat_dma.hpp)
+      void* const last = ws.lowp[0] ? (void*)ws.lowp[0] : (void*)ws.low[0];
+      HIP_TRY(h, launch_down_dma(st, h->down[i + 1], ws.downp[i], ni, Ho, Wo, i < 2 ? (void*)ws.downp[i + 1] : last,
+                                 i < 2 ? gin[i + 1] : (ws.lowp[0] ? bordered : plain), false, ncu));
     }
   } else {
-  HIP_TRY(h, launch_down0_f16(st, h->down0, h->down[0].bias, in, h->H, h->W, ni, Hp / 2, Wp / 2, ws.down[0], ncu));
+  if (h->fold_down01)
+    HIP_TRY(h, launch_down01(st, h->down01, in, h->H, h->W, ni, Hp / 4, Wp / 4, reinterpret_cast<uint4*>(ws.down[1]),
+                             SlotGeom{Hp / 4, Wp / 4, 0, 0}, ncu));
+  else
+    HIP_TRY(h, launch_down0_f16(st, h->down0, h->down[0].bias, in, h->H, h->W, ni, Hp / 2, Wp / 2, ws.down[0], ncu));
   {
     float* src[3] = {ws.down[0], ws.down[1], ws.down[2]};
     float* dst[3] = {ws.down[1], ws.down[2], ws.low[0]};
-    for (int i = 0; i < 3; ++i) {
+    for (int i = h->fold_down01 ? 1 : 0; i < 3; ++i) {
       const int Hi = Hp >> (i + 1), Wi = Wp >> (i + 1);
       if ((h->ablate_x >> (kAblDown + i)) & 1u) HIP_TRY(h, zero_lo_slots(st, src[i], ni, (size_t)Hi * Wi));
       SlotIn ld{U4(src[i]), 0, Hi, Wi};
@@ -1119,6 +1330,15 @@ int lowres_slots(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, con
     }
   }
   }
+  if (ws.lowp[0] != nullptr && ws.downp[1] != nullptr) {     // zero-bordered (x, t), LDS-DMA kernel
+    const FeatPad fp = feat_pad(hl, wl);
+    uint4 *x = ws.lowp[0], *t = ws.lowp[1];
+    for (int i = 0; i < kNFeatRes; ++i) {
+      HIP_TRY(h, (launch_feat_dma<true, false>(st, h->fres[i][0], x, fp, ni, t, nullptr, true, ncu)));
+      HIP_TRY(h, (launch_feat_dma<true, true>(st, h->fres[i][1], t, fp, ni, x, x, true, ncu)));     // in-place residual
+    }
+    HIP_TRY(h, (launch_feat_dma<false, false>(st, h->fout, x, fp, ni, ws.feat, nullptr, false, ncu)));
+  } else {
   float* x = ws.low[0];
   float* t = ws.low[1];
   for (int i = 0; i < kNFeatRes; ++i) {
@@ -1133,6 +1353,7 @@ int lowres_slots(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, con
     SlotIn lx{U4(x), 0, hl, wl};
     HIP_TRY(h, (launch_conv_x3s<3, 1, 32, 8, 16, 16, 1, false, SlotIn>(st, h->fout, lx, ni, hl, wl, ws.feat, nullptr, false, ncu)));
   }
+  }
   if (prof) HIP_TRY(h, hipEventRecord(h->ev[1], st));
   // cost volume -> slots (vol[1]), then every aggregation layer reads slots: agg0 vol[1] -> vol[0], agg1 -> vol[1], ...
   // (zero-bordered volumes volp[] and the LDS-DMA kernel by default; the last layer writes fp32 into vol[] either way)
@@ -1144,8 +1365,18 @@ int lowres_slots(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, con
       const uint4* src = ws.volp[(i + 1) & 1];
       if (i + 1 < kNAgg)
         HIP_TRY(h, launch_agg_dma<true>(st, h->agg[i], src, g, m, ws.volp[i & 1], true, ncu));
+      else if (head_fold_enabled() && h->aout.pfrag)     // the output conv's contraction rides on this layer's epilogue
+        HIP_TRY(h, (launch_agg_dma<false, true>(st, h->agg[i], src, g, m, ws.vol[i & 1], true, ncu, h->aout.pfrag)));
       else
         HIP_TRY(h, launch_agg_dma<false>(st, h->agg[i], src, g, m, ws.vol[i & 1], true, ncu));
+    }
+    if (head_fold_enabled() && h->aout.pfrag) {       // soft-argmin on the partial sums P [m Dl][27][hl][wl]
+      const int npix = m * hl * wl;
+      hipLaunchKernelGGL(k_softargmin_p<16>, dim3((npix + 63) / 64), dim3(64 * Dl), 0, st, ws.vol[(kNAgg - 1) & 1], h->aout.bias,
+                         Dl, hl, wl, npix, ws.disp_low + (size_t)p0 * hl * wl,
+                         want_cost ? ws.cost + (size_t)p0 * Dl * hl * wl : nullptr);
+      HIP_TRY(h, hipGetLastError());
+      return SN_OK;
     }
   } else {
   {
@@ -1733,10 +1964,14 @@ int sn_create_prio(const char* model_file, const sn_config* cfg, int stream_prio
   h->ablate_x = ablate_mask("SN_ABLATE_X");
 #endif
   int feat_idx = 0;
+  h->fold_down01 = low_x3 && down01_enabled();
+  HostLayer hl_down0{};
   for (int i = 0; i < kNDown; ++i) {
     const HostLayer hl_ = bw.next(kC, i == 0 ? 3 : kC, 25);
     if ((rc = upload_conv2d(h, hl_, 4, &h->down[i]))) return fail(rc);
     if (low_x3 && i == 0 && (rc = upload_down0_f16(h, hl_, &h->down0))) return fail(rc);
+    if (i == 0) hl_down0 = hl_;
+    if (h->fold_down01 && i == 1 && (rc = upload_down01(h, hl_down0, hl_, &h->down01))) return fail(rc);
     if (low_x3 && i > 0 &&
         (rc = upload_x3(h, kC, [&](int co, int c, int tap) { return hl_.w[((size_t)co * kC + c) * 25 + tap]; },
                         &h->down[i], 25, (abl_w >> (kAblDown + i - 1)) & 1u)))
@@ -1764,7 +1999,11 @@ int sn_create_prio(const char* model_file, const sn_config* cfg, int stream_prio
         }, &h->agg[i], 9, (abl_w >> (kAblAgg + i)) & 1u)))
       return fail(rc);
   }
-  if ((rc = upload_head(h, bw.next(1, kC, 27), &h->aout))) return fail(rc);
+  {
+    const HostLayer hl_ = bw.next(1, kC, 27);
+    if ((rc = upload_head(h, hl_, &h->aout))) return fail(rc);
+    if (low_x3 && (rc = upload_agg_head_frag(h, hl_, &h->aout))) return fail(rc);
+  }
   for (int lv = 0; lv < h->levels; ++lv) {          // blob order: tower of level 0, then (multi) levels 1, 2, 3
     Tower& T = h->tw[lv];
     {
@@ -1803,6 +2042,8 @@ int sn_destroy(sn_handle* h) {
   };
   for (auto& l : h->down) free_conv(l);
   hipFree(h->down0.wfrag);
+  hipFree(h->down01.wfrag);
+  hipFree(h->down01.bias);
   for (auto& b : h->fres)
     for (auto& l : b) free_conv(l);
   free_conv(h->fout);
@@ -2259,7 +2500,7 @@ int sn_dbg_conv2d(sn_handle* h, const float* in, int cin, int h_px, int w, const
   const bool dma = (lrelu & 16) != 0;        // bit 4 (5x5 stride 2 on slots): k_down_x3s_dma on zero-bordered tensors
   lrelu &= 1;
   if (x3 != slots || (x3 && !(cin == kC && dil == 1))) return SN_ERR_ARG;     // the split-operand kernel reads slots
-  if (dma && !(slots && k == 5 && !residual)) return SN_ERR_ARG;
+  if (dma && !(slots && (k == 3 || !residual))) return SN_ERR_ARG;
   if (slots) {          // split-slot tensors in and out through the weights-stationary kernel (fp16 modes' low-res path)
     ConvLayer Ls;
     HostLayer hls{wt, bias, kC, cin, taps};
@@ -2281,6 +2522,44 @@ int sn_dbg_conv2d(sn_handle* h, const float* in, int cin, int h_px, int w, const
       host_to_slots(residual, 1, Ho, Wo, hres);
       HIP_TRY(h, hipMemcpy(dout, hres.data(), hres.size() * 2, hipMemcpyHostToDevice));
       dres = reinterpret_cast<const float*>(dout);
+    }
+    if (dma && k == 3) {      // k_feat_x3s_dma: zero-bordered input, output and residual (FeatPad)
+      const FeatPad g = feat_pad(h_px, w);
+      const size_t phw = (size_t)g.PH * g.PW;
+      std::vector<_Float16> pin(8 * phw * 8, (_Float16)0.f), pout(8 * phw * 8, (_Float16)0.f);
+      for (int img = 0; img < 8; ++img)      // (block, part) images
+        for (int y = 0; y < h_px; ++y) {
+          memcpy(&pin[((size_t)img * phw + (size_t)(y + 1) * g.PW + 1) * 8], &hin[((size_t)img * h_px + y) * w * 8], (size_t)w * 16);
+          if (residual)
+            memcpy(&pout[((size_t)img * phw + (size_t)(y + 1) * g.PW + 1) * 8], &hres[((size_t)img * h_px + y) * w * 8], (size_t)w * 16);
+        }
+      uint4 *pdin = nullptr, *pdout = nullptr;
+      HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&pdin), pin.size() * 2));
+      ds.track(pdin);
+      HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&pdout), pout.size() * 2));
+      ds.track(pdout);
+      HIP_TRY(h, hipMemcpy(pdin, pin.data(), pin.size() * 2, hipMemcpyHostToDevice));
+      HIP_TRY(h, hipMemcpy(pdout, pout.data(), pout.size() * 2, hipMemcpyHostToDevice));
+      HIP_TRY(h, hipDeviceSynchronize());
+      if (residual)
+        HIP_TRY(h, (launch_feat_dma<true, true>(h->stream, Ls, pdin, g, 1, pdout, pdout, lrelu != 0, h->num_cu)));     // in place, as the pipeline
+      else
+        HIP_TRY(h, (launch_feat_dma<true, false>(h->stream, Ls, pdin, g, 1, pdout, nullptr, lrelu != 0, h->num_cu)));
+      HIP_TRY(h, hipStreamSynchronize(h->stream));
+      HIP_TRY(h, hipMemcpy(pout.data(), pdout, pout.size() * 2, hipMemcpyDeviceToHost));
+      for (int img = 0; img < 8; ++img)
+        for (int y = 0; y < Ho; ++y)
+          memcpy(&hout[((size_t)img * Ho + y) * Wo * 8], &pout[((size_t)img * phw + (size_t)(y + 1) * g.PW + 1) * 8], (size_t)Wo * 16);
+      for (size_t i = 0; i < pout.size(); ++i) {
+        const size_t sl = i / 8, y = (sl % phw) / g.PW, x = sl % g.PW;
+        const bool inside = y >= 1 && y < (size_t)Ho + 1 && x >= 1 && x < (size_t)Wo + 1;
+        if (!inside && (float)pout[i] != 0.f) {
+          set_err(h, "k_feat_x3s_dma wrote outside the image");
+          return SN_ERR_DEVICE;
+        }
+      }
+      host_from_slots(hout, 1, Ho, Wo, out);
+      return SN_OK;
     }
     if (dma) {      // zero-bordered input (two pixels), an output grid with a border of its own (3 pixels of slack)
       const SlotGeom gi = down_in_geom(Ho, Wo), go{Ho + 5, Wo + 7, 2, 3};
@@ -2381,6 +2660,54 @@ int sn_dbg_down0(sn_handle* h, const int8_t* in6, int h_px, int w, const float* 
   HIP_TRY(h, hipMemcpy(din, in6, nin, hipMemcpyHostToDevice));
   HIP_TRY(h, hipMemcpy(dbias, bias, kC * 4, hipMemcpyHostToDevice));
   HIP_TRY(h, launch_down0_f16(h->stream, L, dbias, din, h_px, w, 2, Ho, Wo, dout, h->num_cu));   // the pipeline's kernel
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  std::vector<_Float16> hs(nout * 2);
+  HIP_TRY(h, hipMemcpy(hs.data(), dout, nout * 4, hipMemcpyDeviceToHost));
+  host_from_slots(hs, 2, Ho, Wo, out);
+  return SN_OK;
+}
+
+int sn_dbg_round_kernels_f16(const float* w, int nkernels, float* out) {
+  if (!w || !out || nkernels < 0) return SN_ERR_ARG;
+  for (int k = 0; k < nkernels; ++k) {          // host only: no device needed
+    _Float16 q[9];
+    round_kernel_sum_preserving(w + (size_t)k * 9, q);
+    for (int t = 0; t < 9; ++t) out[(size_t)k * 9 + t] = (float)q[t];
+  }
+  return SN_OK;
+}
+
+int sn_dbg_compose_down01(const float* w0, const float* b0, const float* w1, const float* b1, float* weff, float* beff) {
+  if (!w0 || !b0 || !w1 || !b1 || !weff || !beff) return SN_ERR_ARG;
+  std::vector<double> we, be;
+  compose_down01(w0, b0, w1, b1, we, be);         // host only: no device needed
+  for (size_t i = 0; i < we.size(); ++i) weff[i] = (float)we[i];
+  for (size_t i = 0; i < be.size(); ++i) beff[i] = (float)be[i];
+  return SN_OK;
+}
+
+int sn_dbg_down01(sn_handle* h, const int8_t* in6, int h_px, int w, const float* w0, const float* b0, const float* w1,
+                  const float* b1, float* out) {
+  DevScope ds;      // frees every tracked device buffer on every return path
+  if (!h || !in6 || !w0 || !b0 || !w1 || !b1 || !out || h_px <= 0 || w <= 0) return SN_ERR_ARG;
+  int rc = check_device(h);
+  if (rc) return rc;
+  const int Hp = (h_px + 15) / 16 * 16, Wp = (w + 15) / 16 * 16, Ho = Hp / 4, Wo = Wp / 4;
+  Down01W L;
+  const HostLayer l0{w0, b0, kC, 3, 25}, l1{w1, b1, kC, kC, 25};
+  rc = upload_down01(h, l0, l1, &L);
+  ds.track(L.wfrag);
+  ds.track(L.bias);
+  if (rc) return rc;
+  int8_t* din = nullptr;
+  uint4* dout = nullptr;
+  const size_t nin = (size_t)6 * h_px * w, nout = (size_t)2 * kC * Ho * Wo;     // split slots: same bytes as fp32
+  HIP_TRY(h, dalloc(&din, nin));
+  ds.track(din);
+  HIP_TRY(h, dalloc(&dout, nout / 4));
+  ds.track(dout);
+  HIP_TRY(h, hipMemcpy(din, in6, nin, hipMemcpyHostToDevice));
+  HIP_TRY(h, launch_down01(h->stream, L, din, h_px, w, 2, Ho, Wo, dout, SlotGeom{Ho, Wo, 0, 0}, h->num_cu));   // the pipeline's kernels
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   std::vector<_Float16> hs(nout * 2);
   HIP_TRY(h, hipMemcpy(hs.data(), dout, nout * 4, hipMemcpyDeviceToHost));

@@ -110,3 +110,203 @@ def run_sharded(n: int, infer_shard: Callable[[int, int], torch.Tensor], dst: in
     begin, end = shard_range(n, rank, world)
     local = infer_shard(begin, end)
     return gather_to_root(local, shard_counts(n, world), dst)
+
+
+
+class PeerPullGather:
+    """The gather with NOTHING running on the root's compute units: every rank exports its two
+    output buffer sets ONCE (HIP IPC memory handles), and the root PULLS each peer's maps with plain device-to-device
+    copies on a copy stream of its own — between devices those are copy-engine (SDMA) transfers over the peer's xGMI
+    link: no receive kernel, no workgroups taken from the towers.  `AsyncGather` over RCCL stays the default (north_star:
+    "RCCL over xGMI only for the final gather"); this is the A/B form (`bench.py --gather ipc`): round 4's emulated root
+    ingress measured RCCL-style receive kernels at -9 % for the root at G = 8.
+
+    Two ranks on ONE GPU can open each other's handles, so the whole path runs on a one-GPU box (`--device-map 0,0`);
+    CPU tensors take the same protocol through files in /dev/shm (world-size-2 gloo test, tests/test_dist_gloo.py).
+
+    The caller writes step k's maps into `self.local[k % sets]` between begin() and end():
+        i = g.begin()                       # -> buffer set of this step
+        ... enqueue the step that writes g.local[i] on the current stream ...
+        g.end()
+        ...
+        g.flush()                           # after the last step; then, on the root:
+        maps = g.result(i)                  # [rank 0's set i, rank 1's, ...] as of the last step that used set i
+    Protocol (tiny control messages on a gloo group; no device collective at all):
+      peer   begin(k): wait for the root's "free k - sets" (its pull of the step that last wrote this set has completed)
+             end(k):   record an event behind step k; host-wait for step k-1's event, tell the root "ready k-1"
+      root   begin(k): host-wait for its pulls of step k - sets, tell every peer "free k - sets"
+             end(k):   take "ready k-1" from every peer, enqueue the pulls of step k-1's set on the copy stream
+    so a rank's host runs at most one step ahead of its device and the pulls of step k-1 overlap the compute of step k."""
+
+    def __init__(self, shape, dtype, device, dst: int = 0, sets: int = 2):
+        self.world, self.rank, self.dst = dist.get_world_size(), dist.get_rank(), dst
+        self.device = torch.device(device)
+        self.cuda = self.device.type == "cuda"
+        self.sets = sets
+        self.shape, self.dtype = tuple(int(d) for d in shape), dtype
+        self.ctl = dist.new_group(backend="gloo")            # control plane: eight bytes per step and peer
+        self._paths: List[str] = []
+        self.local = [self._alloc(s) for s in range(sets)]
+        handles = [self._export(s) for s in range(sets)]
+        table = [None] * self.world if self.rank == dst else None
+        dist.gather_object(handles, table, dst=dst, group=self.ctl)
+        self.is_root = self.rank == dst
+        self.peer_views = None
+        self.recv = None
+        self.copy_stream = None
+        if self.is_root:
+            self.peer_views = [[self._open(h) for h in hs] if r != dst else None for r, hs in enumerate(table)]
+            self.recv = [[torch.empty(self.shape, dtype=dtype, device=self.device) if r != dst else None
+                          for r in range(self.world)] for _ in range(sets)]
+            if self.cuda:
+                self.copy_stream = torch.cuda.Stream(device=self.device)
+        self.pull_ev = [torch.cuda.Event() if self.cuda else None for _ in range(sets)]
+        self.step_ev = [torch.cuda.Event() if self.cuda else None for _ in range(sets)]
+        self.k = 0                   # steps begun
+        self.ended = 0               # steps ended
+        self.announced = 0           # peer: "ready" messages sent / root: steps whose pulls are enqueued
+        self.released = 0            # root: "free" messages sent / peer: received
+        dist.barrier(group=self.ctl)
+
+    # ---- buffers and handles -------------------------------------------------------------------------------------
+    def _numel(self):
+        n = 1
+        for d in self.shape:
+            n *= d
+        return n
+
+    def _alloc(self, s):
+        if self.cuda:
+            return torch.empty(self.shape, dtype=self.dtype, device=self.device)
+        import os
+        path = f"/dev/shm/sn_peerpull_{os.getpid()}_{id(self) & 0xffffff:x}_{s}"
+        n = self._numel()
+        t = torch.from_file(path, shared=True, size=max(n, 1), dtype=self.dtype)[:n].view(self.shape)
+        self._paths.append(path)
+        return t
+
+    def _export(self, s):
+        if self.cuda:
+            from torch.multiprocessing.reductions import reduce_tensor
+            fn, args = reduce_tensor(self.local[s])          # hipIpcGetMemHandle behind torch's CUDA-IPC plumbing
+            return ("cuda", fn, args)
+        return ("file", self._paths[s])
+
+    def _open(self, h):
+        if h[0] == "cuda":
+            return h[1](*h[2])                               # hipIpcOpenMemHandle: a tensor on the PEER's device
+        n = self._numel()
+        return torch.from_file(h[1], shared=True, size=max(n, 1), dtype=self.dtype)[:n].view(self.shape)
+
+    # ---- control messages ----------------------------------------------------------------------------------------
+    def _send(self, value, to):
+        dist.send(torch.tensor([value], dtype=torch.int64), dst=to, group=self.ctl)
+
+    def _recv(self, frm):
+        t = torch.zeros(1, dtype=torch.int64)
+        dist.recv(t, src=frm, group=self.ctl)
+        return int(t[0])
+
+    def _peers(self):
+        return [r for r in range(self.world) if r != self.dst]
+
+    # ---- root side -----------------------------------------------------------------------------------------------
+    def _release_through(self, step):           # root: announce steps [released, step] free once their pulls are done
+        while self.released <= step:
+            s = self.released % self.sets
+            if self.cuda:
+                self.pull_ev[s].synchronize()
+            for r in self._peers():
+                self._send(self.released, r)
+            self.released += 1
+
+    def _pull_through(self, step):              # root: enqueue the pulls of steps [announced, step]
+        while self.announced <= step:
+            s = self.announced % self.sets
+            for r in self._peers():
+                got = self._recv(r)
+                if got != self.announced:
+                    raise RuntimeError(f"peer {r} announced step {got}, expected {self.announced}")
+            if self.cuda:
+                with torch.cuda.stream(self.copy_stream):
+                    for r in self._peers():
+                        self.recv[s][r].copy_(self.peer_views[r][s], non_blocking=True)
+                    self.pull_ev[s].record(self.copy_stream)
+            else:
+                for r in self._peers():
+                    self.recv[s][r].copy_(self.peer_views[r][s])
+            self.announced += 1
+
+    # ---- peer side -----------------------------------------------------------------------------------------------
+    def _announce_through(self, step):          # peer: tell the root steps [announced, step] have finished on the device
+        while self.announced <= step:
+            s = self.announced % self.sets
+            if self.cuda:
+                self.step_ev[s].synchronize()
+            self._send(self.announced, self.dst)
+            self.announced += 1
+
+    # ---- the per-step calls --------------------------------------------------------------------------------------
+    def begin(self) -> int:
+        k = self.k
+        if self.k != self.ended:
+            raise RuntimeError("begin() without end()")
+        if k >= self.sets:
+            if self.is_root:
+                self._release_through(k - self.sets)
+            else:
+                while self.released <= k - self.sets:
+                    got = self._recv(self.dst)
+                    if got != self.released:
+                        raise RuntimeError(f"root released step {got}, expected {self.released}")
+                    self.released += 1
+        self.k += 1
+        return k % self.sets
+
+    def end(self) -> None:
+        k = self.ended
+        if self.k != k + 1:
+            raise RuntimeError("end() without begin()")
+        if self.cuda:
+            self.step_ev[k % self.sets].record(torch.cuda.current_stream(self.device))
+        self.ended += 1
+        if k >= 1:
+            if self.is_root:
+                self._pull_through(k - 1)
+            else:
+                self._announce_through(k - 1)
+
+    def flush(self) -> None:
+        """After the last step: every announced / pulled / released counter catches up; the root's copy stream is idle."""
+        last = self.ended - 1
+        if last < 0:
+            return
+        if self.is_root:
+            self._pull_through(last)
+            self._release_through(last)
+        else:
+            self._announce_through(last)
+            while self.released <= last:
+                got = self._recv(self.dst)
+                if got != self.released:
+                    raise RuntimeError(f"root released step {got}, expected {self.released}")
+                self.released += 1
+
+    def result(self, s: int) -> Optional[List[torch.Tensor]]:
+        """Root, after flush(): the maps of the last step that used set s, rank order (its own set first-hand)."""
+        if not self.is_root:
+            return None
+        if self.cuda:
+            self.pull_ev[s].synchronize()
+        return [self.local[s] if r == self.dst else self.recv[s][r] for r in range(self.world)]
+
+    def close(self) -> None:
+        import os
+        self.peer_views = None
+        dist.barrier(group=self.ctl)          # nobody unlinks / frees while a peer may still map it
+        for p in self._paths:
+            try:
+                os.unlink(p)
+            except OSError:
+                pass
+        self._paths = []

@@ -215,7 +215,8 @@ int sn_get_dominant_kernel(sn_handle *h, char *name, size_t name_cap, int *launc
  * 5x5 stride 2), bit 2 (with bit 1) = run it on split-slot tensors (hi/lo fp16, the fp16 modes' low-resolution
  * activation format) through the weights-stationary kernel; the hook converts to and from that layout; bit 3 = the
  * fp32 tower kernel k_ref_conv_f32 (cin 32, 3x3, w % 4 == 0) instead of the generic fp32 kernel; bit 4 (with bits 1
- * and 2, 5x5 stride 2, no residual) = the down-conv kernel of the zero-bordered tensors (k_down_x3s_dma). */
+ * and 2) = the kernel of the zero-bordered tensors: k_down_x3s_dma (5x5 stride 2, no residual) or k_feat_x3s_dma (3x3,
+ * residual allowed: added in place as the feature tower does). */
 int sn_dbg_conv2d(sn_handle *h, const float *in, int cin, int h_px, int w, const float *wt,
                   const float *bias, int k, int stride, int dil, int lrelu, const float *residual,
                   float *out);
@@ -224,6 +225,22 @@ int sn_dbg_conv2d(sn_handle *h, const float *in, int cin, int h_px, int w, const
  * tc = 32 or 64 selects the tile width */
 int sn_dbg_down0(sn_handle *h, const int8_t *in6, int h_px, int w, const float *wt, const float *bias, int tc,
                  float *out);
+/* The rounding SN_PREC_F16 applies to the 3x3 weights of its refinement towers at model load (host only, no device):
+ * w [nkernels][9] fp32 -> out [nkernels][9], every value one of the two fp16 numbers enclosing its input, chosen per kernel
+ * so that the SUM of the nine rounding errors is smallest (csrc/stereonet_hip.hip round_kernel_sum_preserving;
+ * SN_W_ROUND=rne restores round-to-nearest in the engine). */
+int sn_dbg_round_kernels_f16(const float *w, int nkernels, float *out);
+/* The first TWO down-convs (3->32 and 32->32, both 5x5 stride 2, no activation between them) folded into one 13x13
+ * stride-4 convolution, as the fp16 modes run them (csrc/sn_down01.hpp; SN_DOWN01=0 restores the two kernels).
+ * sn_dbg_compose_down01 is the host-side fold alone (no device): w0 [32][3][5][5], b0 [32], w1 [32][32][5][5], b1 [32]
+ * -> weff [9][32][3][13][13], beff [9][32]; class = 3 * row class + column class, each {first, inner, last} row / column
+ * of the quarter-resolution map (down-conv 1's zero padding of the half-resolution map drops taps there).
+ * sn_dbg_down01 runs both eyes through the pipeline's two kernels: in6 int8 [6][h][w] -> out [2][32][ho][wo] with
+ * ho/wo = ceil16(h|w)/4. */
+int sn_dbg_compose_down01(const float *w0, const float *b0, const float *w1, const float *b1, float *weff,
+                          float *beff);
+int sn_dbg_down01(sn_handle *h, const int8_t *in6, int h_px, int w, const float *w0, const float *b0,
+                  const float *w1, const float *b1, float *out);
 /* the refinement input conv (4->32, 3x3, LeakyReLU) through the fp16-MFMA kernel of the fp16 modes:
  * disp_low fp32 [hp/16][wp/16] (full-resolution px / 16 units as the soft-argmin head writes it), in6 int8 [6][h][w],
  * wt [32][4][3][3]; out fp32 [32][hp][wp] (hp/wp = ceil16) read back from the fp16 NCHW8c tensor(s); split != 0

@@ -90,3 +90,45 @@ def test_shard_ranges_cover_everything():
             assert max(shard_counts(n, world)) - min(shard_counts(n, world)) <= 1
     with pytest.raises(ValueError):
         shard_range(4, 2, 2)
+
+
+def _pull_worker(rank, world, port, steps):
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from hobot_stereonet_amd import dist as sdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = sdist.PeerPullGather((3, 4, 5), torch.int32, "cpu", dst=0)
+    seen = {}
+    for k in range(steps):
+        i = g.begin()
+        assert i == k % 2
+        if rank == 0 and k >= 2:
+            # begin(k) has released step k-2: its pull is complete, and nothing newer has been pulled into that set yet
+            got = g.result(i)
+            assert [int(t[0, 0, 0]) for t in got[1:]] == [r * 1000 + (k - 2) for r in range(1, world)]
+            seen[k - 2] = True
+        g.local[i].fill_(rank * 1000 + k)           # "the engine writes this step's maps"
+        g.end()
+    g.flush()
+    if rank == 0:
+        for s in range(min(2, steps)):
+            last = max(k for k in range(steps) if k % 2 == s)
+            got = g.result(s)
+            assert len(got) == world and got[0] is g.local[s]
+            assert [int(t[2, 3, 4]) for t in got] == [r * 1000 + last for r in range(world)]
+        assert len(seen) == max(0, steps - 2)
+    else:
+        assert g.result(0) is None
+    g.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,steps", [(2, 5), (3, 4), (2, 1)])
+def test_peer_pull_gather_protocol(world, steps):
+    """PeerPullGather (the zero-CU gather: the root pulls every peer's exported buffer sets) on CPU tensors shared through
+    /dev/shm: double buffering, the ready / free handshake, flush, result order."""
+    mp.spawn(_pull_worker, args=(world, _free_port(), steps), nprocs=world, join=True)

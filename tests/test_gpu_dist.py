@@ -40,6 +40,24 @@ def test_two_ranks_on_one_gpu_real_engine():
 
 
 @pytest.mark.gpu
+def test_two_ranks_on_one_gpu_peer_pull_gather():
+    """`--gather ipc` (dist.PeerPullGather): rank 1 exports its two output buffer sets as HIP IPC handles, rank 0 opens them and
+    PULLS rank 1's maps with device-to-device copies on its own copy stream (no collective, no receive kernel); two ranks on
+    one GPU can open each other's handles, so the whole path — export, open, ready / free handshake, pulls overlapping the
+    next step, flush — runs here with the real engine, and rank 0 verifies the pulled maps against its own inference of rank
+    1's inputs bit for bit, after the timed steps AND after the further steps of the long measurement."""
+    r, lines = _run(["--gpus", "2", "--dist-backend", "gloo", "--device-map", "0,0", "--gather", "ipc", "--batch", "4", "--steps", "5",
+                     "--warmup", "2", "--no-cpu-baseline", "--no-end-to-end"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["world_size_seen"] == 2
+    assert d["verified"] is True and "gathered maps of ranks 1..1" in d["verification"]
+    assert "ipc-peer-pull" in d["config"]["parallelism"] and d["config"]["devices"] == [0, 0]
+    assert d["value"] > 0
+
+
+@pytest.mark.gpu
 def test_shared_gpu_needs_gloo():
     r, lines = _run(["--gpus", "2", "--device-map", "0,0", "--batch", "2", "--steps", "1"])
     assert r.returncode != 0 and not lines

@@ -54,8 +54,13 @@ def test_forward_small_f16(model_factory, oracle, golden_net, weights_blob, name
     with api.StereoNetHIP(model_factory(w, h, d), precision=api.PREC_F16) as eng:
         disp, raw = eng.infer(x)
         low = eng.dbg_read("disp_low").reshape((h + 15) // 16, (w + 15) // 16)
+        cost = eng.dbg_read("cost").reshape(d // 16, (h + 15) // 16, (w + 15) // 16)
     odisp, _, olow = oracle.forward(weights_blob, x, d)
-    assert np.abs(low - olow).max() < 1e-4            # the low-resolution branch stays fp32
+    assert np.abs(low - olow).max() < 1e-4            # the low-resolution branch: 22-bit split operands
+    # the matching costs themselves: the output conv of the aggregation network rides on the last layer's epilogue as a
+    # taps-as-M contraction (k_agg_x3s_dma HEADP) and k_softargmin_p sums its 27 shifted partial sums
+    gcost = golden_net[name + ".cost"]
+    assert np.abs(cost - gcost).max() < 2e-4 * max(1.0, np.abs(gcost).max())
     epe = float(np.abs(disp - odisp).mean())
     assert epe < EPE_TOL, epe
     assert np.abs(disp - golden_net[name + ".disp"]).mean() < EPE_TOL
@@ -224,6 +229,34 @@ def test_down0_f16_kernel(eng16, oracle, h, w, tc):
         ref = oracle.conv2d(xin, wt, b, 2, 2, 1)
         assert ref.shape == got[eye].shape
         assert np.abs(got[eye] - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("h,w", [(16, 16), (32, 64), (64, 96), (96, 160), (52, 100), (52, 102), (90, 131), (375, 1242),
+                                 (720, 1280)])
+def test_down01_folded_kernels(eng16, oracle, h, w):
+    """The first TWO down-convs as one 13x13 stride-4 convolution (csrc/sn_down01.hpp: k_down01_f16 for the inner weight
+    class, k_down01_border for the first / last row and column): the int8 input / 128 is exact in fp16 and the folded
+    weights are split hi/lo (22 bits), so the result must match the fp32 oracle of the two layers to fp32 round-off of an
+    800-term sum of 75-term sums.  Ragged sizes exercise the unaligned / per-byte staging, partial tiles and the zero
+    region right of / below the image."""
+    rng = np.random.default_rng(h * 11 + w)
+    x = rng.integers(-128, 128, (6, h, w), dtype=np.int8)
+    w0 = (rng.standard_normal((32, 3, 5, 5)) / 8.0).astype(np.float32)
+    b0 = rng.standard_normal(32).astype(np.float32)
+    w1 = (rng.standard_normal((32, 32, 5, 5)) / 28.0).astype(np.float32)
+    b1 = rng.standard_normal(32).astype(np.float32)
+    got = eng16.dbg_down01(x, w0, b0, w1, b1)
+    hp, wp = (h + 15) // 16 * 16, (w + 15) // 16 * 16
+    assert got.shape == (2, 32, hp // 4, wp // 4)
+    for eye in range(2):
+        xin = np.zeros((3, hp, wp), np.float32)               # the padded region is zero input (as in the pipeline)
+        xin[:, :h, :w] = x[3 * eye:3 * eye + 3].astype(np.float32) / 128.0
+        ref = oracle.conv2d(oracle.conv2d(xin, w0, b0, 2, 2, 1), w1, b1, 2, 2, 1)
+        assert ref.shape == got[eye].shape
+        err = np.abs(got[eye] - ref)
+        tol = 3e-5 * max(1.0, np.abs(ref).max())
+        assert err[:, 1:-1, 1:-1].max() <= tol, "inner class"
+        assert err.max() <= tol, "border classes"
 
 
 @pytest.mark.parametrize("h,w,split", [(32, 64, False), (64, 96, True), (52, 100, False), (90, 130, True),

@@ -171,7 +171,14 @@ np.save(sys.argv[3], disp)
                                        ({"SN_TOWER_STREAMS": "2", "SN_TAIL_FUSE": "0"}, True), ({"SN_STREAM_WGS": "100"}, True),
                                        ({"SN_STREAM_PRIORITY": "1"}, True),
                                        # aggregation layers / down-convs on the plain tensors (k_conv_x3s) instead of the zero-bordered ones
-                                       ({"SN_AGG_DMA": "0"}, True), ({"SN_DOWN_DMA": "0"}, True), ({"SN_AGG_DMA": "0", "SN_DOWN_DMA": "0"}, True)])
+                                       ({"SN_AGG_DMA": "0"}, True), ({"SN_DOWN_DMA": "0"}, True), ({"SN_AGG_DMA": "0", "SN_DOWN_DMA": "0"}, True),
+                                       ({"SN_FEAT_DMA": "0"}, True),
+                                       # the first two down-convs as two kernels instead of the folded 13x13 stride-4 conv (another summation
+                                       # order of the same linear map: not bit-identical)
+                                       ({"SN_DOWN01": "0"}, False), ({"SN_DOWN01": "0", "SN_DOWN_DMA": "0"}, False),
+                                       # the aggregation network's output conv as its own kernel on the 32-channel volume (k_head_softargmin)
+                                       # instead of the taps-as-M contraction in the last layer's epilogue + k_softargmin_p
+                                       ({"SN_HEAD_FOLD": "0"}, False), ({"SN_HEAD_FOLD": "0", "SN_AGG_DMA": "0"}, False)])
 def test_diagnostic_switches_run_the_same_network(model_factory, oracle, weights_blob, tmp_path, env, exact):
     """The library's diagnostic environment switches select other schedules / kernel pairings of the
     SAME arithmetic: stream layout switches must be bit-identical to the default, kernel pairings within the EPE bar."""

@@ -303,7 +303,7 @@ def test_baseline_config_c5_kitti_1242x375_d256(model_factory, oracle, weights_b
     assert (raw == np.rint(disp * inv_q).astype(np.int32)).all()
 
 
-@pytest.mark.parametrize("h,w", [(45, 80), (34, 60), (24, 78), (64, 96), (9, 33)])
+@pytest.mark.parametrize("h,w", [(45, 80), (34, 60), (24, 78), (64, 96), (9, 33), (68, 128), (3, 5)])
 def test_lowres_split_conv3x3(small_engine, oracle, h, w):
     """Low-resolution 3x3 layers of the fp16 modes: 22-bit split operands (k_conv_x3s) on hi/lo fp16 slot tensors (the
     production format; the hook converts), so the input is rounded to 22 bits and the output carries one more 22-bit
@@ -320,6 +320,13 @@ def test_lowres_split_conv3x3(small_engine, oracle, h, w):
     ref2 = np.where(v > 0, v, v * np.float32(0.2))
     got2 = small_engine.dbg_conv2d(x, wt, b, 3, 1, 1, lrelu=True, residual=res, x3=True, slots=True)
     assert rel_err(got2, ref2) < 4e-6
+    # the same layer on zero-bordered tensors (k_feat_x3s_dma: LDS-DMA staging, every wave holds both channel chunks, one
+    # barrier per tile): the two chunks' sums are formed separately and added as k_conv_x3s's two K halves are, so the
+    # same bits — plain, and with the in-place residual + activation
+    got_dma = small_engine.dbg_conv2d(x, wt, b, 3, 1, 1, x3=True, slots=True, dma=True)
+    assert np.array_equal(got_dma, got)
+    got2_dma = small_engine.dbg_conv2d(x, wt, b, 3, 1, 1, lrelu=True, residual=res, x3=True, slots=True, dma=True)
+    assert np.array_equal(got2_dma, got2)
 
 
 @pytest.mark.parametrize("d,h,w", [(3, 4, 6), (12, 45, 80), (16, 24, 78), (1, 8, 16), (6, 23, 40), (12, 90, 160)])
