@@ -126,6 +126,7 @@ __device__ __forceinline__ void split_store4(const float (&v)[4], char* hi_ptr, 
 // Output: split-slot tensor [img][4 blocks][hi | lo][go.PH][go.PW], pixel (y, x) at (y + go.py, x + go.px) — the input
 // layout of k_down_x3s_dma (or plain: {Ho, Wo, 0, 0}).  Border pixels (first / last row and column) are not stored.
 // ------------------------------------------------------------------------------------------
+template <bool W4>      // W % 4 == 0: every staged dword is wholly inside or outside its image row
 __global__ __launch_bounds__(256, 1) void k_down01_f16(const int8_t* __restrict__ in6, int H, int W,
                                                     const uint4* __restrict__ wfrag,   // inner class: [39][hi|lo][64]
                                                     const float* __restrict__ bias,    // inner class: [32]
@@ -180,70 +181,105 @@ __global__ __launch_bounds__(256, 1) void k_down01_f16(const int8_t* __restrict_
     ty = (int)tyu;
     tx = (int)txu;
   };
+  // Staging pipeline, all of it inside the MFMA loop of a tile (one wave per SIMD: whatever is not interleaved with the
+  // MFMAs is exposed): even K-steps convert one dword of the window of tile i+1 (in registers since the previous tile) into
+  // the other LDS buffer, odd K-steps request that dword of tile i+2 (17 per thread).  Loads are unconditional:
+  // an element outside the image (27 % of the tiles touch an edge at 1280 x 720) reads the image's first dword instead and
+  // is zeroed when it is converted (`zmask`); that needs W % 4 == 0, so that a dword is wholly inside or outside a row.
+  // Otherwise (W = 1242) interior tiles take the same path unchecked and edge tiles a checked one behind the loop.
   uint32_t pre[T::NLOAD];
-  // Two straight-line forms, chosen per tile (uniform): a window that lies inside the image is 17 unconditional dword
-  // loads per thread whose results are first touched by commit(), AFTER the tile's MFMAs; a window that crosses an image
-  // edge takes the checked path and waits for its loads before it returns.  (One loop with the test inside left hipcc
-  // with loads pending on some paths and their registers reused on others: it put s_waitcnt vmcnt(0) in front of the first
-  // MFMA of every tile, i.e. the whole latency of the next tile's loads was exposed, 29 times per workgroup.)
-  auto fetch = [&](int tile) {
+  unsigned zmask = 0;                       // bit e: element e of `pre` lies outside the image
+  constexpr bool w4 = W4;                   // (a straight-line loop body: hipcc then counts the loads in flight across
+                                            // the back edge exactly instead of waiting for all of them, stores included)
+  struct Win {                              // uniform: the window of the tile being fetched
+    const int8_t* base;                     // the eye's three planes
+    int iy0, xs;
+    bool nochk, slow;
+  };
+  auto fetch_setup = [&](int tile) -> Win {
     int img, ty, tx;
     decode(tile, img, ty, tx);
     const int n = img >> 1, eye = img & 1;
-    const int iy0 = 4 * ty * T::TR - 6, xs = 4 * tx * T::TC - 8;              // window origin (xs % 4 == 0)
-    const int8_t* const base = in6 + ((size_t)n * 6 + eye * 3) * H * (size_t)W;      // uniform
-    const bool inside = iy0 >= 0 && iy0 + T::ROWS <= H && xs >= 0 && xs + 4 * T::NDW <= W;      // uniform
-    if (inside) {
-      const int8_t* const org = base + (size_t)iy0 * W + xs;
+    Win w;
+    w.iy0 = 4 * ty * T::TR - 6;
+    w.xs = 4 * tx * T::TC - 8;                                                 // window origin (xs % 4 == 0)
+    w.base = in6 + ((size_t)n * 6 + eye * 3) * H * (size_t)W;
+    const bool inside = w.iy0 >= 0 && w.iy0 + T::ROWS <= H && w.xs >= 0 && w.xs + 4 * T::NDW <= W;
+    w.nochk = inside;
+    w.slow = !w4 && !inside;
+    return w;
+  };
+  // -> bit e of the zero mask
+  // `lz` = a zero the compiler cannot see through, made once per tile: pk[e] | lz keeps the unpacking of the staging table
+  // inside the tile loop (hoisted, the 4 x 17 unpacked values spill) without a volatile asm per element, which the
+  // machine scheduler would not move anything across
+  auto fetch_one = [&](const Win& w, int e, unsigned lz) -> unsigned {
+    const unsigned p = pk[e] | lz;
+    const int r = (p >> 16) & 63, q = (p >> 22) & 63, c = (p >> 28) & 3;
+    const int y = w.iy0 + r, x = w.xs + 4 * q;
+    // (rounds past the window's last dword re-read its first one; commit_one() sends them to a spare slot)
+    const bool ok = w.nochk | ((unsigned)y < (unsigned)H && x >= 0 && x < W);
+    const unsigned off = ok ? (unsigned)((c * H + y) * W + x) : 0u;             // < 2^32: one eye's three planes
+    __builtin_memcpy(&pre[e], w.base + off, 4);
+    return ok ? 0u : 1u << e;
+  };
+  auto fetch_slow = [&](const Win& w) {     // checked, byte-wise where a dword straddles the right edge; waits for its loads
 #pragma unroll
-      for (int e = 0; e < T::NLOAD; ++e) {
-        unsigned p = pk[e];
-        asm volatile("" : "+v"(p));                   // keep the unpacking inside the tile loop
-        const unsigned r = (p >> 16) & 63u, q = (p >> 22) & 63u, c = (p >> 28) & 3u;
-        // (rounds past the window's last dword re-read its first one; commit() drops them)
-        const unsigned off = (c * (unsigned)H + r) * (unsigned)W + 4u * q;      // < 2^32: one image plane triple
-        __builtin_memcpy(&pre[e], org + off, 4);
-      }
-    } else {
+    for (int e = 0; e < T::NLOAD; ++e) {
+      unsigned p = pk[e];
+      asm volatile("" : "+v"(p));
+      const int r = (p >> 16) & 63, q = (p >> 22) & 63, c = (p >> 28) & 3;
+      const int y = w.iy0 + r, x = w.xs + 4 * q;
+      uint32_t v = 0;
+      if ((p >> 31) && (unsigned)y < (unsigned)H) {
+        const int8_t* const row = w.base + ((size_t)c * H + y) * (size_t)W;
+        if (x >= 0 && x + 3 < W) {
+          __builtin_memcpy(&v, row + x, 4);
+        } else {
 #pragma unroll
-      for (int e = 0; e < T::NLOAD; ++e) {
-        unsigned p = pk[e];
-        asm volatile("" : "+v"(p));
-        const int r = (p >> 16) & 63, q = (p >> 22) & 63, c = (p >> 28) & 3;
-        const int y = iy0 + r, x = xs + 4 * q;
-        uint32_t v = 0;
-        if ((p >> 31) && (unsigned)y < (unsigned)H) {
-          const int8_t* const row = base + ((size_t)c * H + y) * (size_t)W;
-          if (x >= 0 && x + 3 < W) {
-            __builtin_memcpy(&v, row + x, 4);
-          } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-              if ((unsigned)(x + k) < (unsigned)W) v |= (uint32_t)(uint8_t)row[x + k] << (8 * k);
-          }
+          for (int k = 0; k < 4; ++k)
+            if ((unsigned)(x + k) < (unsigned)W) v |= (uint32_t)(uint8_t)row[x + k] << (8 * k);
         }
-        pre[e] = v;
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // nothing of the checked path stays in flight
+      pre[e] = v;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // nothing of the checked path stays in flight
   };
   // one staged dword -> four halves -> LDS; only the last round has threads without an element
-  auto commit_one = [&](_Float16* buf, int e) {
-    unsigned p = pk[e];
-    asm volatile("" : "+v"(p));
+  auto commit_one = [&](_Float16* buf, int e, unsigned zm, unsigned lz) {
+    const unsigned p = pk[e] | lz;
     const unsigned off = (e < T::NLOAD - 1 || (p >> 31)) ? (p & 0xffffu) : (unsigned)(2 * T::BUF * 2);      // spare slot behind the buffers
-    *reinterpret_cast<half4*>(reinterpret_cast<char*>(buf) + off) = i8x4_to_f16(pre[e]);
+    const uint32_t v = (zm >> e) & 1u ? 0u : pre[e];
+    *reinterpret_cast<half4*>(reinterpret_cast<char*>(buf) + off) = i8x4_to_f16(v);
   };
   static_assert(T::NLOAD * 256 - 3 * T::ROWS * T::NDW < 256, "only the last staging round is partial");
+  auto opaque_zero = []() {
+    unsigned z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    return z;
+  };
+  auto fetch_all = [&](int tile) -> unsigned {
+    const Win w = fetch_setup(tile);
+    const unsigned lz = opaque_zero();
+    unsigned zm = 0;
+    if (!W4 && w.slow) {
+      fetch_slow(w);
+    } else {
+#pragma unroll
+      for (int e = 0; e < T::NLOAD; ++e) zm |= fetch_one(w, e, lz);
+    }
+    return zm;
+  };
 
   // XCD-aware persistent schedule (as k_conv_x3s): each XCD walks its own contiguous band of tiles
   const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, nlb = gridDim.x >> 3;
   const int t_end = (int)((long)(xcd + 1) * total / 8);
   int tile = (int)((long)xcd * total / 8) + lb;
   if (tile >= t_end) return;
-  fetch(tile);
+  zmask = fetch_all(tile);
 #pragma unroll
-  for (int e = 0; e < T::NLOAD; ++e) commit_one(s_x, e);
+  for (int e = 0; e < T::NLOAD; ++e) commit_one(s_x, e, zmask, opaque_zero());
+  zmask = fetch_all(tile + nlb < t_end ? tile + nlb : tile);          // the window the first iteration converts
   __syncthreads();
   int cur = 0;
 
@@ -251,12 +287,15 @@ __global__ __launch_bounds__(256, 1) void k_down01_f16(const int8_t* __restrict_
   const unsigned lane_lds = (unsigned)((4 * (2 * wave) * T::PITCH + 4 * j + 8 * g) * 2);
   const unsigned io_lane = (unsigned)j * 16u + (unsigned)g * 8u;
   constexpr int PD = 2;                                         // K-steps of B fragments in flight
+  static_assert(2 * T::NLOAD <= T::NK, "one conversion and one request every other K-step");
   auto koff = [](int t) { return ((t / T::KW) * T::ROWS + (t % T::KW)) * T::PITCH * 2; };
 
   for (; tile < t_end; tile += nlb) {
-    const int nxt = tile + nlb;
-    const int more = __builtin_amdgcn_readfirstlane(nxt < t_end ? 1 : 0);
-    if (more) fetch(nxt);
+    const int nxt2 = tile + 2 * nlb;
+    const Win w2 = fetch_setup(nxt2 < t_end ? nxt2 : tile);     // no such tile: this one again (harmless, no branch per K-step)
+    const bool slow2 = w2.slow;                                 // uniform
+    unsigned zm2 = 0;
+    const unsigned lz = opaque_zero();
     const char* bufc = reinterpret_cast<const char*>(s_x + cur * T::BUF) + lane_lds;
     auto bfrag = [&](int t, int s) {
       const uint2* p = reinterpret_cast<const uint2*>(bufc + koff(t) + s * 4 * T::PITCH * 2);
@@ -277,16 +316,30 @@ __global__ __launch_bounds__(256, 1) void k_down01_f16(const int8_t* __restrict_
         xb[(t + PD) % (PD + 1)][0] = bfrag(t + PD, 0);
         xb[(t + PD) % (PD + 1)][1] = bfrag(t + PD, 1);
       }
-      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const half8 x = *reinterpret_cast<const half8*>(&xb[t % (PD + 1)][s]);
         acc0[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t], x, t == 0 ? bv : acc0[s], 0, 0, 0);
         acc1[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[t], x, t == 0 ? zero : acc1[s], 0, 0, 0);
       }
-      // the next tile's window goes to the other buffer inside the second half of the loop: its loads were issued ~20
-      // K-steps (~2500 matrix cycles) ago, and the conversion's VALU work runs in the shadow of the MFMAs
-      if (t >= T::NK - T::NLOAD - 2 && t < T::NK - 2) commit_one(s_x + (cur ^ 1) * T::BUF, t - (T::NK - T::NLOAD - 2));
+      // element e: converted (tile i+1 -> the other buffer) at K-step 2 e, requested again (tile i+2 -> the same register)
+      // at K-step 2 e + 1 — every load has a whole tile's MFMAs to land, the VALU work is spread evenly over the loop
+      if ((t & 1) == 0 && t / 2 < T::NLOAD) commit_one(s_x + (cur ^ 1) * T::BUF, t / 2, zmask, lz);
+      if ((t & 1) == 1 && t / 2 < T::NLOAD && (W4 || !slow2)) zm2 |= fetch_one(w2, t / 2, lz);
+      // Issue order inside the K-step (in-order issue, one wave per SIMD: an MFMA behind an MFMA waits for the matrix pipe,
+      // and whatever stands behind THAT waits with it): one MFMA, then a share of the step's other instructions, four
+      // times — the staging arithmetic runs in the 32 cycles each MFMA occupies the pipe instead of after all four.
+      // (0x008 MFMA, 0x100 DS read, 0x006 VALU | SALU, 0x230 VMEM read | DS write)
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x006, 5, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x006, 7, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x006, 7, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x006, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x230, 1, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     {
@@ -308,6 +361,8 @@ __global__ __launch_bounds__(256, 1) void k_down01_f16(const int8_t* __restrict_
         }
       }
     }
+    if (!W4 && slow2) fetch_slow(w2);                           // (W % 4 != 0 only) an edge window, behind the loop
+    zmask = zm2;
     lds_barrier();
     cur ^= 1;
   }
@@ -369,8 +424,19 @@ __global__ __launch_bounds__(256) void k_down01_border(const int8_t* __restrict_
   const int xw = 4 * ox - 8 + 8 * g;
   // one input channel (13 K-steps) at a time: its 26 window dwords and 26 A fragments are requested together, so the wave
   // pays the memory latency three times instead of 39
-  auto load4 = [&](const int8_t* row, int x) -> uint32_t {      // four window columns x .. x + 3 of one image row
+  // W % 4 == 0 (uniform): a dword is wholly inside or outside its row, so the load is unconditional (an outside one reads
+  // the plane's first dword) and the selection happens when the value is used — no branch, nothing waits inside the
+  // request phase.  Otherwise the checked, byte-wise form.
+  const bool w4 = (W & 3) == 0;
+  auto load4 = [&](const int8_t* row, int x, bool row_ok, bool& ok) -> uint32_t {      // window columns x .. x + 3 of one image row
     uint32_t v = 0;
+    if (w4) {
+      ok = row_ok && x >= 0 && x < W;
+      __builtin_memcpy(&v, ok ? row + x : base, 4);
+      return v;
+    }
+    ok = true;
+    if (!row_ok) return 0u;
     if (x >= 0 && x + 3 < W) {
       __builtin_memcpy(&v, row + x, 4);
     } else if (x + 3 >= 0 && x < W) {
@@ -384,21 +450,23 @@ __global__ __launch_bounds__(256) void k_down01_border(const int8_t* __restrict_
   for (int c = 0; c < 3; ++c) {
     uint32_t v0[T::KW], v1[T::KW];
     uint4 fa[T::KW], fb[T::KW];
+    unsigned keep0 = 0, keep1 = 0;
 #pragma unroll
     for (int u = 0; u < T::KW; ++u) {
       const int y = 4 * oy - 6 + u;
-      v0[u] = v1[u] = 0;
-      if ((unsigned)y < (unsigned)H) {
-        const int8_t* row = base + ((size_t)c * H + y) * (size_t)W;
-        v0[u] = load4(row, xw);
-        v1[u] = load4(row, xw + 4);
-      }
+      const bool row_ok = (unsigned)y < (unsigned)H;
+      const int8_t* row = base + ((size_t)c * H + (row_ok ? y : 0)) * (size_t)W;
+      bool k0, k1;
+      v0[u] = load4(row, xw, row_ok, k0);
+      v1[u] = load4(row, xw + 4, row_ok, k1);
+      keep0 |= k0 ? 1u << u : 0u;
+      keep1 |= k1 ? 1u << u : 0u;
       fa[u] = wsrc[(2 * (c * T::KW + u)) * 64];
       fb[u] = wsrc[(2 * (c * T::KW + u) + 1) * 64];
     }
 #pragma unroll
     for (int u = 0; u < T::KW; ++u) {
-      const half4 a = i8x4_to_f16(v0[u]), b = i8x4_to_f16(v1[u]);
+      const half4 a = i8x4_to_f16((keep0 >> u) & 1u ? v0[u] : 0u), b = i8x4_to_f16((keep1 >> u) & 1u ? v1[u] : 0u);
       half8 x;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {

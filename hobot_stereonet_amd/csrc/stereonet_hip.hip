@@ -431,16 +431,22 @@ int upload_down01(sn_handle* h, const HostLayer& l0, const HostLayer& l1, Down01
 hipError_t launch_down01(hipStream_t st, const Down01W& L, const int8_t* in6, int H, int W, int nimg, int Ho, int Wo,
                          uint4* out, const SlotGeom& og, int num_cu) {
   using T = Down01;
-  hipError_t e = ensure_lds_attr(k_down01_f16, T::LDS_BYTES);
+  const bool w4 = (W % 4) == 0;
+  hipError_t e = w4 ? ensure_lds_attr(k_down01_f16<true>, T::LDS_BYTES) : ensure_lds_attr(k_down01_f16<false>, T::LDS_BYTES);
   if (e != hipSuccess) return e;
   const int tiles_x = (Wo + T::TC - 1) / T::TC, tiles_y = (Ho + T::TR - 1) / T::TR;
   const int total = tiles_x * tiles_y * nimg;
   int blocks = num_cu / 8 * 8;                    // one workgroup per CU (register budget), whole XCD bands
   while (blocks > 8 && blocks / 8 > (total + 7) / 8) blocks -= 8;
   const int al4 = (W % 4 == 0) && (reinterpret_cast<uintptr_t>(in6) % 4 == 0);
-  hipLaunchKernelGGL(k_down01_f16, dim3(blocks), dim3(256), T::LDS_BYTES, st, in6, H, W,
-                     L.wfrag + (size_t)T::INNER * T::NK * 2 * 64, L.bias + T::INNER * kC, out, Ho, Wo, tiles_x, tiles_y, nimg,
-                     al4, og.PH, og.PW, og.py, og.px);
+  if (w4)
+    hipLaunchKernelGGL(k_down01_f16<true>, dim3(blocks), dim3(256), T::LDS_BYTES, st, in6, H, W,
+                       L.wfrag + (size_t)T::INNER * T::NK * 2 * 64, L.bias + T::INNER * kC, out, Ho, Wo, tiles_x, tiles_y, nimg,
+                       al4, og.PH, og.PW, og.py, og.px);
+  else
+    hipLaunchKernelGGL(k_down01_f16<false>, dim3(blocks), dim3(256), T::LDS_BYTES, st, in6, H, W,
+                       L.wfrag + (size_t)T::INNER * T::NK * 2 * 64, L.bias + T::INNER * kC, out, Ho, Wo, tiles_x, tiles_y, nimg,
+                       al4, og.PH, og.PW, og.py, og.px);
   const int per_img = 4 + 2 * ((Wo - 2 + 31) / 32) + 2 * ((Ho - 2 + 31) / 32);
   hipLaunchKernelGGL(k_down01_border, dim3((per_img * nimg + 3) / 4), dim3(256), 0, st, in6, H, W, L.wfrag, L.bias, out, Ho, Wo,
                      nimg, og.PH, og.PW, og.py, og.px);
