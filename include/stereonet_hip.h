@@ -70,8 +70,13 @@ enum {
   SN_PREC_F16X3 = 1,     /* refinement tower on fp16 MFMA with hi/lo operand split (3 MFMAs per   */
                          /* product, ~2^-22 relative): fp32-class accuracy at 3/16 of the fp32    */
                          /* MFMA cost; activations stored as two fp16 tensors                     */
-  SN_PREC_F16 = 2,       /* refinement tower on plain fp16 MFMA operands; low-resolution branch on */
-                         /* 22-bit split fp16 operands (the default, and what bench.py measures)  */
+  SN_PREC_F16 = 2,       /* refinement tower on plain fp16 MFMA operands (3x3 weights rounded per  */
+                         /* kernel so that every kernel's tap sum survives: no coherent offset);  */
+                         /* low-resolution branch on 22-bit split fp16 operands (the default, and */
+                         /* what bench.py measures).  Envelope: EPE vs the fp32 oracle < 1e-3 px   */
+                         /* while the refinement adds up to ~2-3 px on average (8 weight draws,   */
+                         /* profiles/r05_epe_sensitivity_*.txt); the error then grows linearly    */
+                         /* with the residual: larger ones belong to SN_PREC_F16X3                */
   SN_PREC_FP32 = 3       /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere                  */
 };
 
@@ -225,6 +230,13 @@ int sn_dbg_conv2d(sn_handle *h, const float *in, int cin, int h_px, int w, const
  * tc = 32 or 64 selects the tile width */
 int sn_dbg_down0(sn_handle *h, const int8_t *in6, int h_px, int w, const float *wt, const float *bias, int tc,
                  float *out);
+/* The six residual blocks of the feature tower (fp16 modes: split operands on zero-bordered split-slot tensors) on caller
+ * data: in [nimg][32][h][w] -> out (same shape) = block^6(in), block(x) = lrelu(x + conv2(lrelu(conv1(x)))), both 3x3;
+ * wts [12][32][32][3][3], biases [12][32] in network order (block 0 conv 1, block 0 conv 2, ...).  chain = 0: twelve
+ * k_feat_x3s_dma launches; 1: the pipeline's single k_feat_chain_x3s_dma launch (per-image group barriers between the
+ * layers).  The hook also checks that the tensors' zero borders stay zero. */
+int sn_dbg_feat_blocks(sn_handle *h, const float *in, int nimg, int h_px, int w, const float *wts,
+                       const float *biases, int chain, float *out);
 /* The rounding SN_PREC_F16 applies to the 3x3 weights of its refinement towers at model load (host only, no device):
  * w [nkernels][9] fp32 -> out [nkernels][9], every value one of the two fp16 numbers enclosing its input, chosen per kernel
  * so that the SUM of the nine rounding errors is smallest (csrc/stereonet_hip.hip round_kernel_sum_preserving;

@@ -2,7 +2,8 @@
 """Where does the fp16 tower's error come from?  (follow-up of scripts/epe_sensitivity.py.)
 CPU emulation of the refinement tower (torch, float64 reference) with the fp16 roundings of SN_PREC_F16 switched on
 ONE GROUP AT A TIME:
-    W  the 3x3 weights of the twelve tower convs (rounded once at model load)
+    W  the 3x3 weights of the twelve tower convs, rounded to nearest once at model load (rounds 1-4)
+    w  the same weights with the library's sum-preserving rounding of every 3x3 kernel (round 5, api.round_kernels_f16)
     I  the output of ref.in (stored fp16)
     T  the intermediate of every residual block (t, fp16 in LDS)
     S  the block outputs = the residual stream (stored fp16), blocks 0..4
@@ -21,7 +22,7 @@ import torch.nn.functional as F
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from hobot_stereonet_amd import spec, weights  # noqa: E402
+from hobot_stereonet_amd import api, spec, weights  # noqa: E402
 
 torch.set_num_threads(8)
 arg = lambda k, d: sys.argv[sys.argv.index(k) + 1] if k in sys.argv else d
@@ -34,6 +35,14 @@ def q(x, on):
     return x.to(torch.float16).to(x.dtype) if on else x
 
 
+def qw(w, rnd):
+    if "W" in rnd:
+        return q(w, True)
+    if "w" in rnd:
+        return torch.from_numpy(api.round_kernels_f16(w.numpy().astype(np.float32)).astype(np.float64))
+    return w
+
+
 def lrelu(x):
     return F.leaky_relu(x, spec.LRELU_SLOPE)
 
@@ -44,7 +53,7 @@ def tower(blob, x4, rnd):
     x = q(x, "I" in rnd)
     nb = len(spec.REF_DILATIONS)
     for i, dil in enumerate(spec.REF_DILATIONS):
-        w1, w2 = q(g(f"ref.res{i}.1.w"), "W" in rnd), q(g(f"ref.res{i}.2.w"), "W" in rnd)
+        w1, w2 = qw(g(f"ref.res{i}.1.w"), rnd), qw(g(f"ref.res{i}.2.w"), rnd)
         t = q(lrelu(F.conv2d(x, w1, g(f"ref.res{i}.1.b"), padding=dil, dilation=dil)), "T" in rnd)
         y = lrelu(x + F.conv2d(t, w2, g(f"ref.res{i}.2.b"), padding=dil, dilation=dil))
         x = q(y, ("L" if i == nb - 1 else "S") in rnd)
@@ -52,7 +61,8 @@ def tower(blob, x4, rnd):
 
 
 print(f"# fp16 rounding groups of the refinement tower, one at a time: mean |D (r - r_ref)| in px, D = {D}, {W_}x{H_}")
-print(f"{'seed':>4} {'|D r|':>7} " + " ".join(f"{n:>9}" for n in ("W", "I", "T", "S", "L", "all", "all-S", "rss")))
+print("# 'W mean' / 'w mean' = SIGNED mean of that group's error: the weight term is an offset, the sum-preserving rounding removes it")
+print(f"{'seed':>4} {'|D r|':>7} " + " ".join(f"{n:>9}" for n in ("W", "W mean", "w", "w mean", "I", "T", "S", "L", "all (W)", "all (w)")))
 for seed in seeds:
     blob = weights.synthetic(seed)
     rng = np.random.default_rng(900 + seed)
@@ -62,8 +72,9 @@ for seed in seeds:
     x4 = torch.cat([up / D, img], 1)
     with torch.no_grad():
         ref = tower(blob, x4, "")
-        errs = {}
-        for grp in ("W", "I", "T", "S", "L", "WITSL", "WITL"):
-            errs[grp] = float((D * (tower(blob, x4, grp) - ref)).abs().mean())
-    rss = float(np.sqrt(sum(errs[g] ** 2 for g in "WITSL")))
-    print(f"{seed:4d} {float((D * ref).abs().mean()):7.3f} " + " ".join(f"{errs[g]:9.2e}" for g in ("W", "I", "T", "S", "L", "WITSL", "WITL")) + f" {rss:9.2e}", flush=True)
+        errs, means = {}, {}
+        for grp in ("W", "w", "I", "T", "S", "L", "WITSL", "wITSL"):
+            e = D * (tower(blob, x4, grp) - ref)
+            errs[grp], means[grp] = float(e.abs().mean()), float(e.mean())
+    cols = [f"{errs['W']:9.2e}", f"{means['W']:+9.2e}", f"{errs['w']:9.2e}", f"{means['w']:+9.2e}"] + [f"{errs[g]:9.2e}" for g in ("I", "T", "S", "L", "WITSL", "wITSL")]
+    print(f"{seed:4d} {float((D * ref).abs().mean()):7.3f} " + " ".join(cols), flush=True)

@@ -171,8 +171,12 @@ np.save(sys.argv[3], disp)
                                        ({"SN_TOWER_STREAMS": "2", "SN_TAIL_FUSE": "0"}, True), ({"SN_STREAM_WGS": "100"}, True),
                                        ({"SN_STREAM_PRIORITY": "1"}, True),
                                        # aggregation layers / down-convs on the plain tensors (k_conv_x3s) instead of the zero-bordered ones
-                                       ({"SN_AGG_DMA": "0"}, True), ({"SN_DOWN_DMA": "0"}, True), ({"SN_AGG_DMA": "0", "SN_DOWN_DMA": "0"}, True),
+                                       # (the plain-volume form has no folded output conv: SN_HEAD_FOLD=0 on both sides of those two)
+                                       ({"SN_AGG_DMA": "0", "SN_HEAD_FOLD": "0"}, True), ({"SN_DOWN_DMA": "0"}, True),
+                                       ({"SN_AGG_DMA": "0", "SN_DOWN_DMA": "0", "SN_HEAD_FOLD": "0"}, True),
                                        ({"SN_FEAT_DMA": "0"}, True),
+                                       # the six feature residual blocks as twelve launches instead of one launch with group barriers
+                                       ({"SN_FEAT_CHAIN": "0"}, True), ({"SN_FEAT_CHAIN": "0", "SN_NO_OVERLAP": "1"}, True),
                                        # the first two down-convs as two kernels instead of the folded 13x13 stride-4 conv (another summation
                                        # order of the same linear map: not bit-identical)
                                        ({"SN_DOWN01": "0"}, False), ({"SN_DOWN01": "0", "SN_DOWN_DMA": "0"}, False),
@@ -191,7 +195,8 @@ def test_diagnostic_switches_run_the_same_network(model_factory, oracle, weights
     script = tmp_path / "run.py"
     script.write_text(_ENV_SCRIPT)
     outs = {}
-    for tag, e in (("default", {}), ("switch", env)):
+    base = {"SN_HEAD_FOLD": "0"} if (exact and env.get("SN_HEAD_FOLD") == "0") else {}      # equality needs the same head form
+    for tag, e in (("default", base), ("switch", env)):
         out = str(tmp_path / f"{tag}.npy")
         r = subprocess.run([sys.executable, str(script), root, model, out], env=dict(os.environ, **e), capture_output=True,
                            text=True, timeout=300)

@@ -329,6 +329,32 @@ def test_lowres_split_conv3x3(small_engine, oracle, h, w):
     assert np.array_equal(got2_dma, got2)
 
 
+@pytest.mark.parametrize("nimg,h,w", [(5, 45, 80), (32, 45, 80), (2, 24, 78), (9, 9, 33), (3, 68, 128)])
+def test_feature_blocks_chain_kernel(small_engine, oracle, nimg, h, w):
+    """The six residual blocks of the feature tower in ONE launch (k_feat_chain_x3s_dma: image i belongs to a group of
+    workgroups for all twelve layers, a per-image counter in device memory is the barrier between layers) against twelve
+    k_feat_x3s_dma launches (bit-identical: same tiles, same sums) and against the oracle's blocks; image counts that are
+    not multiples of 8 leave XCDs with fewer groups, 32 is the pipeline's 16-pair piece."""
+    rng = np.random.default_rng(nimg * 1000 + h + w)
+    x = rng.standard_normal((nimg, 32, h, w)).astype(np.float32)
+    wts = (rng.standard_normal((12, 32, 32, 3, 3)) / 17.0).astype(np.float32)
+    wts[1::2] *= 0.5
+    b = (rng.standard_normal((12, 32)) * 0.05).astype(np.float32)
+    one = small_engine.dbg_feat_blocks(x, wts, b, chain=True)
+    twelve = small_engine.dbg_feat_blocks(x, wts, b, chain=False)
+    assert np.array_equal(one, twelve)
+    again = small_engine.dbg_feat_blocks(x, wts, b, chain=True)          # (the counters are reset per launch)
+    assert np.array_equal(one, again)
+    for i in (0, nimg - 1):
+        ref = x[i]
+        for k in range(6):
+            t = oracle.conv2d(ref, wts[2 * k], b[2 * k], 1, 1, 1)
+            t = np.where(t > 0, t, t * np.float32(0.2))
+            v = ref + oracle.conv2d(t, wts[2 * k + 1], b[2 * k + 1], 1, 1, 1)
+            ref = np.where(v > 0, v, v * np.float32(0.2))
+        assert rel_err(one[i], ref) < 2e-5
+
+
 @pytest.mark.parametrize("d,h,w", [(3, 4, 6), (12, 45, 80), (16, 24, 78), (1, 8, 16), (6, 23, 40), (12, 90, 160)])
 def test_lowres_split_conv3d(small_engine, oracle, d, h, w):
     rng = np.random.default_rng(d + h + w)

@@ -72,7 +72,8 @@ def test_tail_form_equals_block_plus_head_bit_for_bit(eng16, hk, wk, ho, wo, ups
     assert np.array_equal(r0, r1)
     inv_q = np.float32(1.0 / (192.0 * float(np.float32(spec.OUT_SCALE))))
     assert np.array_equal(r1, np.rint(d1 * inv_q).astype(np.int32))
-    assert d1.std() > 0.5 and (d1 == 0).any()                        # the map is not trivial and the relu clips somewhere
+    # the map is not trivial and the relu clips somewhere (the one-strip case starts from an all-zero 1 x 4 map: only D * r)
+    assert d1.std() > (0.5 if hk > 16 else 0.1) and (d1 == 0).any()
 
 
 @pytest.mark.parametrize("hk,wk,ho,wo,ups", [(112, 144, 100, 129, 16), (48, 156, 48, 156, 2)])
