@@ -101,7 +101,6 @@ def load_library(path: Optional[str] = None):
     lib.sn_dbg_down0.argtypes = [vp, i8p, ip, ip, fp, fp, ip, fp]
     lib.sn_dbg_compose_down01.argtypes = [fp, fp, fp, fp, fp, fp]
     lib.sn_dbg_round_kernels_f16.argtypes = [fp, ip, fp]
-    lib.sn_dbg_feat_blocks.argtypes = [vp, fp, ip, ip, ip, fp, fp, ip, fp]
     lib.sn_dbg_down01.argtypes = [vp, i8p, ip, ip, fp, fp, fp, fp, fp]
     lib.sn_dbg_refin.argtypes = [vp, fp, i8p, ip, ip, ip, fp, fp, ip, fp]
     lib.sn_dbg_conv3d.argtypes = [vp, fp, ip, ip, ip, fp, fp, ip, fp]
@@ -116,7 +115,7 @@ def load_library(path: Optional[str] = None):
                  "sn_infer_sbs_nv12", "sn_preprocess_sbs_nv12_batch", "sn_submit", "sn_submit_nv12", "sn_wait", "sn_synchronize", "sn_set_profiling",
                  "sn_get_stage_ms", "sn_get_dominant_kernel", "sn_mgpu_shard", "sn_mgpu_create", "sn_mgpu_destroy",
                  "sn_mgpu_get_info", "sn_mgpu_get_handle", "sn_mgpu_infer_batch", "sn_mgpu_infer_batch_device",
-                 "sn_mgpu_submit_device", "sn_mgpu_wait", "sn_mgpu_ring_init", "sn_mgpu_ring_submit", "sn_mgpu_ring_wait", "sn_dbg_conv2d", "sn_dbg_down0", "sn_dbg_compose_down01", "sn_dbg_round_kernels_f16", "sn_dbg_feat_blocks", "sn_dbg_down01", "sn_dbg_refin", "sn_dbg_conv3d", "sn_dbg_ref_conv_f16", "sn_dbg_ref_conv_f16x3", "sn_dbg_ref_block_f16", "sn_dbg_ref_tail_f16", "sn_dbg_read", "sn_dbg_copy_limited", "sn_depth_from_raw"):
+                 "sn_mgpu_submit_device", "sn_mgpu_wait", "sn_mgpu_ring_init", "sn_mgpu_ring_submit", "sn_mgpu_ring_wait", "sn_dbg_conv2d", "sn_dbg_down0", "sn_dbg_compose_down01", "sn_dbg_round_kernels_f16", "sn_dbg_down01", "sn_dbg_refin", "sn_dbg_conv3d", "sn_dbg_ref_conv_f16", "sn_dbg_ref_conv_f16x3", "sn_dbg_ref_block_f16", "sn_dbg_ref_tail_f16", "sn_dbg_read", "sn_dbg_copy_limited", "sn_depth_from_raw"):
         getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
@@ -347,19 +346,6 @@ class StereoNetHIP:
         out = np.empty((2, 32, ho, wo), np.float32)
         self._check(self._lib.sn_dbg_down0(self._h, x.ctypes.data, h, w, wt.ctypes.data, bias.ctypes.data, tc,
                                            out.ctypes.data), "sn_dbg_down0")
-        return out
-
-    def dbg_feat_blocks(self, x, wts, biases, chain=True):
-        """x float32 (nimg, 32, h, w) -> same shape: the six residual blocks of the feature tower (fp16 modes' kernels);
-        wts (12, 32, 32, 3, 3), biases (12, 32); chain: one k_feat_chain_x3s_dma launch, else twelve k_feat_x3s_dma launches."""
-        x = np.ascontiguousarray(x, np.float32)
-        wts = np.ascontiguousarray(wts, np.float32)
-        biases = np.ascontiguousarray(biases, np.float32)
-        nimg, c, h, w = x.shape
-        assert c == 32 and wts.shape == (12, 32, 32, 3, 3) and biases.shape == (12, 32)
-        out = np.empty_like(x)
-        self._check(self._lib.sn_dbg_feat_blocks(self._h, x.ctypes.data, nimg, h, w, wts.ctypes.data, biases.ctypes.data,
-                                                 int(bool(chain)), out.ctypes.data), "sn_dbg_feat_blocks")
         return out
 
     def dbg_down01(self, in6, w0, b0, w1, b1):

@@ -234,228 +234,4 @@ __global__ __launch_bounds__(256, OUTSLOT ? 2 : 1) void k_feat_x3s_dma(ConvArgs 
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// The twelve convs of the six residual blocks in ONE launch.  A layer of a 45 x 80 map is ~2.5 us of
-// matrix work in a 13-15 us launch whichever kernel runs it (k_conv_x3s and k_feat_x3s_dma measure the same): what a
-// launch costs is its ramp, 36 KB of weights per wave, the first tile's latency chain and the drain.  Here the workgroups
-// stay: image i belongs to a GROUP of G workgroups of one XCD (blockIdx = 8 (slot G + member) + xcd, image = 8 slot + xcd),
-// every member keeps its tiles of that image for all twelve layers, and between two layers the group — not the grid —
-// meets at a counter in device memory: a layer-(L+1) tile needs the halo of layer L from its neighbours in the SAME image
-// only.  The next layer's weights are requested before the wait.  No workgroup ever waits for a workgroup that is
-// dispatched after its own group (groups are consecutive in an XCD's dispatch order), so a group whose members are all
-// resident always finishes and frees its slots: partial residency (another stream's kernel holding CUs) delays, it does
-// not deadlock.  x <- block(x) in place, t is the intermediate; same arithmetic, same bits as twelve k_feat_x3s_dma launches.
-// ------------------------------------------------------------------------------------------
-struct FeatChain {
-  static constexpr int NL = 12;
-  const uint4* w[NL];        // split A fragments of layer L (upload_x3)
-  const float* bias[NL];
-};
-
-__global__ __launch_bounds__(256, 2) void k_feat_chain_x3s_dma(FeatChain ch, uint4* __restrict__ xt, uint4* __restrict__ tt,
-                                                             FeatPad g, int nimg, int G, int tiles_x, int tiles_y,
-                                                             unsigned* __restrict__ bar) {      // [nimg] counters + [1] timeout flag, zeroed by the host
-  using T = FeatDma;
-  constexpr int BUF = T::BUF, KW = T::KW;
-  extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
-  float* s_bias = reinterpret_cast<float*>(smem4 + 2 * BUF);
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int gh = lane >> 5, j = lane & 31;
-  const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3;
-  const int slot = lb / G, member = lb - slot * G;
-  const int img = slot * 8 + xcd;
-  if (img >= nimg) return;                       // (a whole group: nobody waits for it)
-
-  constexpr int ROT = T::PITCH % 16;
-  const int pr = j / 16, pc = ((j % 16) - pr * ROT) & 15;
-  const int srow = 2 * wave + pr;
-  const int lane_base = gh * T::PLANE + srow * T::PITCH + pc;
-  const unsigned phw = (unsigned)(g.PH * g.PW);
-  // (the per-lane source offsets of the six DMA instructions are recomputed per tile from an opaque copy of the lane id:
-  // kept in registers across the layer loop they are what pushes this kernel past the 256 registers two workgroups per CU
-  // allow; ~10 VALU instructions each, issued behind MFMAs)
-  auto srel_of = [&](int e, unsigned lane_o) {
-    const int L = (4 * e + wave) * 64 + (int)lane_o;
-    const int part = L / (T::NCB * T::PLANE);
-    const int rem = L - part * (T::NCB * T::PLANE);
-    const int cb = rem / T::PLANE;
-    const int rc = rem - cb * T::PLANE;
-    const int r = rc / T::PITCH, cc = rc - r * T::PITCH;
-    return L < T::NSL ? (unsigned)(((cb * 2 + part) * (int)phw + r * g.PW + cc) * 16) : 0u;
-  };
-  const unsigned img_off = (unsigned)img * 8u * phw * 16u;
-  const FastDiv div_tx((unsigned)tiles_x);
-  auto tile_off = [&](int ti, int& ty, int& tx) {
-    unsigned txu;
-    ty = (int)div_tx.divmod((unsigned)ti, txu);
-    tx = (int)txu;
-    return (unsigned)__builtin_amdgcn_readfirstlane((int)(img_off + (unsigned)(ty * T::TR * g.PW + tx * T::TC) * 16u));
-  };
-  const unsigned lds0 = lds_addr(smem4);
-  const int tpi = tiles_x * tiles_y;
-  auto koff_of = [&](int k) {
-    const int kc = k / T::TAPS, tap = k - kc * T::TAPS;
-    const int ky = tap / 3, kx = tap - ky * 3;
-    return 2 * kc * T::PLANE + ky * T::PITCH + kx;
-  };
-  f32x16 zero;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) zero[r] = 0.f;
-
-  half8 wh[T::NK], wl[T::NK];
-  auto load_weights = [&](int L) {
-    const uint4* wsrc = ch.w[L] + lane;
-#pragma unroll
-    for (int k = 0; k < T::NK; ++k) {
-      const uint4 a = wsrc[(2 * k) * 64], b = wsrc[(2 * k + 1) * 64];
-      wh[k] = *reinterpret_cast<const half8*>(&a);
-      wl[k] = *reinterpret_cast<const half8*>(&b);
-    }
-  };
-  load_weights(0);
-
-#pragma unroll 1
-  for (int L = 0; L < FeatChain::NL; ++L) {
-    const bool has_res = (L & 1) != 0;                                  // uniform: conv2 of a block adds x in place
-    const uint4* const vin = has_res ? tt : xt;
-    uint4* const vout = has_res ? xt : tt;
-    auto dma = [&](int e, int buf, unsigned toff, unsigned lane_o) {
-      glds16(lds0 + (unsigned)(buf * BUF * 16) + (unsigned)((4 * e + wave) * 1024), srel_of(e, lane_o) + toff, vin);
-    };
-    auto opaque_lane = [&]() {
-      unsigned v = (unsigned)lane;
-      asm volatile("" : "+v"(v));
-      return v;
-    };
-    if (tid < kC) s_bias[tid] = ch.bias[L][tid];                       // (the group barrier below ordered the last reads of it)
-    int ti = member;
-    int c_ty, c_tx;
-    unsigned toff = tile_off(ti, c_ty, c_tx);
-    {
-      const unsigned lane_o = opaque_lane();
-#pragma unroll
-      for (int e = 0; e < KW; ++e) dma(e, 0, toff, lane_o);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int cur = 0;
-    for (; ti < tpi; ti += G) {
-      const unsigned lane_o = opaque_lane();
-      const int nxt = ti + G;
-      const int more = __builtin_amdgcn_readfirstlane(nxt < tpi ? 1 : 0);
-      int n_ty = c_ty, n_tx = c_tx;
-      const unsigned ntoff = more ? tile_off(nxt, n_ty, n_tx) : toff;
-      const int e_y = c_ty * T::TR + srow, e_x = c_tx * T::TC + pc;
-      const bool e_in = e_y < g.H && e_x < g.W;
-      const unsigned pad_off = ((unsigned)(e_y + 1) * (unsigned)g.PW + (unsigned)(e_x + 1)) * 16u + gh * 8u;
-      uint2 rraw[8];
-      if (has_res) {
-        const char* rs = reinterpret_cast<const char*>(xt) + img_off;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) rraw[q] = *reinterpret_cast<const uint2*>(rs + (size_t)q * phw * 16 + (e_in ? pad_off : 0u));
-      } else {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) rraw[q] = uint2{0u, 0u};
-      }
-      const uint4* s_xh = smem4 + cur * BUF + lane_base;
-      const uint4* s_xl = s_xh + T::NCB * T::PLANE;
-      f32x16 acc0, acc1;
-      float p0[16];
-      uint4 bh[2], bl[2];
-      bh[0] = s_xh[koff_of(0)];
-      bl[0] = s_xl[koff_of(0)];
-#pragma unroll
-      for (int k = 0; k < T::NK; ++k) {
-        const int cb_ = k & 1, nx = cb_ ^ 1;
-        if (k + 1 < T::NK) {
-          bh[nx] = s_xh[koff_of(k + 1)];
-          bl[nx] = s_xl[koff_of(k + 1)];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        const half8 xh = *reinterpret_cast<const half8*>(&bh[cb_]);
-        const half8 xl = *reinterpret_cast<const half8*>(&bl[cb_]);
-        const bool first = k % T::TAPS == 0;
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[k], xh, first ? zero : acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[k], xh, first ? zero : acc1, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[k], xl, acc1, 0, 0, 0);
-        if (k >= 1 && 2 * (k - 1) < KW) {
-          dma(2 * (k - 1), cur ^ 1, ntoff, lane_o);
-          if (2 * (k - 1) + 1 < KW) dma(2 * (k - 1) + 1, cur ^ 1, ntoff, lane_o);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (k == T::TAPS - 1) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) p0[r] = acc0[r] + acc1[r] * kSplitInv;
-        }
-      }
-      float fin[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p1 = acc0[r] + acc1[r] * kSplitInv;
-        fin[r] = p0[r] + p1;
-      }
-#pragma unroll
-      for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(rraw[q].x), "+v"(rraw[q].y));      // first use: after the MFMAs
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      lds_barrier();
-      if (e_in) {
-        char* const o = reinterpret_cast<char*>(vout) + img_off;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          char* oq = o + (size_t)(2 * q) * phw * 16;
-          half4 hh, hl;
-          const half4 rh = *reinterpret_cast<const half4*>(&rraw[2 * q]);
-          const half4 rl = *reinterpret_cast<const half4*>(&rraw[2 * q + 1]);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int r = 4 * q + e;
-            float v = fin[r] + s_bias[8 * q + 4 * gh + e];
-            if (has_res) v += (float)rh[e] + (float)rl[e] * kSplitInv;
-            v = fmaxf(v, v * kSlope);
-            const _Float16 hi = (_Float16)v;
-            hh[e] = hi;
-            hl[e] = (_Float16)((v - (float)hi) * kSplitScale);
-          }
-          __builtin_nontemporal_store(hh, reinterpret_cast<half4*>(oq + pad_off));
-          __builtin_nontemporal_store(hl, reinterpret_cast<half4*>(oq + (size_t)phw * 16 + pad_off));
-        }
-      }
-      cur ^= 1;
-      toff = ntoff;
-      c_ty = n_ty;
-      c_tx = n_tx;
-    }
-    if (L + 1 == FeatChain::NL) break;
-    // ---- group barrier: every store of this layer visible device-wide, then count in, then wait for the group -------
-    // (the hand-off recipe of cdna_hip_programming.md §6 G16: every wave drains its stores, ONE lane releases at agent
-    // scope — buffer_wbl2 writes back the XCD L2's dirty lines whoever dirtied them, 256 threads doing it is 2-4x the price —,
-    // an explicit wait the compiler cannot drop, then the counter)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_fetch_add(&bar[img], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    load_weights(L + 1);                          // requested before the wait: they do not depend on the other members
-    if (tid == 0) {
-      // (bounded: ~2 s of polling.  A group that never completes — which the dispatch-order argument above rules out —
-      // raises the flag behind the counters and goes on, so that a defect shows up as a failed comparison, not as a hung GPU)
-      const unsigned target = (unsigned)(G * (L + 1));
-      unsigned spins = 0;
-      while (__hip_atomic_load(&bar[img], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++spins == (1u << 24)) {
-          __hip_atomic_store(&bar[nimg], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");    // the neighbours' rows are read through this CU's L1: drop stale lines
-    }
-    __syncthreads();
-  }
-}
-
 }  // namespace sn

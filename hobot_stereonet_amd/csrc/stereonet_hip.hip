@@ -110,7 +110,6 @@ struct Workspace {          // activations for up to `nb` pairs
   float* vol[2] = {nullptr, nullptr};
   uint4* volp[2] = {nullptr, nullptr};
   uint4* lowp[2] = {nullptr, nullptr};            // zero-bordered (x, t) of the 3x3 feature layers (fp16 modes, FeatPad)
-  unsigned* feat_bar = nullptr;                   // group-barrier counters of k_feat_chain_x3s_dma: one per image of a piece
   uint4* downp[3] = {nullptr, nullptr, nullptr};   // zero-bordered inputs of down-convs 1..3 (fp16 modes, DownDma)   // zero-bordered split-slot volumes of the aggregation layers (fp16 modes, VolPad)
   float* cost = nullptr;     // [nb][Dl][hl][wl] (debug / parity)
   float* disp_low = nullptr;
@@ -593,35 +592,6 @@ bool feat_dma_enabled() {
 }
 
 FeatPad feat_pad(int H, int W) { return FeatPad{H, W, FeatPad::ph(H), FeatPad::pw(W)}; }
-
-// SN_FEAT_CHAIN=0: the twelve convs of the feature residual blocks as twelve k_feat_x3s_dma launches instead of one
-// k_feat_chain_x3s_dma launch with per-image group barriers (bit-identical)
-bool feat_chain_enabled() {
-  static const bool on = !(getenv("SN_FEAT_CHAIN") != nullptr && atoi(getenv("SN_FEAT_CHAIN")) == 0);
-  return on;
-}
-
-// x <- resblock^6(x) on zero-bordered tensors, one launch (sn_feat_dma.hpp k_feat_chain_x3s_dma).  bar: nimg counters.
-hipError_t launch_feat_chain(hipStream_t st, const ConvLayer (*fres)[2], uint4* x, uint4* t, const FeatPad& g, int nimg,
-                             unsigned* bar, int num_cu) {
-  FeatChain ch{};
-  for (int i = 0; i < FeatChain::NL; ++i) {
-    ch.w[i] = fres[i / 2][i % 2].wx3;
-    ch.bias[i] = fres[i / 2][i % 2].bias;
-  }
-  hipError_t e = ensure_lds_attr(k_feat_chain_x3s_dma, (int)FeatDma::LDS_BYTES);
-  if (e != hipSuccess) return e;
-  const int tiles_x = (g.W + 15) / 16, tiles_y = (g.H + 7) / 8, tpi = tiles_x * tiles_y;
-  const int slots = (nimg + 7) / 8;                      // images per XCD
-  int G = (2 * num_cu / 8) / slots;                      // workgroups per image: two per CU, all groups resident at once
-  if (G > tpi) G = tpi;
-  if (G < 1) G = 1;
-  e = hipMemsetAsync(bar, 0, (size_t)(nimg + 1) * sizeof(unsigned), st);      // counters + the timeout flag
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_feat_chain_x3s_dma, dim3(8 * slots * G), dim3(256), FeatDma::LDS_BYTES, st, ch, x, t, g, nimg, G, tiles_x,
-                     tiles_y, bar);
-  return hipGetLastError();
-}
 
 // 3x3 32->32 feature layer on zero-bordered split-slot tensors (sn_feat_dma.hpp): two persistent workgroups per CU.
 // out / res: FeatPad tensors (OUTSLOT) or fp32 NCHW.
@@ -1239,7 +1209,6 @@ int alloc_ws(sn_handle* h, Workspace* ws, int nb, int rb, int ns) {
       HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&ws->lowp[k]), bytes));
       HIP_TRY(h, memset_now(ws->lowp[k], 0, bytes));       // the borders stay zero: kernels write image pixels only
     }
-    HIP_TRY(h, dalloc(&ws->feat_bar, (size_t)2 * pb + 1));
   }
   if (h->precision != SN_PREC_FP32 && agg_dma_enabled()) {
     const VolPad g = vol_pad(h->Dl, h->hl, h->wl);
@@ -1302,7 +1271,6 @@ void free_ws(Workspace* ws) {
   for (auto p : ws->volp) hipFree(p);
   for (auto p : ws->downp) hipFree(p);
   for (auto p : ws->lowp) hipFree(p);
-  hipFree(ws->feat_bar);
   hipFree(ws->cost);
   hipFree(ws->disp_low);
   for (auto p : ws->ref) hipFree(p);
@@ -1371,14 +1339,12 @@ int lowres_slots(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, con
   if (ws.lowp[0] != nullptr && ws.downp[1] != nullptr) {     // zero-bordered (x, t), LDS-DMA kernel
     const FeatPad fp = feat_pad(hl, wl);
     uint4 *x = ws.lowp[0], *t = ws.lowp[1];
-    static_assert(FeatChain::NL == 2 * kNFeatRes, "the chain kernel runs every residual block");
-    if (feat_chain_enabled() && ws.feat_bar) {      // all six blocks in one launch, per-image group barriers between layers
-      HIP_TRY(h, launch_feat_chain(st, h->fres, x, t, fp, ni, ws.feat_bar, ncu));
-    } else {
-      for (int i = 0; i < kNFeatRes; ++i) {
-        HIP_TRY(h, (launch_feat_dma<true, false>(st, h->fres[i][0], x, fp, ni, t, nullptr, true, ncu)));
-        HIP_TRY(h, (launch_feat_dma<true, true>(st, h->fres[i][1], t, fp, ni, x, x, true, ncu)));     // in-place residual
-      }
+    // (one launch per layer: a single launch for all twelve with per-image group barriers in device memory was built and
+    // measured in round 5 — bit-identical, 609 us instead of 167 us per 16-pair piece: an agent-scope hand-off costs several
+    // kernel boundaries, DESIGN.md §5d, profiles/r05_feat_chain_ab.txt)
+    for (int i = 0; i < kNFeatRes; ++i) {
+      HIP_TRY(h, (launch_feat_dma<true, false>(st, h->fres[i][0], x, fp, ni, t, nullptr, true, ncu)));
+      HIP_TRY(h, (launch_feat_dma<true, true>(st, h->fres[i][1], t, fp, ni, x, x, true, ncu)));     // in-place residual
     }
     HIP_TRY(h, (launch_feat_dma<false, false>(st, h->fout, x, fp, ni, ws.feat, nullptr, false, ncu)));
   } else {
@@ -2707,75 +2673,6 @@ int sn_dbg_down0(sn_handle* h, const int8_t* in6, int h_px, int w, const float* 
   std::vector<_Float16> hs(nout * 2);
   HIP_TRY(h, hipMemcpy(hs.data(), dout, nout * 4, hipMemcpyDeviceToHost));
   host_from_slots(hs, 2, Ho, Wo, out);
-  return SN_OK;
-}
-
-int sn_dbg_feat_blocks(sn_handle* h, const float* in, int nimg, int h_px, int w, const float* wts, const float* biases,
-                       int chain, float* out) {
-  DevScope ds;      // frees every tracked device buffer on every return path
-  if (!h || !in || !wts || !biases || !out || nimg <= 0 || h_px <= 0 || w <= 0) return SN_ERR_ARG;
-  int rc = check_device(h);
-  if (rc) return rc;
-  ConvLayer L[kNFeatRes][2];
-  for (int i = 0; i < 2 * kNFeatRes; ++i) {
-    const float* wt = wts + (size_t)i * kC * kC * 9;
-    ConvLayer& l = L[i / 2][i % 2];
-    HostLayer hl{wt, biases + (size_t)i * kC, kC, kC, 9};
-    rc = upload_conv2d(h, hl, 8, &l);
-    ds.track(l.bias);
-    ds.track(l.wpk);
-    if (rc) return rc;
-    rc = upload_x3(h, kC, [&](int co, int c, int tap) { return wt[((size_t)co * kC + c) * 9 + tap]; }, &l, 9);
-    ds.track(l.wx3);
-    if (rc) return rc;
-  }
-  const FeatPad g = feat_pad(h_px, w);
-  const size_t phw = (size_t)g.PH * g.PW, plane = (size_t)h_px * w;
-  std::vector<_Float16> hin, pin((size_t)nimg * 8 * phw * 8, (_Float16)0.f), hout((size_t)nimg * 8 * plane * 8);
-  host_to_slots(in, nimg, h_px, w, hin);
-  for (int im = 0; im < nimg * 8; ++im)        // (image, block, part) planes into the zero-bordered layout
-    for (int y = 0; y < h_px; ++y)
-      memcpy(&pin[((size_t)im * phw + (size_t)(y + 1) * g.PW + 1) * 8], &hin[((size_t)im * h_px + y) * w * 8], (size_t)w * 16);
-  uint4 *dx = nullptr, *dt = nullptr;
-  unsigned* bar = nullptr;
-  HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&dx), pin.size() * 2));
-  ds.track(dx);
-  HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&dt), pin.size() * 2));
-  ds.track(dt);
-  HIP_TRY(h, dalloc(&bar, (size_t)nimg + 1));
-  ds.track(bar);
-  HIP_TRY(h, hipMemcpy(dx, pin.data(), pin.size() * 2, hipMemcpyHostToDevice));
-  HIP_TRY(h, memset_now(dt, 0, pin.size() * 2));
-  if (chain) {
-    HIP_TRY(h, launch_feat_chain(h->stream, L, dx, dt, g, nimg, bar, h->num_cu));
-  } else {
-    for (int i = 0; i < kNFeatRes; ++i) {
-      HIP_TRY(h, (launch_feat_dma<true, false>(h->stream, L[i][0], dx, g, nimg, dt, nullptr, true, h->num_cu)));
-      HIP_TRY(h, (launch_feat_dma<true, true>(h->stream, L[i][1], dt, g, nimg, dx, dx, true, h->num_cu)));
-    }
-  }
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
-  if (chain) {
-    unsigned flag = 0;
-    HIP_TRY(h, hipMemcpy(&flag, bar + nimg, sizeof(flag), hipMemcpyDeviceToHost));
-    if (flag) {
-      set_err(h, "k_feat_chain_x3s_dma: a group barrier timed out");
-      return SN_ERR_DEVICE;
-    }
-  }
-  HIP_TRY(h, hipMemcpy(pin.data(), dx, pin.size() * 2, hipMemcpyDeviceToHost));
-  for (int im = 0; im < nimg * 8; ++im)
-    for (int y = 0; y < h_px; ++y)
-      memcpy(&hout[((size_t)im * h_px + y) * w * 8], &pin[((size_t)im * phw + (size_t)(y + 1) * g.PW + 1) * 8], (size_t)w * 16);
-  for (size_t i = 0; i < pin.size(); ++i) {
-    const size_t sl = i / 8, y = (sl % phw) / g.PW, x = sl % g.PW;
-    const bool inside = y >= 1 && y < (size_t)h_px + 1 && x >= 1 && x < (size_t)w + 1;
-    if (!inside && (float)pin[i] != 0.f) {
-      set_err(h, "the feature kernels wrote outside the image");
-      return SN_ERR_DEVICE;
-    }
-  }
-  host_from_slots(hout, nimg, h_px, w, out);
   return SN_OK;
 }
 

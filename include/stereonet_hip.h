@@ -230,13 +230,6 @@ int sn_dbg_conv2d(sn_handle *h, const float *in, int cin, int h_px, int w, const
  * tc = 32 or 64 selects the tile width */
 int sn_dbg_down0(sn_handle *h, const int8_t *in6, int h_px, int w, const float *wt, const float *bias, int tc,
                  float *out);
-/* The six residual blocks of the feature tower (fp16 modes: split operands on zero-bordered split-slot tensors) on caller
- * data: in [nimg][32][h][w] -> out (same shape) = block^6(in), block(x) = lrelu(x + conv2(lrelu(conv1(x)))), both 3x3;
- * wts [12][32][32][3][3], biases [12][32] in network order (block 0 conv 1, block 0 conv 2, ...).  chain = 0: twelve
- * k_feat_x3s_dma launches; 1: the pipeline's single k_feat_chain_x3s_dma launch (per-image group barriers between the
- * layers).  The hook also checks that the tensors' zero borders stay zero. */
-int sn_dbg_feat_blocks(sn_handle *h, const float *in, int nimg, int h_px, int w, const float *wts,
-                       const float *biases, int chain, float *out);
 /* The rounding SN_PREC_F16 applies to the 3x3 weights of its refinement towers at model load (host only, no device):
  * w [nkernels][9] fp32 -> out [nkernels][9], every value one of the two fp16 numbers enclosing its input, chosen per kernel
  * so that the SUM of the nine rounding errors is smallest (csrc/stereonet_hip.hip round_kernel_sum_preserving;

@@ -32,7 +32,7 @@ python scripts/pmc_traffic.py $(find $OUT/${TAG}_pmc_FETCH_SIZE -name "*counter_
 python scripts/mfma_busy.py $(find $OUT/${TAG}_pmc_mfma -name "*counter_collection.csv" | head -1) $OUT/${TAG}_mfma_busy.json > $OUT/${TAG}_mfma_busy.txt 2>&1
 # round 5: same-box A/B of the low-resolution changes through the library's switches ("SN_X=0" = the default tree; the first
 # switch line = the round-4 kernels: two down-conv kernels, per-layer k_conv_x3s feature launches, k_head_softargmin)
-AB_STEPS=20 bash scripts/ab_env.sh SN_X=0 SN_DOWN01=0,SN_FEAT_DMA=0,SN_HEAD_FOLD=0 SN_DOWN01=0 SN_FEAT_CHAIN=0 SN_FEAT_DMA=0 SN_HEAD_FOLD=0 SN_X=0 SN_DOWN01=0,SN_FEAT_DMA=0,SN_HEAD_FOLD=0 > $OUT/${TAG}_lowres_ab.txt 2>&1
+AB_STEPS=20 bash scripts/ab_env.sh SN_X=0 SN_DOWN01=0,SN_FEAT_DMA=0,SN_HEAD_FOLD=0 SN_DOWN01=0 SN_FEAT_DMA=0 SN_HEAD_FOLD=0 SN_X=0 SN_DOWN01=0,SN_FEAT_DMA=0,SN_HEAD_FOLD=0 > $OUT/${TAG}_lowres_ab.txt 2>&1
 $T python bench.py --precision f16x3 --no-cpu-baseline --no-end-to-end --steps 20 > $OUT/${TAG}_f16x3_b64_bench.json 2>> $OUT/${TAG}_bench.err
 $T python bench.py --precision fp32 --no-cpu-baseline --no-end-to-end --steps 5 --batch 16 > $OUT/${TAG}_fp32_b16_bench.json 2>> $OUT/${TAG}_bench.err
 $T python bench.py --no-cpu-baseline --no-end-to-end --batch 1 --steps 400 --warmup 20 > $OUT/${TAG}_f16_b1_bench.json 2>> $OUT/${TAG}_bench.err

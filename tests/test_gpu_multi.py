@@ -175,8 +175,6 @@ np.save(sys.argv[3], disp)
                                        ({"SN_AGG_DMA": "0", "SN_HEAD_FOLD": "0"}, True), ({"SN_DOWN_DMA": "0"}, True),
                                        ({"SN_AGG_DMA": "0", "SN_DOWN_DMA": "0", "SN_HEAD_FOLD": "0"}, True),
                                        ({"SN_FEAT_DMA": "0"}, True),
-                                       # the six feature residual blocks as twelve launches instead of one launch with group barriers
-                                       ({"SN_FEAT_CHAIN": "0"}, True), ({"SN_FEAT_CHAIN": "0", "SN_NO_OVERLAP": "1"}, True),
                                        # the first two down-convs as two kernels instead of the folded 13x13 stride-4 conv (another summation
                                        # order of the same linear map: not bit-identical)
                                        ({"SN_DOWN01": "0"}, False), ({"SN_DOWN01": "0", "SN_DOWN_DMA": "0"}, False),
