@@ -810,7 +810,11 @@ hipError_t conv5x5s2(hipStream_t st, const ConvLayer& L, const float* in, int ni
                      float* out) {
   LoadF32 ld{in, kC, Hin, Win};
   const int Ho = Hin / 2, Wo = Win / 2;
-  if (Ho * Wo <= 64 * 128) return launch_conv<5, 2, 1, 4, 4, 32>(st, L, ld, nimg, Ho, Wo, out, nullptr, false);
+  // 8 x 64 tiles are the efficient shape, but a launch needs workgroups: a single pair's second down-conv is 56 of them on
+  // 256 CUs (130 us for a quarter of the first one's work, profiles/r05_fp32_b1_kernel_summary.txt); below two workgroups
+  // per CU the 4 x 32 shape (same K order, same sums) fills the chip instead
+  const long big_tiles = (long)((Wo + 63) / 64) * ((Ho + 7) / 8) * nimg;
+  if (Ho * Wo <= 64 * 128 || big_tiles < 512) return launch_conv<5, 2, 1, 4, 4, 32>(st, L, ld, nimg, Ho, Wo, out, nullptr, false);
   return launch_conv<5, 2, 1, 4, 8, 64>(st, L, ld, nimg, Ho, Wo, out, nullptr, false);
 }
 
