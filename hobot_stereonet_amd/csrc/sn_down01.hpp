@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256, 1) void k_down01_f16(const int8_t* __restrict_
                                                     const uint4* __restrict__ wfrag,   // inner class: [39][hi|lo][64]
                                                     const float* __restrict__ bias,    // inner class: [32]
                                                     uint4* __restrict__ out, int Ho, int Wo, int tiles_x, int tiles_y,
-                                                    int nimg, int al4, int oPH, int oPW, int opy, int opx) {
+                                                    int nimg, int oPH, int oPW, int opy, int opx) {
   using T = Down01;
   extern __shared__ __attribute__((aligned(16))) _Float16 s_x[];
   const int tid = threadIdx.x, lane = tid & 63;

@@ -438,15 +438,15 @@ hipError_t launch_down01(hipStream_t st, const Down01W& L, const int8_t* in6, in
   const int total = tiles_x * tiles_y * nimg;
   int blocks = num_cu / 8 * 8;                    // one workgroup per CU (register budget), whole XCD bands
   while (blocks > 8 && blocks / 8 > (total + 7) / 8) blocks -= 8;
-  const int al4 = (W % 4 == 0) && (reinterpret_cast<uintptr_t>(in6) % 4 == 0);
+  // (dword loads at any byte address: the int8 planes need no alignment, only W % 4 decides which instance runs)
   if (w4)
     hipLaunchKernelGGL(k_down01_f16<true>, dim3(blocks), dim3(256), T::LDS_BYTES, st, in6, H, W,
                        L.wfrag + (size_t)T::INNER * T::NK * 2 * 64, L.bias + T::INNER * kC, out, Ho, Wo, tiles_x, tiles_y, nimg,
-                       al4, og.PH, og.PW, og.py, og.px);
+                       og.PH, og.PW, og.py, og.px);
   else
     hipLaunchKernelGGL(k_down01_f16<false>, dim3(blocks), dim3(256), T::LDS_BYTES, st, in6, H, W,
                        L.wfrag + (size_t)T::INNER * T::NK * 2 * 64, L.bias + T::INNER * kC, out, Ho, Wo, tiles_x, tiles_y, nimg,
-                       al4, og.PH, og.PW, og.py, og.px);
+                       og.PH, og.PW, og.py, og.px);
   const int per_img = 4 + 2 * ((Wo - 2 + 31) / 32) + 2 * ((Ho - 2 + 31) / 32);
   hipLaunchKernelGGL(k_down01_border, dim3((per_img * nimg + 3) / 4), dim3(256), 0, st, in6, H, W, L.wfrag, L.bias, out, Ho, Wo,
                      nimg, og.PH, og.PW, og.py, og.px);
