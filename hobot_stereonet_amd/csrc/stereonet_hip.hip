@@ -1461,12 +1461,16 @@ int lowres(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, const int
   return SN_OK;
 }
 
-// Pieces of one forward(): [p0, p0 + m).  The first piece is short (the towers can only start when its low-resolution
-// branch is done: nothing overlaps that time), the others take ws.pb pairs (the low-resolution launches are dominated by
-// fixed costs: 13 of the 23 launches of a piece do ~1 us of matrix work in ~9 us).
-inline int first_piece(const Workspace& ws, int n) {
+// Pieces of one forward(): [p0, p0 + m), ws.pb pairs each.  Rounds 1-4 started with a short piece (2-4 pairs: the towers
+// can only start when the first piece's low-resolution branch is done).  With the round-5 low-resolution branch a whole
+// first piece measures faster in the fp16 modes (fewer, fuller launches of kernels that are mostly fixed cost: 3041-3049 ->
+// 3064-3068 pairs/s at 1280x720, 4070 -> 4121 at 1242x375, profiles/r05_schedule_sweep.txt) — the device is never idle
+// either way, so what counts is the sum of the kernel times.  SN_PREC_FP32 keeps the short first piece: its low-resolution
+// branch (generic fp32 kernel) is five times longer.  SN_FIRST_PIECE=n forces n pairs.
+inline int first_piece(const sn_handle* h, const Workspace& ws, int n) {
   static const int forced = getenv("SN_FIRST_PIECE") ? atoi(getenv("SN_FIRST_PIECE")) : 0;     // experiment switch
-  int m = ws.rb * ws.ns > 2 ? ws.rb * ws.ns : 2;
+  int m = ws.pb;
+  if (h->precision == SN_PREC_FP32) m = ws.rb * ws.ns > 2 ? ws.rb * ws.ns : 2;
   if (forced > 0) m = forced;
   if (m > ws.pb) m = ws.pb;
   return m < n ? m : n;
@@ -1678,7 +1682,7 @@ int forward(sn_handle* h, Workspace& ws, hipStream_t st, int n, const int8_t* in
   for (int s = 0; s < ns; ++s) HIP_TRY(h, hipStreamWaitEvent(h->s_tow[s], h->ev_fork, 0));
   int k = 0, chunk = 0;
   for (int p0 = 0, m = 0; p0 < n; p0 += m, ++k) {
-    m = p0 == 0 ? first_piece(ws, n) : ((n - p0) < ws.pb ? (n - p0) : ws.pb);
+    m = p0 == 0 ? first_piece(h, ws, n) : ((n - p0) < ws.pb ? (n - p0) : ws.pb);
     // the piece-local low-res buffers are reused by the next piece: only disp_low crosses streams
     if ((rc = lowres(h, ws, h->s_low, p0, m, in6, want_cost, false))) return rc;
     hipEvent_t e = h->ev_piece[k % kMaxPieceEvents];
@@ -1893,10 +1897,11 @@ int sn_create_prio(const char* model_file, const sn_config* cfg, int stream_prio
     int rc_auto = (int)(256.0 / (2.0 * tensor_mb * h->tower_streams) + 0.5);
     // With every residual block streamed (fp16 mode, SN_FUSE=4) a launch reads x and writes y ONCE while it does two
     // convolutions: ~2.8 TB/s at the rate the matrix pipes allow, which HBM sustains — the chunk no longer has to live in
-    // the Infinity Cache, and fuller launches amortise the restart rows and the launch itself: ~3.7 Mpx per launch
-    // (1280x720: 4 pairs, 2583 -> 2653 pairs/s; 8 pairs measured equal).
+    // the Infinity Cache, and fuller launches amortise the restart rows and the launch itself: ~5.5 Mpx per launch
+    // (1280x720: 6 pairs; round 3: 4 pairs 2583 -> 2653 pairs/s; round 5, three interleaved runs: 4 pairs 3064-3068,
+    // 6 pairs 3074-3081, 8 pairs 3071-3078, profiles/r05_schedule_sweep.txt).
     if (h->precision == SN_PREC_F16 && fuse_env() == 4 && stream_block_supports(8)) {
-      const int by_px = (int)(3.7e6 / ((double)h->Hp * h->Wp) + 0.5);
+      const int by_px = (int)(5.5e6 / ((double)h->Hp * h->Wp) + 0.5);
       if (by_px > rc_auto) rc_auto = by_px;
     }
     h->refine_chunk = rc_auto < 1 ? 1 : (rc_auto > 8 ? 8 : rc_auto);

@@ -89,10 +89,10 @@ typedef struct sn_config {
   int precision;     /* SN_PREC_*; 0 = SN_PREC_F16                                                */
   int task_num;      /* async slots for sn_submit; <=0 -> 4 (stereonet_node.cpp:144)              */
   int refine_chunk;  /* pairs per refinement-tower launch; <=0 -> sized by work per launch, about    */
-                     /* 3.7 Mpx (4 at 1280x720, 8 at 1248x384, max 8); the per-layer forms           */
+                     /* 5.5 Mpx (6 at 1280x720, 8 at 1248x384, max 8); the per-layer forms           */
                      /* (SN_FUSE=0, SN_PREC_F16X3, SN_PREC_FP32) keep the Infinity-Cache sizing       */
-  int piece;         /* pairs per low-resolution piece of the pipeline; <=0 -> 16 (the first piece of */
-                     /* a call is 2-4 pairs: nothing overlaps its low-resolution branch)             */
+  int piece;         /* pairs per low-resolution piece of the pipeline; <=0 -> 16 (SN_PREC_FP32: the    */
+                     /* first piece of a call is 2-4 pairs, nothing overlaps its low-res branch)     */
 } sn_config;
 
 typedef struct sn_io_info {
