@@ -5,7 +5,7 @@ reference runs is unknown (stereonet_infer/src/stereonet_node.cpp:131-136 only c
 bound north_star states has to be shown as a property of the KERNELS over a plausible envelope of weights:
 
     weight seeds 0..7  x  refinement-head gain {1, 2, 4, 8}  x  low-resolution activation scale {0.5, 1, 2}
-    at C2 (1280x720 D=192, single-scale) and C5 (1242x375 D=256, hierarchical), modes F16 / F16X3 / FP32
+    at C1 (960x540 D=48), C2 (1280x720 D=192, single-scale) and C5 (1242x375 D=256, hierarchical), modes F16 / F16rne / F16X3 / FP32
 
 Per cell: mean and max |disp - oracle| in px (HIP path through the C ABI vs oracle/stereonet_oracle.c on the same input and
 weights), plus what the envelope means in pixels: `refine_px` = mean |disp - upsampled soft-argmin map| of the oracle.
@@ -33,7 +33,8 @@ ACTS = (1.0,) if quick else (0.5, 1.0, 2.0)
 # F16 = the library default (sum-preserving rounding of the tower's 3x3 weights); F16rne = the same mode with plain
 # round-to-nearest weights (SN_W_ROUND=rne): what rounds 1-4 shipped
 MODES = (("F16", api.PREC_F16, None), ("F16rne", api.PREC_F16, "rne"), ("F16X3", api.PREC_F16X3, None), ("FP32", api.PREC_FP32, None))
-CONFIGS = tuple(c for c in (("C2 1280x720 D=192 single", 1280, 720, 192, 1), ("C5 1242x375 D=256 multi", 1242, 375, 256, 4))
+CONFIGS = tuple(c for c in (("C1 960x540 D=48 single", 960, 540, 48, 1), ("C2 1280x720 D=192 single", 1280, 720, 192, 1),
+                            ("C5 1242x375 D=256 multi", 1242, 375, 256, 4))
                 if which == "all" or c[0].lower().startswith(which.lower()))
 BOUND = {"F16": 1e-3, "F16rne": 1e-3, "F16X3": 2e-4, "FP32": 2e-4}
 
