@@ -373,6 +373,7 @@ __global__ __launch_bounds__(256, 1) void k_down01_f16(const int8_t* __restrict_
 // wave per run of up to 32 pixels of one class; A fragments streamed from L2 (80 KB per class), B fragments gathered
 // from the int8 image with per-byte bounds tests.  Same K order and the same two MFMAs per K-step as the inner kernel.
 // ------------------------------------------------------------------------------------------
+template <bool W4>      // W % 4 == 0 (as k_down01_f16): straight-line unconditional loads; otherwise the checked byte-wise form
 __global__ __launch_bounds__(256) void k_down01_border(const int8_t* __restrict__ in6, int H, int W,
                                                        const uint4* __restrict__ wfrag,   // [9][39][hi|lo][64]
                                                        const float* __restrict__ bias,    // [9][32]
@@ -382,9 +383,9 @@ __global__ __launch_bounds__(256) void k_down01_border(const int8_t* __restrict_
   const int lane = threadIdx.x & 63, j = lane & 31, g = lane >> 5;
   const int nT = (Wo - 2 + 31) / 32, nL = (Ho - 2 + 31) / 32, per_img = 4 + 2 * nT + 2 * nL;
   const int wid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
-  if (wid >= per_img * nimg) return;
-  const int img = wid / per_img;
-  int ch = wid - img * per_img;
+  if (wid >= per_img * (nimg >> 1)) return;        // a wave takes its run of pixels in BOTH eyes of a pair (nimg = 2 pairs):
+  const int n = wid / per_img;                     // each A fragment it fetches from L2 then serves two MFMAs per weight half
+  int ch = wid - n * per_img;
   int cls, oy, ox;
   bool valid = true;
   if (ch < 4) {                                    // corners
@@ -412,14 +413,13 @@ __global__ __launch_bounds__(256) void k_down01_border(const int8_t* __restrict_
     oy = 0;
     ox = 0;
   }
-  const int n = img >> 1, eye = img & 1;
-  const int8_t* const base = in6 + ((size_t)n * 6 + eye * 3) * H * (size_t)W;
+  const int8_t* const base = in6 + (size_t)n * 6 * H * (size_t)W;        // eye e: planes 3 e .. 3 e + 2
   const uint4* wsrc = wfrag + (size_t)cls * T::NK * 2 * 64 + lane;
-  f32x16 acc0, acc1;
+  f32x16 acc0[2], acc1[2];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    acc0[r] = bias[cls * kC + (r & 3) + 8 * (r >> 2) + 4 * g];
-    acc1[r] = 0.f;
+    acc0[0][r] = acc0[1][r] = bias[cls * kC + (r & 3) + 8 * (r >> 2) + 4 * g];
+    acc1[0][r] = acc1[1][r] = 0.f;
   }
   const int xw = 4 * ox - 8 + 8 * g;
   // one input channel (13 K-steps) at a time: its 26 window dwords and 26 A fragments are requested together, so the wave
@@ -427,10 +427,10 @@ __global__ __launch_bounds__(256) void k_down01_border(const int8_t* __restrict_
   // W % 4 == 0 (uniform): a dword is wholly inside or outside its row, so the load is unconditional (an outside one reads
   // the plane's first dword) and the selection happens when the value is used — no branch, nothing waits inside the
   // request phase.  Otherwise the checked, byte-wise form.
-  const bool w4 = (W & 3) == 0;
+  constexpr bool w4 = W4;
   auto load4 = [&](const int8_t* row, int x, bool row_ok, bool& ok) -> uint32_t {      // window columns x .. x + 3 of one image row
     uint32_t v = 0;
-    if (w4) {
+    if constexpr (w4) {
       ok = row_ok && x >= 0 && x < W;
       __builtin_memcpy(&v, ok ? row + x : base, 4);
       return v;
@@ -448,44 +448,52 @@ __global__ __launch_bounds__(256) void k_down01_border(const int8_t* __restrict_
   };
 #pragma unroll 1
   for (int c = 0; c < 3; ++c) {
-    uint32_t v0[T::KW], v1[T::KW];
+    uint32_t v0[2][T::KW], v1[2][T::KW];
     uint4 fa[T::KW], fb[T::KW];
-    unsigned keep0 = 0, keep1 = 0;
+    unsigned keep0 = 0, keep1 = 0;                 // (the same for both eyes: same pixel, same window)
 #pragma unroll
     for (int u = 0; u < T::KW; ++u) {
       const int y = 4 * oy - 6 + u;
       const bool row_ok = (unsigned)y < (unsigned)H;
-      const int8_t* row = base + ((size_t)c * H + (row_ok ? y : 0)) * (size_t)W;
-      bool k0, k1;
-      v0[u] = load4(row, xw, row_ok, k0);
-      v1[u] = load4(row, xw + 4, row_ok, k1);
-      keep0 |= k0 ? 1u << u : 0u;
-      keep1 |= k1 ? 1u << u : 0u;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int8_t* row = base + ((size_t)(3 * e + c) * H + (row_ok ? y : 0)) * (size_t)W;
+        bool k0, k1;
+        v0[e][u] = load4(row, xw, row_ok, k0);
+        v1[e][u] = load4(row, xw + 4, row_ok, k1);
+        keep0 |= k0 ? 1u << u : 0u;
+        keep1 |= k1 ? 1u << u : 0u;
+      }
       fa[u] = wsrc[(2 * (c * T::KW + u)) * 64];
       fb[u] = wsrc[(2 * (c * T::KW + u) + 1) * 64];
     }
 #pragma unroll
-    for (int u = 0; u < T::KW; ++u) {
-      const half4 a = i8x4_to_f16((keep0 >> u) & 1u ? v0[u] : 0u), b = i8x4_to_f16((keep1 >> u) & 1u ? v1[u] : 0u);
-      half8 x;
+    for (int u = 0; u < T::KW; ++u)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        x[e] = a[e];
-        x[4 + e] = b[e];
+      for (int e = 0; e < 2; ++e) {
+        const half4 a = i8x4_to_f16((keep0 >> u) & 1u ? v0[e][u] : 0u), b = i8x4_to_f16((keep1 >> u) & 1u ? v1[e][u] : 0u);
+        half8 x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          x[k] = a[k];
+          x[4 + k] = b[k];
+        }
+        acc0[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8*>(&fa[u]), x, acc0[e], 0, 0, 0);
+        acc1[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8*>(&fb[u]), x, acc1[e], 0, 0, 0);
       }
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8*>(&fa[u]), x, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8*>(&fb[u]), x, acc1, 0, 0, 0);
-    }
   }
   if (valid) {
     const size_t plane_b = (size_t)oPH * oPW * 16;
-    char* const p = reinterpret_cast<char*>(out) + (size_t)img * 8 * plane_b + ((size_t)(oy + opy) * oPW + ox + opx) * 16 + g * 8;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float v[4];
+    for (int e = 0; e < 2; ++e) {
+      char* const p = reinterpret_cast<char*>(out) + (size_t)(2 * n + e) * 8 * plane_b + ((size_t)(oy + opy) * oPW + ox + opx) * 16 + g * 8;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = acc0[4 * q + e] + acc1[4 * q + e] * kSplitInv;
-      split_store4(v, p + (size_t)(2 * q) * plane_b, p + (size_t)(2 * q + 1) * plane_b);
+      for (int q = 0; q < 4; ++q) {
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = acc0[e][4 * q + k] + acc1[e][4 * q + k] * kSplitInv;
+        split_store4(v, p + (size_t)(2 * q) * plane_b, p + (size_t)(2 * q + 1) * plane_b);
+      }
     }
   }
 }
