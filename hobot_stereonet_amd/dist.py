@@ -301,8 +301,14 @@ class PeerPullGather:
         return [self.local[s] if r == self.dst else self.recv[s][r] for r in range(self.world)]
 
     def close(self) -> None:
+        import gc
         import os
         self.peer_views = None
+        self.recv = None
+        gc.collect()                          # the IPC mappings go with the last reference to the opened tensors
+        if self.cuda:
+            torch.cuda.synchronize(self.device)
+            torch.cuda.ipc_collect()          # torch caches opened IPC allocations: release them before the producers exit
         dist.barrier(group=self.ctl)          # nobody unlinks / frees while a peer may still map it
         for p in self._paths:
             try:
