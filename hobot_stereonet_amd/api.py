@@ -18,7 +18,9 @@ import numpy as np
 from . import build as _build
 
 SN_MEM_HOST, SN_MEM_DEVICE = 0, 1
-PREC_DEFAULT, PREC_F16X3, PREC_F16, PREC_FP32 = 0, 1, 2, 3      # include/stereonet_hip.h; 0 selects PREC_F16
+PREC_DEFAULT, PREC_F16X3, PREC_F16, PREC_FP32, PREC_AUTO = 0, 1, 2, 3, 4      # include/stereonet_hip.h; 0 selects PREC_AUTO
+PREC_NAMES = {PREC_F16X3: "f16x3", PREC_F16: "f16", PREC_FP32: "fp32", PREC_AUTO: "auto"}
+ABI_VERSION = 3
 STAGES = ("features", "aggregate", "refine", "refine_conv", "total", "dominant")
 
 
@@ -33,7 +35,22 @@ class SnIoInfo(C.Structure):
                 ("max_batch", C.c_int), ("precision", C.c_int), ("task_num", C.c_int), ("device", C.c_int),
                 ("out_scale", C.c_float), ("in_bytes", C.c_size_t), ("out_bytes", C.c_size_t),
                 ("flops_per_pair", C.c_double), ("refine_chunk", C.c_int), ("piece", C.c_int),
-                ("tower_streams", C.c_int), ("refine_levels", C.c_int)]
+                ("tower_streams", C.c_int), ("refine_levels", C.c_int), ("precision_selected", C.c_int)]
+
+
+class SnRefineStats(C.Structure):
+    """sn_refine_stats (include/stereonet_hip.h): the refinement statistic and SN_PREC_AUTO's state."""
+    _fields_ = [("levels", C.c_int), ("precision", C.c_int), ("precision_selected", C.c_int), ("precision_last", C.c_int),
+                ("calls", C.c_uint64), ("pairs", C.c_uint64), ("switches", C.c_uint64), ("reruns", C.c_uint64),
+                ("level_px", C.c_double * 4), ("residual_px", C.c_double), ("running_px", C.c_double),
+                ("envelope_px", C.c_double), ("limit_px", C.c_double), ("selfcheck_epe_px", C.c_double),
+                ("selfcheck_residual_px", C.c_double)]
+
+
+class SnAutoState(C.Structure):
+    """sn_auto_state: SN_PREC_AUTO's state machine (pure functions sn_auto_*)."""
+    _fields_ = [("mode", C.c_int), ("calm", C.c_int), ("envelope_px", C.c_double), ("epe_per_px", C.c_double),
+                ("running_px", C.c_double), ("switches", C.c_uint64)]
 
 
 class StereoNetError(RuntimeError):
@@ -111,11 +128,18 @@ def load_library(path: Optional[str] = None):
     lib.sn_dbg_read.argtypes = [vp, C.c_char_p, fp, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.sn_dbg_copy_limited.argtypes = [vp, vp, C.c_size_t, ip, vp]
     lib.sn_depth_from_raw.argtypes = [vp, ip, i32p, C.c_float, C.c_float, fp, fp, ip, vp]
+    lib.sn_get_refine_stats.argtypes = [vp, C.POINTER(SnRefineStats)]
+    lib.sn_auto_init.argtypes = [C.POINTER(SnAutoState), ip]
+    lib.sn_auto_observe.argtypes = [C.POINTER(SnAutoState), C.c_double]
+    lib.sn_auto_limit_px.argtypes = [C.POINTER(SnAutoState)]
+    lib.sn_auto_limit_px.restype = C.c_double
+    lib.sn_auto_envelope_px.argtypes = [ip]
+    lib.sn_auto_envelope_px.restype = C.c_double
     for name in ("sn_create", "sn_destroy", "sn_get_io_info", "sn_infer_i8", "sn_infer_batch", "sn_preprocess_nv12",
                  "sn_infer_sbs_nv12", "sn_preprocess_sbs_nv12_batch", "sn_submit", "sn_submit_nv12", "sn_wait", "sn_synchronize", "sn_set_profiling",
                  "sn_get_stage_ms", "sn_get_dominant_kernel", "sn_mgpu_shard", "sn_mgpu_create", "sn_mgpu_destroy",
                  "sn_mgpu_get_info", "sn_mgpu_get_handle", "sn_mgpu_infer_batch", "sn_mgpu_infer_batch_device",
-                 "sn_mgpu_submit_device", "sn_mgpu_wait", "sn_mgpu_ring_init", "sn_mgpu_ring_submit", "sn_mgpu_ring_wait", "sn_dbg_conv2d", "sn_dbg_down0", "sn_dbg_compose_down01", "sn_dbg_round_kernels_f16", "sn_dbg_down01", "sn_dbg_refin", "sn_dbg_conv3d", "sn_dbg_ref_conv_f16", "sn_dbg_ref_conv_f16x3", "sn_dbg_ref_block_f16", "sn_dbg_ref_tail_f16", "sn_dbg_read", "sn_dbg_copy_limited", "sn_depth_from_raw"):
+                 "sn_mgpu_submit_device", "sn_mgpu_wait", "sn_mgpu_ring_init", "sn_mgpu_ring_submit", "sn_mgpu_ring_wait", "sn_dbg_conv2d", "sn_dbg_down0", "sn_dbg_compose_down01", "sn_dbg_round_kernels_f16", "sn_dbg_down01", "sn_dbg_refin", "sn_dbg_conv3d", "sn_dbg_ref_conv_f16", "sn_dbg_ref_conv_f16x3", "sn_dbg_ref_block_f16", "sn_dbg_ref_tail_f16", "sn_dbg_read", "sn_dbg_copy_limited", "sn_depth_from_raw", "sn_get_refine_stats", "sn_auto_init", "sn_auto_observe"):
         getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
@@ -129,7 +153,7 @@ def round_kernels_f16(w):
     out = np.empty_like(a)
     rc = load_library().sn_dbg_round_kernels_f16(a.ctypes.data, a.size // 9, out.ctypes.data)
     if rc:
-        raise StereoNetError(f"sn_dbg_round_kernels_f16: {error_string(rc)}")
+        raise StereoNetError(rc, "sn_dbg_round_kernels_f16")
     return out
 
 
@@ -143,7 +167,7 @@ def compose_down01(w0, b0, w1, b1):
     rc = load_library().sn_dbg_compose_down01(w0.ctypes.data, b0.ctypes.data, w1.ctypes.data, b1.ctypes.data,
                                               weff.ctypes.data, beff.ctypes.data)
     if rc:
-        raise StereoNetError(f"sn_dbg_compose_down01: {error_string(rc)}")
+        raise StereoNetError(rc, "sn_dbg_compose_down01")
     return weff, beff
 
 
@@ -176,6 +200,7 @@ class StereoNetHIP:
         self.max_batch = info.max_batch
         self.refine_chunk, self.piece, self.tower_streams = info.refine_chunk, info.piece, info.tower_streams
         self.refine_levels = info.refine_levels
+        self.precision = info.precision
         self.out_scale = float(info.out_scale)
         self.flops_per_pair = float(info.flops_per_pair)
 
@@ -201,6 +226,24 @@ class StereoNetHIP:
 
     def __exit__(self, *exc):
         self.close()
+
+    # -- refinement statistic / SN_PREC_AUTO ----------------------------------------------------
+    def refine_stats(self) -> dict:
+        """sn_get_refine_stats as a dict (precisions as names): what the refinement moved the last call's maps by, and
+        which arithmetic an SN_PREC_AUTO handle is in."""
+        st = SnRefineStats()
+        self._check(self._lib.sn_get_refine_stats(self._h, C.byref(st)), "sn_get_refine_stats")
+        d = {k: getattr(st, k) for k, _ in SnRefineStats._fields_ if k != "level_px"}
+        d["level_px"] = [float(v) for v in st.level_px][:max(1, st.levels)]
+        for k in ("precision", "precision_selected", "precision_last"):
+            d[k] = PREC_NAMES.get(d[k], str(d[k]))
+        return d
+
+    @property
+    def precision_selected(self) -> int:
+        info = SnIoInfo()
+        self._check(self._lib.sn_get_io_info(self._h, C.byref(info)), "sn_get_io_info")
+        return info.precision_selected
 
     # -- Run (host numpy buffers) ---------------------------------------------------------------
     def infer(self, in6: np.ndarray, want_disp: bool = True, want_raw: bool = True):

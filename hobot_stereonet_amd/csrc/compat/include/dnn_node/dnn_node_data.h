@@ -51,6 +51,11 @@ struct DnnNodeRunTimeStat {
   int infer_time_ms = 0;
   int parse_time_ms = 0;
   bool fps_updated = false;
+  // Extension of this backend (filled together with fps_updated): what the refinement moved the last request's map by
+  // (sn_get_refine_stats: residual_px) and the arithmetic its map was computed in ("f16", "f16x3", "fp32"; under the
+  // default SN_PREC_AUTO the engine leaves the fp16 tower when that statistic leaves its envelope)
+  float refine_residual_px = 0.f;
+  const char* arithmetic = "f16";
 };
 
 struct DnnNodeOutput {

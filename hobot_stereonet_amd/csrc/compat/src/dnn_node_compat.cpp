@@ -112,7 +112,9 @@ int DnnNode::Init() {
   cfg.max_batch = 1;
   cfg.task_num = dnn_node_para_ptr_->task_num;
   const char* prec = getenv("STEREONET_PRECISION");   // knob kept out of the ROS parameter surface
-  cfg.precision = (prec && !strcmp(prec, "fp32")) ? SN_PREC_FP32 : (prec && !strcmp(prec, "f16x3")) ? SN_PREC_F16X3 : SN_PREC_F16;
+  // unset / "auto": SN_PREC_AUTO (the fp16 tower while the model stays inside its envelope, the split mode otherwise)
+  cfg.precision = (prec && !strcmp(prec, "fp32")) ? SN_PREC_FP32 : (prec && !strcmp(prec, "f16x3")) ? SN_PREC_F16X3
+                  : (prec && !strcmp(prec, "f16")) ? SN_PREC_F16 : SN_PREC_AUTO;
   const int rc = sn_create(dnn_node_para_ptr_->model_file.c_str(), &cfg, &engine_);
   if (rc != SN_OK) {
     RCLCPP_ERROR(rclcpp::get_logger("dnn"), "load model %s failed: %s", dnn_node_para_ptr_->model_file.c_str(),
@@ -159,6 +161,11 @@ void DnnNode::UpdateStat(const std::shared_ptr<DnnNodeOutput>& out, float infer_
     in_count_ = out_count_ = 0;
     stat_t0_ = t;
     out->rt_stat->fps_updated = true;
+    sn_refine_stats rs;
+    if (sn_get_refine_stats(engine_, &rs) == SN_OK) {
+      out->rt_stat->refine_residual_px = (float)rs.residual_px;
+      out->rt_stat->arithmetic = rs.precision_last == SN_PREC_F16X3 ? "f16x3" : rs.precision_last == SN_PREC_FP32 ? "fp32" : "f16";
+    }
   }
   out->rt_stat->input_fps = last_in_fps_;
   out->rt_stat->output_fps = last_out_fps_;

@@ -353,8 +353,9 @@ int StereonetNode::PostProcess(const std::shared_ptr<hobot::dnn_node::DnnNodeOut
   if (st && st->fps_updated)
     RCLCPP_WARN(kLog,
                 "input fps: %.2f, out fps: %.2f, preprocess time ms: %d, infer time ms: %d, msg preparation for pub "
-                "time cost ms: %d",
-                st->input_fps, st->output_fps, request->preprocess_time_ms, st->infer_time_ms, pack_ms);
+                "time cost ms: %d, refinement residual px: %.3f, arithmetic: %s",
+                st->input_fps, st->output_fps, request->preprocess_time_ms, st->infer_time_ms, pack_ms,
+                st->refine_residual_px, st->arithmetic);
   return 0;
 }
 

@@ -208,6 +208,20 @@ struct UpScale {
   float rs, mul;            // 1 / factor, factor (the values are disparities in pixels of the finer grid)
 };
 
+// Refinement statistic (sn_get_refine_stats, SN_PREC_AUTO): every head form adds the |D r| of the pixels it writes — what the
+// refinement level moves the map by, in the level's pixels.  Per-lane partial sums meet in a wave reduction and leave as ONE
+// 64-bit fixed-point atomic per wave (units of 2^-20 px): integer addition does not depend on the order the waves arrive in,
+// so the statistic is identical from run to run, and nothing of it feeds back into the maps (outputs bit-unchanged).
+// (|dmax * acc| and not |d - up|: `up` is itself a product (map value x factor) and `up + dmax * acc` contracts into ONE fma
+// with whichever product has fewer uses; a second use of `up` flipped that choice and the last bit of d — seen as a
+// difference against the round-5 library wherever dmax is not a power of two, profiles/r06_ab_outputs.txt)
+constexpr float kStatScale = 1048576.0f;
+__device__ __forceinline__ void refine_stat_commit(unsigned long long* stat, float lane_sum) {
+#pragma unroll
+  for (int off = 32; off; off >>= 1) lane_sum += __shfl_xor(lane_sum, off);
+  if (stat != nullptr && (threadIdx.x & 63) == 0) atomicAdd(stat, (unsigned long long)(lane_sum * kStatScale + 0.5f));
+}
+
 // bilinear upsample, align_corners=False (half-pixel centres, edge clamp), values x factor
 __device__ __forceinline__ float upsample_map(const float* low, int hl, int wl, int y, int x, UpScale u) {
   float sy = ((float)y + 0.5f) * u.rs - 0.5f;
@@ -1172,11 +1186,13 @@ __global__ __launch_bounds__(256) void k_head_final(const float* __restrict__ xi
                                                     float dmax, float inv_q,
                                                     float* __restrict__ out_disp,       // nullable [n][H][W]
                                                     int32_t* __restrict__ out_raw,      // nullable [n][H][W]
-                                                    UpScale ups) {
+                                                    UpScale ups,
+                                                    unsigned long long* __restrict__ stat) {   // nullable: sum |D r|
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
   const int n = blockIdx.z;
-  if (x >= W || y >= H) return;
+  float moved = 0.f;
+  if (x < W && y < H) {
   const size_t plane = (size_t)Hp * Wp;
   const float* src = xin + (size_t)n * kC * plane;
   float acc = bias;
@@ -1197,10 +1213,13 @@ __global__ __launch_bounds__(256) void k_head_final(const float* __restrict__ xi
   }
   const float up = upsample_map(disp_low + (size_t)n * hl * wl, hl, wl, y, x, ups);
   float d = up + dmax * acc;
+  moved = fabsf(dmax * acc);
   d = d > 0.f ? d : 0.f;
   const size_t o = ((size_t)n * H + y) * W + x;
   if (out_disp) out_disp[o] = d;
   if (out_raw) out_raw[o] = (int32_t)__float2int_rn(d * inv_q);
+  }
+  refine_stat_commit(stat, moved);
 }
 
 
@@ -2120,7 +2139,8 @@ __global__ __launch_bounds__(256) void k_head_final_f16(const uint4* __restrict_
                                                         float bias, const float* __restrict__ disp_low, int hl,
                                                         int wl, int H, int W, float dmax, float inv_q,
                                                         float* __restrict__ out_disp, int32_t* __restrict__ out_raw,
-                                                        int tiles_x, int tiles_y, UpScale ups) {
+                                                        int tiles_x, int tiles_y, UpScale ups,
+                                                        unsigned long long* __restrict__ stat) {   // nullable: sum |D r|
   using T = HeadTile<TH>;
   extern __shared__ __attribute__((aligned(16))) float s_p[];           // [9][RP][CP]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -2187,6 +2207,7 @@ __global__ __launch_bounds__(256) void k_head_final_f16(const uint4* __restrict_
   }
   __syncthreads();
   const float* dl = disp_low + (size_t)n * hl * wl;
+  float moved = 0.f;
   for (int p = tid; p < T::TH * T::TWO; p += 256) {
     const int oy = p / T::TWO, ox = p - oy * T::TWO;
     const int y = y0 + oy, x = x0 + ox;
@@ -2198,11 +2219,13 @@ __global__ __launch_bounds__(256) void k_head_final_f16(const uint4* __restrict_
       for (int kx = 0; kx < 3; ++kx) acc += s_p[(ky * 3 + kx) * T::PLANE + (oy + ky) * T::CP + ox + kx];
     const float up = upsample_map(dl, hl, wl, y, x, ups);
     float d = up + dmax * acc;
+    moved += fabsf(dmax * acc);
     d = d > 0.f ? d : 0.f;
     const size_t o = ((size_t)n * H + y) * W + x;
     if (out_disp) out_disp[o] = d;
     if (out_raw) out_raw[o] = (int32_t)__float2int_rn(d * inv_q);
   }
+  refine_stat_commit(stat, moved);
 }
 
 }  // namespace sn

@@ -240,6 +240,7 @@ struct StreamHeadArgs {
   float bias, dmax, inv_q;
   int hl, wl, H, W;        // H, W: size of the output maps (<= g.H, g.W)
   UpScale ups;
+  unsigned long long* stat = nullptr;   // nullable: sum of |D r| over the written pixels (refine_stat_commit)
 };
 
 template <int DIL, int TW, int R, int NXS, int NWR, bool HEAD = false>
@@ -358,6 +359,7 @@ __global__ __launch_bounds__(128 * NWR, NWR / 2) __attribute__((amdgpu_waves_per
       return (int)sx;
     };
     int p4 = 0;                           // HEAD: (4 q) mod PROWS, the P ring position of slot q
+    float moved = 0.f;                    // HEAD: this lane's sum of |D r| (refinement statistic)
     dm.step(0, 0, f0, f1, sc.hsub);
     dma_issue(dm, 0);
     dm.step(1, 0, f0, f1, sc.hsub);
@@ -412,8 +414,10 @@ __global__ __launch_bounds__(128 * NWR, NWR / 2) __attribute__((amdgpu_waves_per
             const float v = hy * (hx * w0[x0 - cb] + lx * w0[x1 - cb]) + ly * (hx * w0[64 + x0 - cb] + lx * w0[64 + x1 - cb]);
             const float up = v * ha.ups.mul;
             float d = up + ha.dmax * acc;
+            const float mv = fabsf(ha.dmax * acc);
             d = d > 0.f ? d : 0.f;
             if (lane >= 1 && lane <= T::OW && X < ha.W) {
+              moved += mv;
               const size_t oi = ((size_t)fin_img * ha.H + o) * ha.W + X;
               if (ha.out_disp) ha.out_disp[oi] = d;
               if (ha.out_raw) ha.out_raw[oi] = (int32_t)__float2int_rn(d * ha.inv_q);
@@ -508,6 +512,7 @@ __global__ __launch_bounds__(128 * NWR, NWR / 2) __attribute__((amdgpu_waves_per
       qt = qt + 1 == T::NTS ? 0 : qt + 1;
       p4 = p4 + R >= T::PROWS ? p4 + R - T::PROWS : p4 + R;
     }
+    if constexpr (HEAD) refine_stat_commit(ha.stat, moved);
     SN_STAMP_WG(1);
   } else {
     // ============================ conv2 waves: conv2 + residual + stores ============================

@@ -36,6 +36,7 @@ constexpr int kNDown = 4, kNFeatRes = 6, kNAgg = 4, kNRefRes = 6;
 constexpr int kRefDil[kNRefRes] = {1, 2, 4, 8, 1, 1};
 constexpr float kOutScale = 2.60443857769133e-6f;   // stereonet_node.cpp:282
 constexpr double kWireFactor = 16.0 * 12.0;         // parser.cpp:86
+constexpr double kAutoEnvelopeSingle = 1.0, kAutoEnvelopeMulti = 2.9;   // sn_auto_envelope_px
 constexpr int kMaxPieceEvents = 64;
 constexpr int kMaxTowerStreams = 2;
 
@@ -98,11 +99,18 @@ struct HeadLayer {          // C -> 1 layers (VALU kernels)
 };
 
 constexpr int kMaxLevels = 4, kMultiLevels = 4;              // hierarchical refinement: 1/8, 1/4, 1/2, 1
+constexpr int kStatWords = 8;                                // refinement statistic: [level 0..3] sum |D r|, [4] self-check sum |a - b|
 constexpr int kTileCtrStride = 8 * 16;                       // uints per tower launch (one 64-B line per XCD)
 constexpr size_t kTileCtrBytes = (size_t)2 * 6 * kTileCtrStride * sizeof(unsigned);   // 2 * kNRefRes launches
 
 struct Workspace {          // activations for up to `nb` pairs
   int nb = 0, rb = 0, pb = 0;   // batch capacity, pairs per tower launch, pairs per low-res piece
+  int rb_x3 = 0;                // SN_PREC_AUTO: pairs per tower launch while the handle runs in SN_PREC_F16X3 (same buffers)
+  int rbk_x3[4] = {};           // ... and per coarse level
+  // refinement statistic: one 64-bit fixed-point sum of |D r| per level (refine_stat_commit) + the self-check's sum at [4];
+  // copied to the pinned twin at the end of every forward()
+  unsigned long long* stats = nullptr;
+  unsigned long long* stats_host = nullptr;
   int8_t* in6 = nullptr;
   float* down[3] = {nullptr, nullptr, nullptr};
   float* low[3] = {nullptr, nullptr, nullptr};
@@ -136,7 +144,8 @@ struct Workspace {          // activations for up to `nb` pairs
 struct Tower {               // one refinement level: weights (in the forms the precision mode needs) + geometry
   ConvLayer rin, rres[kNRefRes][2];
   Down0F16 refin;
-  RefLayerF16 rres16[kNRefRes][2];
+  RefLayerF16 rres16[kNRefRes][2];      // SN_PREC_F16 (and AUTO): plain fp16 A fragments
+  RefLayerF16 rres16x3[kNRefRes][2];    // SN_PREC_F16X3 (and AUTO): hi / lo split A fragments
   HeadLayer rout;
   RefGeom rg{};
   int Hk = 0, Wk = 0;        // padded size of this level: Hp >> k, Wp >> k
@@ -155,8 +164,23 @@ struct Slot {                // async request slot (sn_submit / sn_wait)
   // hipGraph of {H2D, forward, D2H} per output mask (1 = int32, 2 = float, 3 = both): the second request with a
   // given mask is captured, later ones replay it (the ~45 launches of a single-pair forward are launch-bound)
   // the first index is the input kind: 0 = int8 model tensor (sn_submit), 1 = side-by-side NV12 frame (sn_submit_nv12)
-  hipGraphExec_t gexec[2][4] = {};
-  int uses[2][4] = {};
+  // the last index is the arithmetic the request runs in (0 = SN_PREC_F16X3, 1 = anything else): SN_PREC_AUTO may change it
+  hipGraphExec_t gexec[2][4][2] = {};
+  int uses[2][4][2] = {};
+  int mode_run = 0;          // arithmetic of the request in flight (SN_PREC_*)
+};
+
+// SN_PREC_AUTO (include/stereonet_hip.h): the handle starts in SN_PREC_F16 and moves to SN_PREC_F16X3 when the refinement
+// statistic leaves the envelope inside which the fp16 tower keeps EPE <= 1e-3 px, or when the self-check says so.
+struct AutoCtl {
+  sn_auto_state st{};
+  bool calibrated = false;       // the self-check (one pair in both arithmetics) has run since the handle last entered F16
+  bool pending = false;          // a stream-enqueued call's statistic has not been folded in yet (ev_stats marks it)
+  int pending_mode = 0, pending_n = 0;
+  double selfcheck_epe = -1.0, selfcheck_res = -1.0;
+  double last_level[4] = {}, last_res = 0.0;
+  int last_mode = 0;
+  uint64_t calls = 0, pairs = 0, reruns = 0;
 };
 
 }  // namespace
@@ -165,6 +189,12 @@ struct sn_handle {
   int device = 0;
   int W = 0, H = 0, D = 0, Wp = 0, Hp = 0, wl = 0, hl = 0, Dl = 0;
   int max_batch = 1, precision = SN_PREC_F16, task_num = 4, refine_chunk = 1, piece = 16;
+  // `precision` is what the caller configured; SN_PREC_AUTO runs in actl.st.mode (SN_PREC_F16 or SN_PREC_F16X3)
+  AutoCtl actl;
+  std::mutex mu_cal;         // the self-check's scratch maps (chk) are shared by every slot
+  float* chk[2] = {nullptr, nullptr};
+  hipEvent_t ev_stats = nullptr;
+  int refine_chunk_x3 = 1;   // SN_PREC_AUTO: pairs per tower launch in SN_PREC_F16X3
   hipStream_t stream = nullptr;
   // piece pipeline: the low-resolution branch of piece k+1 runs on s_low while the refinement towers of piece k run
   // on s_tow[]; consecutive tower chunks alternate between the tower streams so that the ramp-up / tail of one
@@ -1093,17 +1123,18 @@ inline bool stream_block_supports(int dil) {
 
 hipError_t launch_head_final_f16(hipStream_t st, bool split, const uint4* x, size_t lo_slots, const RefGeom& g,
                                  const float* w, float bias, const float* disp_low, int hl, int wl, int H, int W, float dmax,
-                                 float inv_q, UpScale ups, float* out_disp, int32_t* out_raw, int nimg) {
+                                 float inv_q, UpScale ups, float* out_disp, int32_t* out_raw, int nimg,
+                                 unsigned long long* stat = nullptr) {
   constexpr int TH = 16;
   using T = HeadTile<TH>;
   const int tiles_x = (W + T::TWO - 1) / T::TWO, tiles_y = (H + TH - 1) / TH;
   const dim3 grid((unsigned)(tiles_x * tiles_y * nimg));
   if (split)
     hipLaunchKernelGGL((k_head_final_f16<true, TH>), grid, dim3(256), T::LDS_BYTES, st, x, lo_slots, g, w, bias, disp_low, hl,
-                       wl, H, W, dmax, inv_q, out_disp, out_raw, tiles_x, tiles_y, ups);
+                       wl, H, W, dmax, inv_q, out_disp, out_raw, tiles_x, tiles_y, ups, stat);
   else
     hipLaunchKernelGGL((k_head_final_f16<false, TH>), grid, dim3(256), T::LDS_BYTES, st, x, (size_t)0, g, w, bias, disp_low,
-                       hl, wl, H, W, dmax, inv_q, out_disp, out_raw, tiles_x, tiles_y, ups);
+                       hl, wl, H, W, dmax, inv_q, out_disp, out_raw, tiles_x, tiles_y, ups, stat);
   return hipGetLastError();
 }
 
@@ -1182,9 +1213,13 @@ inline int level_chunk_pairs(int rb, int pb, int lv) {     // coarse level lv ru
   return lv == 0 ? rb : (r < pb ? (int)r : pb);
 }
 
-int alloc_ws(sn_handle* h, Workspace* ws, int nb, int rb, int ns) {
+// rb_x3: pairs per tower launch while an SN_PREC_AUTO handle runs in SN_PREC_F16X3 (0 = rb: every other precision)
+int alloc_ws(sn_handle* h, Workspace* ws, int nb, int rb, int ns, int rb_x3 = 0) {
+  const bool is_auto = h->precision == SN_PREC_AUTO;
+  if (rb_x3 <= 0 || rb_x3 > rb) rb_x3 = rb;
   ws->nb = nb;
   ws->rb = rb;
+  ws->rb_x3 = rb_x3;
   ws->ns = (ns > 1 && nb > rb) ? (ns < kMaxTowerStreams ? ns : kMaxTowerStreams) : 1;
   if (h->levels > 1) ws->ns = 1;      // the level maps of a piece live in one buffer set: one tower stream
   ws->pb = piece_pairs(h, nb, rb);
@@ -1195,7 +1230,8 @@ int alloc_ws(sn_handle* h, Workspace* ws, int nb, int rb, int ns) {
   // or a tensor would not fit 32-bit byte offsets; the plain ones are then not allocated at all (0.9 GB per 16-pair piece)
   bool padded_down = h->precision != SN_PREC_FP32 && down_dma_enabled();
   size_t downp_bytes[3] = {0, 0, 0};
-  for (int k = 0; k < 3 && padded_down; ++k) {      // input of down-conv k + 1: output grid (Hp, Wp) >> (k + 2)
+  // (folded down-convs 0 + 1: the half-resolution tensor never exists, so its size cannot veto the zero-bordered layout)
+  for (int k = h->fold_down01 ? 1 : 0; k < 3 && padded_down; ++k) {      // input of down-conv k + 1: output grid (Hp, Wp) >> (k + 2)
     const SlotGeom g = down_in_geom(h->Hp >> (k + 2), h->Wp >> (k + 2));
     downp_bytes[k] = (size_t)2 * pb * 8 * g.PH * g.PW * sizeof(uint4);
     padded_down = downp_bytes[k] < ((size_t)1 << 32);
@@ -1229,35 +1265,43 @@ int alloc_ws(sn_handle* h, Workspace* ws, int nb, int rb, int ns) {
   }
   HIP_TRY(h, dalloc(&ws->cost, (size_t)nb * h->Dl * hw));
   HIP_TRY(h, dalloc(&ws->disp_low, (size_t)nb * hw));
+  // hi tensor (+ lo tensor behind it in SN_PREC_F16X3).  An AUTO handle keeps the fp16 layout for rb pairs and puts the lo
+  // tensor of its (smaller) split chunks BEHIND that region: the split mode's hi tensor then sits where the fp16 tensors of
+  // the first pairs do — same image pixels, same zero borders — and the lo tensor never touches a border of the fp16
+  // layout (with the lo tensor directly behind rb_x3 pairs its pixels landed on the zero borders of pair rb_x3's fp16 plane:
+  // the first fp16 call after a split call then read non-zero padding — caught by tests/test_gpu_auto.py)
+  auto tensor_slots = [&](const RefGeom& rg, int pairs, int pairs_x3) {
+    const size_t one = ref16_slots(rg, pairs) + ref_slack(rg), lo = ref16_slots(rg, pairs_x3) + ref_slack(rg);
+    return h->precision == SN_PREC_F16X3 ? 2 * one : (is_auto ? one + lo : one);
+  };
   if (h->precision == SN_PREC_FP32) {
     for (int k = 0; k < 2 * ws->ns; ++k) HIP_TRY(h, dalloc(&ws->ref[k], (size_t)rb * kC * HWp));
   } else {
-    for (int k = 0; k < 2 * ws->ns; ++k) {
-      const size_t slots = (ref16_slots(h->tw[0].rg, rb) + ref_slack(h->tw[0].rg)) * (h->precision == SN_PREC_F16X3 ? 2 : 1);
-      HIP_TRY(h, alloc_ref16(h->tw[0].rg, slots, &ws->ref16_raw[k], &ws->ref16[k]));
-    }
+    for (int k = 0; k < 2 * ws->ns; ++k)
+      HIP_TRY(h, alloc_ref16(h->tw[0].rg, tensor_slots(h->tw[0].rg, rb, rb_x3), &ws->ref16_raw[k], &ws->ref16[k]));
     // fine-grained: the queue words must be coherent across the 8 XCD L2s at device scope and with the memset
     // one counter block per tower chunk of a forward(): chunks never straddle a low-resolution piece, so every
     // piece may end with one short chunk (forward() numbers the chunks with a running ordinal)
     // a hierarchical model adds the coarse-level launches of every piece: one block per (piece, level, coarse chunk)
-    ws->n_chunks = (nb + rb - 1) / rb + (nb + pb - 1) / pb + 2;
+    ws->n_chunks = (nb + rb_x3 - 1) / rb_x3 + (nb + pb - 1) / pb + 2;
     for (int lv = 1; lv < h->levels; ++lv) {
-      const int rbk = level_chunk_pairs(rb, pb, lv);
+      const int rbk = level_chunk_pairs(rb_x3, pb, lv);
       ws->n_chunks += ((nb + pb - 1) / pb + 2) * ((pb + rbk - 1) / rbk + 1);
     }
     HIP_TRY(h, hipExtMallocWithFlags(reinterpret_cast<void**>(&ws->tile_ctr), kTileCtrBytes * ws->n_chunks, hipDeviceMallocFinegrained));
   }
   ws->rbk[0] = rb;
+  ws->rbk_x3[0] = rb_x3;
   for (int lv = 1; lv < h->levels; ++lv) {
     const Tower& T = h->tw[lv];
     const size_t HWk = (size_t)T.Hk * T.Wk;
     ws->rbk[lv] = level_chunk_pairs(rb, pb, lv);
+    ws->rbk_x3[lv] = level_chunk_pairs(rb_x3, pb, lv);
     for (int k = 0; k < 2; ++k) {
       if (h->precision == SN_PREC_FP32) {
         HIP_TRY(h, dalloc(&ws->ref_lv[lv][k], (size_t)ws->rbk[lv] * kC * HWk));
       } else {
-        const size_t slots = (ref16_slots(T.rg, ws->rbk[lv]) + ref_slack(T.rg)) * (h->precision == SN_PREC_F16X3 ? 2 : 1);
-        HIP_TRY(h, alloc_ref16(T.rg, slots, &ws->ref16_lv_raw[lv][k], &ws->ref16_lv[lv][k]));
+        HIP_TRY(h, alloc_ref16(T.rg, tensor_slots(T.rg, ws->rbk[lv], ws->rbk_x3[lv]), &ws->ref16_lv_raw[lv][k], &ws->ref16_lv[lv][k]));
       }
     }
     HIP_TRY(h, dalloc(&ws->pyr[lv], (size_t)pb * 3 * HWk));
@@ -1266,6 +1310,10 @@ int alloc_ws(sn_handle* h, Workspace* ws, int nb, int rb, int ns) {
   HIP_TRY(h, dalloc(&ws->out_disp, (size_t)nb * HW));
   HIP_TRY(h, dalloc(&ws->out_raw, (size_t)nb * HW));
   HIP_TRY(h, dalloc(&ws->nv12, (size_t)HW * 3));
+  HIP_TRY(h, dalloc(&ws->stats, kStatWords));
+  HIP_TRY(h, memset_now(ws->stats, 0, kStatWords * sizeof(unsigned long long)));
+  HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&ws->stats_host), kStatWords * sizeof(unsigned long long), hipHostMallocDefault));
+  memset(ws->stats_host, 0, kStatWords * sizeof(unsigned long long));
   return SN_OK;
 }
 
@@ -1292,6 +1340,8 @@ void free_ws(Workspace* ws) {
   hipFree(ws->out_disp);
   hipFree(ws->out_raw);
   hipFree(ws->nv12);
+  hipFree(ws->stats);
+  if (ws->stats_host) hipHostFree(ws->stats_host);
   *ws = Workspace();
 }
 
@@ -1488,16 +1538,19 @@ inline int first_piece(const sn_handle* h, const Workspace& ws, int n) {
 //   H, W       size of the level's output map (the image for level 0, the whole padded level otherwise)
 //   dnorm      D / 2^level: disparity normalisation at the tower input and residual scale at its output
 //   od / orw   float map and (level 0 only) wire map, both nullable
-//   cap        pairs the activation buffers were allocated for (c <= cap)
+//   cap        pairs the hi region of the activation buffers holds: the lo tensor of SN_PREC_F16X3 starts behind it (c <= cap)
+//   mode       SN_PREC_F16 / SN_PREC_F16X3 / SN_PREC_FP32: the arithmetic of this call (an SN_PREC_AUTO handle holds two)
+//   stat       the level's refinement statistic (sum of |D r|, refine_stat_commit)
 int refine_level(sn_handle* h, Workspace& ws, hipStream_t st, const Tower& T, float* rx, float* rt, uint4* rx16,
                  uint4* rt16, const float* src, int sh, int sw, UpScale ups, const void* img_src, bool pyr, int H, int W,
-                 float dnorm, float* od, int32_t* orw, unsigned* chunk_ctr, int c, int cap, bool pe) {
+                 float dnorm, float* od, int32_t* orw, unsigned* chunk_ctr, int c, int cap, bool pe, int mode,
+                 unsigned long long* stat) {
   const int ncu = h->num_cu;
   const int Hk = T.Hk, Wk = T.Wk;
   // The wire factor is the reference's literal 16 * 12 for EVERY dmax (parser.cpp:86, stereonet_node.cpp:288,
   // publisher_member_function.py:75): the unmodified consumers recover pixels whatever D the model was built for.
   const float inv_q = (float)(1.0 / (kWireFactor * (double)kOutScale));
-  if (h->precision == SN_PREC_FP32) {
+  if (mode == SN_PREC_FP32) {
     LoadRefineIn ld{src, reinterpret_cast<const int8_t*>(img_src), sh, sw, H, W, Hk, Wk, 1.0f / dnorm, ups,
                     pyr ? reinterpret_cast<const float*>(img_src) : nullptr};
     if (Hk * Wk <= 64 * 128)
@@ -1512,7 +1565,7 @@ int refine_level(sn_handle* h, Workspace& ws, hipStream_t st, const Tower& T, fl
     if (pe) HIP_TRY(h, hipEventRecord(h->ev[5], st));
     dim3 grid((W + 63) / 64, (H + 3) / 4, c);
     hipLaunchKernelGGL(k_head_final, grid, dim3(256), 0, st, rx, T.rout.w, T.rout.bias, src, sh, sw, Hk, Wk, H, W, dnorm,
-                       inv_q, od, orw, ups);
+                       inv_q, od, orw, ups, stat);
   } else {
     // fp16 tower: ref.in writes the NCHW8c fp16 tensor, the 12 C->C convs run on v_mfma_f32_32x32x16_f16, the head
     // reads fp16 and finishes in fp32
@@ -1530,7 +1583,7 @@ int refine_level(sn_handle* h, Workspace& ws, hipStream_t st, const Tower& T, fl
     int launch_no = 0;
     auto flip = [&]() { g.rev = rev_env ? (launch_no++ & 1) : 0; };
     flip();
-    const bool x3 = h->precision == SN_PREC_F16X3;
+    const bool x3 = mode == SN_PREC_F16X3;
     const size_t lo_slots = ref16_slots(g, cap) + ref_slack(g);         // hi tensor -> lo tensor (F16X3); cap = pairs the buffers hold
     HIP_TRY(h, launch_refin_f16(st, T.refin, T.rin.bias, src, img_src, pyr, sh, sw, H, W, 1.0f / dnorm, ups, g, c, x16, x3,
                                 lo_slots * 16, ncu));
@@ -1541,11 +1594,11 @@ int refine_level(sn_handle* h, Workspace& ws, hipStream_t st, const Tower& T, fl
     const bool tail = !x3 && last_streamed && h->tail_fuse && kRefDil[kNRefRes - 1] == 1 && ups.rs <= 0.5f;
     for (int i = 0; i < kNRefRes; ++i) {
       if (x3) {
-        HIP_TRY(h, ref_conv_f16x3(st, T.rres16[i][0], g, ncu, kRefDil[i], x16, t16, nullptr, lo_slots, c, true));
-        HIP_TRY(h, ref_conv_f16x3(st, T.rres16[i][1], g, ncu, kRefDil[i], t16, x16, x16, lo_slots, c, true));
+        HIP_TRY(h, ref_conv_f16x3(st, T.rres16x3[i][0], g, ncu, kRefDil[i], x16, t16, nullptr, lo_slots, c, true));
+        HIP_TRY(h, ref_conv_f16x3(st, T.rres16x3[i][1], g, ncu, kRefDil[i], t16, x16, x16, lo_slots, c, true));
       } else if (tail && i == kNRefRes - 1) {
         if (pe) HIP_TRY(h, hipEventRecord(h->ev[5], st));          // the plain tower launches end here
-        StreamHeadArgs ha{T.rout.w, src, od, orw, T.rout.bias, dnorm, inv_q, sh, sw, H, W, ups};
+        StreamHeadArgs ha{T.rout.w, src, od, orw, T.rout.bias, dnorm, inv_q, sh, sw, H, W, ups, stat};
         HIP_TRY(h, ref_block_stream_tail(st, T.rres16[i][0], T.rres16[i][1], g, ncu, x16, c, h->dump, ha));
       } else {
         const bool dom = pe && h->fuse_mode == 4 && stream_block_supports(kRefDil[i]) && h->dom_pairs < 6;
@@ -1558,11 +1611,17 @@ int refine_level(sn_handle* h, Workspace& ws, hipStream_t st, const Tower& T, fl
     if (!tail) {
       if (pe) HIP_TRY(h, hipEventRecord(h->ev[5], st));
       HIP_TRY(h, launch_head_final_f16(st, x3, x16, lo_slots, g, T.rout.w, T.rout.bias, src, sh, sw, H, W, dnorm, inv_q, ups,
-                                       od, orw, c));
+                                       od, orw, c, stat));
     }
   }
   HIP_TRY(h, hipGetLastError());
   return SN_OK;
+}
+
+// pairs per tower launch of level lv for a call in `mode` (an SN_PREC_AUTO handle in SN_PREC_F16X3 packs fewer pairs into the
+// same buffers)
+inline int chunk_pairs(const sn_handle* h, const Workspace& ws, int mode, int lv = 0) {
+  return (h->precision == SN_PREC_AUTO && mode == SN_PREC_F16X3) ? ws.rbk_x3[lv] : ws.rbk[lv];
 }
 
 // Next tile-queue block of this forward() (nullptr for the fp32 path, which has no queues); the pool is sized by
@@ -1582,7 +1641,7 @@ inline int take_ctr_block(sn_handle* h, Workspace& ws, int* ctr_block, unsigned*
 // pyramid of the left eye, then the towers of levels levels-1 .. 1, each starting from the x2 upsample of the map below
 // it (the soft-argmin map for the coarsest), values x2, normalised by D / 2^level.  Level k runs in chunks of
 // ws.rbk[k] pairs.  Leaves the level-1 maps of the piece in ws.lvl_disp[1].  *ctr_block: next free tile-queue block.
-int refine_coarse(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, const int8_t* in6, int* ctr_block) {
+int refine_coarse(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, const int8_t* in6, int* ctr_block, int mode) {
   const size_t HW = (size_t)h->H * h->W;
   const int8_t* in_piece = in6 + (size_t)p0 * 6 * HW;
   for (int lv = 1; lv < h->levels; ++lv) {       // level 1 from the int8 input, the others from the level above
@@ -1603,14 +1662,16 @@ int refine_coarse(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, co
     const Tower& T = h->tw[lv];
     const size_t HWk = (size_t)T.Hk * T.Wk;
     const float dnorm = (float)h->D / (float)(1 << lv);
-    for (int q = 0; q < m; q += ws.rbk[lv]) {
-      const int c = (m - q) < ws.rbk[lv] ? (m - q) : ws.rbk[lv];
+    const int rbk = chunk_pairs(h, ws, mode, lv);
+    for (int q = 0; q < m; q += rbk) {
+      const int c = (m - q) < rbk ? (m - q) : rbk;
       unsigned* ctr = nullptr;
       int rc = take_ctr_block(h, ws, ctr_block, &ctr);
       if (rc) return rc;
       rc = refine_level(h, ws, st, T, ws.ref_lv[lv][0], ws.ref_lv[lv][1], ws.ref16_lv[lv][0], ws.ref16_lv[lv][1],
                                   src + (size_t)q * sh * sw, sh, sw, UpScale{0.5f, 2.0f}, ws.pyr[lv] + (size_t)q * 3 * HWk, true,
-                                  T.Hk, T.Wk, dnorm, ws.lvl_disp[lv] + (size_t)q * HWk, nullptr, ctr, c, ws.rbk[lv], false);
+                                  T.Hk, T.Wk, dnorm, ws.lvl_disp[lv] + (size_t)q * HWk, nullptr, ctr, c, ws.rbk[lv], false, mode,
+                                  ws.stats + lv);
       if (rc) return rc;
     }
     src = ws.lvl_disp[lv];
@@ -1625,7 +1686,7 @@ int refine_coarse(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, co
 //   single-scale model: x16 upsample of the soft-argmin map;
 //   hierarchical model: x2 upsample of the piece's level-1 maps (refine_coarse ran before on the same stream).
 int refine_chunk(sn_handle* h, Workspace& ws, hipStream_t st, int sidx, int* ctr_block, int p0, int q0, int c,
-                 const int8_t* in6, float* out_disp, int32_t* out_raw, bool pe) {
+                 const int8_t* in6, float* out_disp, int32_t* out_raw, bool pe, int mode) {
   const int hl = h->hl, wl = h->wl;
   const size_t HW = (size_t)h->H * h->W;
   float* od = out_disp ? out_disp + (size_t)q0 * HW : nullptr;
@@ -1644,7 +1705,7 @@ int refine_chunk(sn_handle* h, Workspace& ws, hipStream_t st, int sidx, int* ctr
     ups = UpScale{0.5f, 2.0f};
   }
   return refine_level(h, ws, st, h->tw[0], ws.ref[2 * sidx], ws.ref[2 * sidx + 1], ws.ref16[2 * sidx], ws.ref16[2 * sidx + 1],
-                      src, sh, sw, ups, in_chunk, false, h->H, h->W, (float)h->D, od, orw, ctr, c, ws.rb, pe);
+                      src, sh, sw, ups, in_chunk, false, h->H, h->W, (float)h->D, od, orw, ctr, c, ws.rb, pe, mode, ws.stats);
 }
 
 // in6: device int8 [n][6][H][W]; out_disp / out_raw: device, nullable.
@@ -1658,27 +1719,36 @@ int refine_chunk(sn_handle* h, Workspace& ws, hipStream_t st, int sidx, int* ctr
 //              the CUs that chunk A's launch drains, and A's next launch (which depends only on A) is ready by the
 //              time B drains.  Two one-pair chunks in flight = four 61 MB tensors = the footprint of one two-pair
 //              chunk, still inside the 256 MB Infinity Cache.
+// mode: the arithmetic of this call (SN_PREC_F16 / F16X3 / FP32; 0 = the handle's current one).  Ends with the copy of the
+// refinement statistic to the workspace's pinned twin, in stream order.
 int forward(sn_handle* h, Workspace& ws, hipStream_t st, int n, const int8_t* in6, float* out_disp,
-            int32_t* out_raw, bool want_cost) {
+            int32_t* out_raw, bool want_cost, int mode = 0) {
+  if (mode == 0) mode = h->precision == SN_PREC_AUTO ? h->actl.st.mode : h->precision;
+  const int rb = chunk_pairs(h, ws, mode);
   const bool prof = h->profiling && (&ws == &h->ws);
-  const bool piped = !prof && (&ws == &h->ws) && h->overlap && n > ws.rb;
+  const bool piped = !prof && (&ws == &h->ws) && h->overlap && n > rb;
   int rc;
   int ctr_block = 0;          // tile-queue blocks are handed out in launch order (alloc_ws sized the pool)
   if (ws.tile_ctr) HIP_TRY(h, hipMemsetAsync(ws.tile_ctr, 0, kTileCtrBytes * ws.n_chunks, st));
+  HIP_TRY(h, hipMemsetAsync(ws.stats, 0, kMaxLevels * sizeof(unsigned long long), st));
+  auto finish = [&]() -> int {
+    HIP_TRY(h, hipMemcpyAsync(ws.stats_host, ws.stats, kStatWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    return SN_OK;
+  };
   if (!piped) {
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[0], st));
     for (int p0 = 0, m = 0; p0 < n; p0 += m) {
       m = (n - p0) < ws.pb ? (n - p0) : ws.pb;
       if ((rc = lowres(h, ws, st, p0, m, in6, want_cost, prof && p0 == 0))) return rc;
       if (prof && p0 == 0) HIP_TRY(h, hipEventRecord(h->ev[2], st));
-      if (h->levels > 1 && (rc = refine_coarse(h, ws, st, p0, m, in6, &ctr_block))) return rc;
-      for (int q0 = p0; q0 < p0 + m; q0 += ws.rb) {
-        const int c = (p0 + m - q0) < ws.rb ? (p0 + m - q0) : ws.rb;
-        if ((rc = refine_chunk(h, ws, st, 0, &ctr_block, p0, q0, c, in6, out_disp, out_raw, prof && q0 == 0))) return rc;
+      if (h->levels > 1 && (rc = refine_coarse(h, ws, st, p0, m, in6, &ctr_block, mode))) return rc;
+      for (int q0 = p0; q0 < p0 + m; q0 += rb) {
+        const int c = (p0 + m - q0) < rb ? (p0 + m - q0) : rb;
+        if ((rc = refine_chunk(h, ws, st, 0, &ctr_block, p0, q0, c, in6, out_disp, out_raw, prof && q0 == 0, mode))) return rc;
       }
     }
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[3], st));
-    return SN_OK;
+    return finish();
   }
   const int ns = ws.ns;
   HIP_TRY(h, hipEventRecord(h->ev_fork, st));
@@ -1695,16 +1765,16 @@ int forward(sn_handle* h, Workspace& ws, hipStream_t st, int n, const int8_t* in
     if (h->levels > 1) {                   // coarse levels of the whole piece first (one tower stream: alloc_ws)
       HIP_TRY(h, hipStreamWaitEvent(h->s_tow[0], e, 0));
       waited[0] = true;
-      if ((rc = refine_coarse(h, ws, h->s_tow[0], p0, m, in6, &ctr_block))) return rc;
+      if ((rc = refine_coarse(h, ws, h->s_tow[0], p0, m, in6, &ctr_block, mode))) return rc;
     }
-    for (int q0 = p0; q0 < p0 + m; q0 += ws.rb, ++chunk) {
-      const int c = (p0 + m - q0) < ws.rb ? (p0 + m - q0) : ws.rb;
+    for (int q0 = p0; q0 < p0 + m; q0 += rb, ++chunk) {
+      const int c = (p0 + m - q0) < rb ? (p0 + m - q0) : rb;
       const int s = chunk % ns;
       if (!waited[s]) {
         HIP_TRY(h, hipStreamWaitEvent(h->s_tow[s], e, 0));
         waited[s] = true;
       }
-      if ((rc = refine_chunk(h, ws, h->s_tow[s], s, &ctr_block, p0, q0, c, in6, out_disp, out_raw, false))) return rc;
+      if ((rc = refine_chunk(h, ws, h->s_tow[s], s, &ctr_block, p0, q0, c, in6, out_disp, out_raw, false, mode))) return rc;
     }
   }
   HIP_TRY(h, hipEventRecord(h->ev_join, h->s_low));
@@ -1713,7 +1783,7 @@ int forward(sn_handle* h, Workspace& ws, hipStream_t st, int n, const int8_t* in
     HIP_TRY(h, hipEventRecord(h->ev_tow_join[s], h->s_tow[s]));
     HIP_TRY(h, hipStreamWaitEvent(st, h->ev_tow_join[s], 0));
   }
-  return SN_OK;
+  return finish();
 }
 
 int collect_profile(sn_handle* h) {
@@ -1747,6 +1817,154 @@ int collect_profile(sn_handle* h) {
 int check_device(sn_handle* h) {
   HIP_TRY(h, hipSetDevice(h->device));
   return SN_OK;
+}
+
+// ---- refinement statistic and SN_PREC_AUTO (include/stereonet_hip.h) ---------------------------------------------------
+__global__ __launch_bounds__(256) void k_abs_diff_sum(const float* __restrict__ a, const float* __restrict__ b, size_t n,
+                                                      unsigned long long* __restrict__ out) {
+  float sum = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) sum += fabsf(a[i] - b[i]);
+  refine_stat_commit(out, sum);
+}
+
+// mean |D_k r_k| per level from a workspace's pinned statistic of an n-pair call (valid once the stream that ran forward()
+// has been synchronised): level 0 writes the H x W output maps, a coarse level its whole padded map
+void read_stats(const sn_handle* h, const Workspace& ws, int n, double* level_px, double* residual_px) {
+  double res = 0.0;
+  for (int lv = 0; lv < kMaxLevels; ++lv) {
+    level_px[lv] = 0.0;
+    if (lv >= h->levels || n <= 0) continue;
+    const double px = lv == 0 ? (double)h->H * h->W : (double)h->tw[lv].Hk * h->tw[lv].Wk;
+    level_px[lv] = (double)ws.stats_host[lv] / (double)kStatScale / (px * n);
+    res += level_px[lv] * (double)(1 << lv);
+  }
+  *residual_px = res;
+}
+
+// every call is counted when it is issued (the statistic of an enqueue-only call may be superseded by the next call's before
+// anybody looks at it; the count may not)
+void count_call(sn_handle* h, int n) {
+  std::lock_guard<std::mutex> lk(h->mu);
+  ++h->actl.calls;
+  h->actl.pairs += (uint64_t)n;
+}
+
+// Folds the statistic of one finished call (run in `mode`) into the handle; returns the arithmetic the handle is in
+// afterwards.  observe = false: a repeated call (its first run has been observed already).
+int fold_stats(sn_handle* h, const double* level_px, double residual_px, int n, int mode, bool observe = true) {
+  std::lock_guard<std::mutex> lk(h->mu);
+  AutoCtl& a = h->actl;
+  for (int lv = 0; lv < kMaxLevels; ++lv) a.last_level[lv] = level_px[lv];
+  a.last_res = residual_px;
+  a.last_mode = mode;
+  if (!observe) {
+    ++a.reruns;
+    return a.st.mode;
+  }
+  if (h->precision != SN_PREC_AUTO) {
+    a.st.running_px = a.st.running_px < 0.0 ? residual_px : 0.75 * a.st.running_px + 0.25 * residual_px;
+    return h->precision;
+  }
+  const int before = a.st.mode;
+  const int after = sn_auto_observe(&a.st, residual_px);
+  if (before == SN_PREC_F16X3 && after == SN_PREC_F16) a.calibrated = false;      // re-entering F16: check it again
+  return after;
+}
+
+// SN_PREC_AUTO's self-check: ONE pair in both arithmetics (the low-resolution branch is the same code, so the maps differ by
+// the towers' arithmetic alone), mean |F16 - F16X3| against the pair's residual -> the handle's measured EPE per pixel of
+// residual.  Runs on `st` with the workspace of the call that triggers it and returns after synchronising.
+int auto_selfcheck(sn_handle* h, Workspace& ws, hipStream_t st, const int8_t* in6_pair) {
+  std::lock_guard<std::mutex> cal(h->mu_cal);
+  {
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (h->actl.calibrated) return SN_OK;
+  }
+  const bool prof = h->profiling;
+  h->profiling = false;                  // the stage events belong to the caller's own forward()
+  int rc = forward(h, ws, st, 1, in6_pair, h->chk[1], nullptr, false, SN_PREC_F16X3);
+  if (!rc) rc = forward(h, ws, st, 1, in6_pair, h->chk[0], nullptr, false, SN_PREC_F16);    // last: the intermediates sn_dbg_read sees
+  h->profiling = prof;
+  if (rc) return rc;
+  const size_t HW = (size_t)h->H * h->W;
+  HIP_TRY(h, hipMemsetAsync(ws.stats + 4, 0, sizeof(unsigned long long), st));
+  hipLaunchKernelGGL(k_abs_diff_sum, dim3(512), dim3(256), 0, st, h->chk[0], h->chk[1], HW, ws.stats + 4);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipMemcpyAsync(ws.stats_host, ws.stats, kStatWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  HIP_TRY(h, hipStreamSynchronize(st));
+  double lvl[kMaxLevels], res = 0.0;
+  read_stats(h, ws, 1, lvl, &res);
+  const double epe = (double)ws.stats_host[4] / (double)kStatScale / (double)HW;
+  std::lock_guard<std::mutex> lk(h->mu);
+  AutoCtl& a = h->actl;
+  a.selfcheck_epe = epe;
+  a.selfcheck_res = res;
+  // (a model whose refinement adds nothing has nothing to lose in fp16: keep the envelope alone)
+  a.st.epe_per_px = res > 1e-6 ? epe / res : 0.0;
+  a.calibrated = true;
+  return SN_OK;
+}
+
+// A statistic of an earlier call that only enqueued its work (device buffers + caller stream): folded in once its copy has
+// landed (wait = false: only if it already has).
+int fold_pending(sn_handle* h, bool wait) {
+  AutoCtl& a = h->actl;
+  if (!a.pending) return SN_OK;
+  if (wait) {
+    HIP_TRY(h, hipEventSynchronize(h->ev_stats));
+  } else if (hipEventQuery(h->ev_stats) != hipSuccess) {
+    (void)hipGetLastError();               // hipErrorNotReady: try again at the next call
+    return SN_OK;
+  }
+  a.pending = false;
+  double lvl[kMaxLevels], res = 0.0;
+  read_stats(h, h->ws, a.pending_n, lvl, &res);
+  fold_stats(h, lvl, res, a.pending_n, a.pending_mode);
+  return SN_OK;
+}
+
+// forward() on the handle's own workspace for the synchronous entry points.  post() enqueues what follows the network
+// (device-to-host copies).  blocking: the entry point returns after completion — the statistic is folded in before it
+// does and, under SN_PREC_AUTO, a call that left the fp16 tower's envelope is REPEATED in SN_PREC_F16X3.  Not blocking
+// (work only enqueued on the caller's stream): the statistic is folded in by a later call; an AUTO handle that has not had
+// its self-check yet blocks once.
+template <class Post>
+int run_forward(sn_handle* h, hipStream_t st, int n, const int8_t* din, float* ddisp, int32_t* draw, bool want_cost,
+                bool blocking, Post post) {
+  const bool is_auto = h->precision == SN_PREC_AUTO;
+  AutoCtl& a = h->actl;
+  int rc = fold_pending(h, false);
+  if (rc) return rc;
+  int mode, calibrated;
+  {
+    std::lock_guard<std::mutex> lk(h->mu);
+    mode = is_auto ? a.st.mode : h->precision;
+    calibrated = a.calibrated;
+  }
+  const bool check = is_auto && mode == SN_PREC_F16 && !calibrated;
+  if ((rc = forward(h, h->ws, st, n, din, ddisp, draw, want_cost, mode))) return rc;
+  if ((rc = post())) return rc;
+  count_call(h, n);
+  if (!blocking && !check) {
+    HIP_TRY(h, hipEventRecord(h->ev_stats, st));
+    a.pending = true;
+    a.pending_n = n;
+    a.pending_mode = mode;
+    return SN_OK;
+  }
+  HIP_TRY(h, hipStreamSynchronize(st));
+  double lvl[kMaxLevels], res = 0.0;
+  read_stats(h, h->ws, n, lvl, &res);
+  if (check && (rc = auto_selfcheck(h, h->ws, st, din))) return rc;
+  const int next = fold_stats(h, lvl, res, n, mode);
+  if (is_auto && mode == SN_PREC_F16 && next == SN_PREC_F16X3) {
+    if ((rc = forward(h, h->ws, st, n, din, ddisp, draw, want_cost, SN_PREC_F16X3))) return rc;
+    if ((rc = post())) return rc;
+    HIP_TRY(h, hipStreamSynchronize(st));
+    read_stats(h, h->ws, n, lvl, &res);
+    fold_stats(h, lvl, res, n, SN_PREC_F16X3, false);
+  }
+  return collect_profile(h);
 }
 
 // host <-> split-slot layout (SlotIn): src/dst fp32 [nimg][32][H][W]
@@ -1845,8 +2063,16 @@ int sn_create_prio(const char* model_file, const sn_config* cfg, int stream_prio
   const int H = c.height > 0 ? c.height : (int)hd.height;
   const int D = c.dmax > 0 ? c.dmax : (int)hd.dmax;
   if (W <= 0 || H <= 0 || D < 16 || D % 16 || D > 256) return SN_ERR_ARG;   // NV12 entry points add w%4, h%2
-  if (c.precision == SN_PREC_DEFAULT) c.precision = SN_PREC_F16;
-  if (c.precision != SN_PREC_FP32 && c.precision != SN_PREC_F16 && c.precision != SN_PREC_F16X3) return SN_ERR_ARG;
+  if (c.precision == SN_PREC_DEFAULT) {
+    // SN_PRECISION=f16|f16x3|fp32|auto: what "default" means for this process (A/B runs of unmodified callers)
+    const char* e = getenv("SN_PRECISION");
+    c.precision = SN_PREC_AUTO;
+    if (e && !strcmp(e, "f16")) c.precision = SN_PREC_F16;
+    else if (e && !strcmp(e, "f16x3")) c.precision = SN_PREC_F16X3;
+    else if (e && !strcmp(e, "fp32")) c.precision = SN_PREC_FP32;
+  }
+  if (c.precision != SN_PREC_FP32 && c.precision != SN_PREC_F16 && c.precision != SN_PREC_F16X3 && c.precision != SN_PREC_AUTO)
+    return SN_ERR_ARG;
 
   int ndev = 0;
   g_create_err.clear();
@@ -1878,6 +2104,9 @@ int sn_create_prio(const char* model_file, const sn_config* cfg, int stream_prio
   h->refine_chunk = c.refine_chunk;                            // <= 0: chosen below from the tensor size
   h->piece = c.piece > 0 ? c.piece : 16;
   h->levels = levels;
+  sn_auto_init(&h->actl.st, levels);
+  if (c.precision != SN_PREC_AUTO) h->actl.st.mode = c.precision;
+  h->actl.last_mode = h->actl.st.mode;
   for (int k = 0; k < levels; ++k) {
     h->tw[k].Hk = h->Hp >> k;
     h->tw[k].Wk = h->Wp >> k;
@@ -1890,6 +2119,14 @@ int sn_create_prio(const char* model_file, const sn_config* cfg, int stream_prio
     h->tower_streams = e ? atoi(e) : (h->precision == SN_PREC_FP32 ? 2 : 1);
     if (h->tower_streams < 1) h->tower_streams = 1;
     if (h->tower_streams > kMaxTowerStreams) h->tower_streams = kMaxTowerStreams;
+  }
+  const bool want_f16 = c.precision == SN_PREC_F16 || c.precision == SN_PREC_AUTO;
+  const bool want_x3 = c.precision == SN_PREC_F16X3 || c.precision == SN_PREC_AUTO;
+  {
+    // the Infinity-Cache sizing of the per-layer forms, for the split tensors of SN_PREC_F16X3 (what an AUTO handle falls back to)
+    const double tensor_mb = 4.0 * h->tw[0].rg.Hs * h->tw[0].rg.Ws * 16.0 / 1048576.0 * 2.0;
+    const int r = (int)(256.0 / (2.0 * tensor_mb * h->tower_streams) + 0.5);
+    h->refine_chunk_x3 = r < 1 ? 1 : (r > 8 ? 8 : r);
   }
   if (h->refine_chunk <= 0) {
     // Pairs per tower launch: as many as keep the activations in flight — (x, t) per tower stream — inside the
@@ -1904,7 +2141,7 @@ int sn_create_prio(const char* model_file, const sn_config* cfg, int stream_prio
     // the Infinity Cache, and fuller launches amortise the restart rows and the launch itself: ~5.5 Mpx per launch
     // (1280x720: 6 pairs; round 3: 4 pairs 2583 -> 2653 pairs/s; round 5, three interleaved runs: 4 pairs 3064-3068,
     // 6 pairs 3074-3081, 8 pairs 3071-3078, profiles/r05_schedule_sweep.txt).
-    if (h->precision == SN_PREC_F16 && fuse_env() == 4 && stream_block_supports(8)) {
+    if (want_f16 && fuse_env() == 4 && stream_block_supports(8)) {
       const int by_px = (int)(5.5e6 / ((double)h->Hp * h->Wp) + 0.5);
       if (by_px > rc_auto) rc_auto = by_px;
     }
@@ -1912,6 +2149,7 @@ int sn_create_prio(const char* model_file, const sn_config* cfg, int stream_prio
   }
   h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (h->refine_chunk > h->max_batch) h->refine_chunk = h->max_batch;
+  if (h->refine_chunk_x3 > h->refine_chunk) h->refine_chunk_x3 = h->refine_chunk;
 
   // the kernels use 32-bit element / byte offsets inside one tensor: keep every tensor below 2^32
   {
@@ -1924,6 +2162,7 @@ int sn_create_prio(const char* model_file, const sn_config* cfg, int stream_prio
     double ref_bytes = 0;
     for (int lv = 0; lv < h->levels; ++lv) {
       const RefGeom& rg = h->tw[lv].rg;
+      // (SN_PREC_F16X3's lo tensor sits behind the hi tensor; its offset is folded into 64-bit base pointers)
       const double b = ((double)level_chunk_pairs(h->refine_chunk, pb, lv) * 4.0 * rg.Hs * rg.Ws + (double)ref_slack(rg) + (double)ref_front(rg)) * 16.0;
       if (b > ref_bytes) ref_bytes = b;
     }
@@ -1944,6 +2183,10 @@ int sn_create_prio(const char* model_file, const sn_config* cfg, int stream_prio
     if (hipEventCreate(&e) != hipSuccess) return fail(SN_ERR_DEVICE);
   for (auto& e : h->ev_dom)
     if (hipEventCreate(&e) != hipSuccess) return fail(SN_ERR_DEVICE);
+  if (hipEventCreateWithFlags(&h->ev_stats, hipEventDisableTiming) != hipSuccess) return fail(SN_ERR_DEVICE);
+  if (c.precision == SN_PREC_AUTO)
+    for (auto& p : h->chk)
+      if (dalloc(&p, (size_t)H * W) != hipSuccess) return fail(SN_ERR_NOMEM);
   // (Disjoint CU sets for the pipeline streams through hipExtStreamCreateWithCUMask were measured and dropped:
   // 1940 pairs/s shared vs 1700 / 1680 / 1510 with 64 / 96 / 128 CUs split off for the low-resolution branch.)
   // High-priority pipeline streams (stream_prio = 1: sn_mgpu_create for its own exchange streams when more than one
@@ -2036,19 +2279,16 @@ int sn_create_prio(const char* model_file, const sn_config* cfg, int stream_prio
     for (int i = 0; i < kNRefRes; ++i)
       for (int j = 0; j < 2; ++j) {
         const HostLayer hl_ = bw.next(kC, kC, 9);
-        if (h->precision == SN_PREC_FP32) {
-          if ((rc = upload_conv2d(h, hl_, 8, &T.rres[i][j]))) return fail(rc);
-        } else if (h->precision == SN_PREC_F16X3) {
-          if ((rc = upload_ref_f16x3(h, hl_, &T.rres16[i][j]))) return fail(rc);
-        } else {
-          if ((rc = upload_ref_f16(h, hl_, &T.rres16[i][j]))) return fail(rc);
-        }
+        if (h->precision == SN_PREC_FP32 && (rc = upload_conv2d(h, hl_, 8, &T.rres[i][j]))) return fail(rc);
+        if (want_x3 && (rc = upload_ref_f16x3(h, hl_, &T.rres16x3[i][j]))) return fail(rc);
+        if (want_f16 && (rc = upload_ref_f16(h, hl_, &T.rres16[i][j]))) return fail(rc);
       }
     if ((rc = upload_head(h, bw.next(1, kC, 9), &T.rout))) return fail(rc);
   }
   if (bw.off != blob.size()) return fail(SN_ERR_FORMAT);
 
-  if ((rc = alloc_ws(h, &h->ws, h->max_batch, h->refine_chunk, h->tower_streams))) return fail(rc == SN_ERR_DEVICE ? SN_ERR_NOMEM : rc);
+  if ((rc = alloc_ws(h, &h->ws, h->max_batch, h->refine_chunk, h->tower_streams, h->refine_chunk_x3)))
+    return fail(rc == SN_ERR_DEVICE ? SN_ERR_NOMEM : rc);
   *out = h;
   return SN_OK;
 }
@@ -2080,10 +2320,18 @@ int sn_destroy(sn_handle* h) {
         hipFree(l.wfrag);
         hipFree(l.bias);
       }
+    for (auto& b : T.rres16x3)
+      for (auto& l : b) {
+        hipFree(l.wfrag);
+        hipFree(l.bias);
+      }
     hipFree(T.rout.w);
   }
   hipFree(h->dump);
   hipFree(h->aout.w);
+  hipFree(h->aout.pfrag);
+  for (auto p : h->chk) hipFree(p);
+  if (h->ev_stats) hipEventDestroy(h->ev_stats);
   free_ws(&h->ws);
   for (auto& s : h->slots) {
     free_ws(&s.ws);
@@ -2091,8 +2339,9 @@ int sn_destroy(sn_handle* h) {
     if (s.pin_raw) hipHostFree(s.pin_raw);
     if (s.pin_disp) hipHostFree(s.pin_disp);
     for (auto& gk : s.gexec)
-      for (auto& g : gk)
-        if (g) hipGraphExecDestroy(g);
+      for (auto& gm : gk)
+        for (auto& g : gm)
+          if (g) hipGraphExecDestroy(g);
     if (s.ev0) hipEventDestroy(s.ev0);
     if (s.ev1) hipEventDestroy(s.ev1);
     if (s.stream) hipStreamDestroy(s.stream);
@@ -2138,13 +2387,92 @@ int sn_get_io_info(const sn_handle* h, sn_io_info* info) {
     mac += (wp * hp / (double)(1 << (2 * k))) * (4.0 * kC * 9 + 2.0 * kNRefRes * kC * kC * 9 + kC * 9);
   info->flops_per_pair = 2.0 * mac;
   info->refine_levels = h->levels;
-  info->refine_chunk = h->ws.rb;
+  info->precision_selected = h->precision == SN_PREC_AUTO ? h->actl.st.mode : h->precision;
+  info->refine_chunk = chunk_pairs(h, h->ws, info->precision_selected);
   info->piece = h->ws.pb;
   info->tower_streams = h->ws.ns;
   return SN_OK;
 }
 
 int sn_abi_version(void) { return SN_ABI_VERSION; }
+
+// ---- SN_PREC_AUTO's state machine: pure functions, no device (tests/test_auto_precision.py) -------------------------------
+// Envelope of the fp16 tower per shape class, in full-resolution pixels of residual_px = sum_k 2^k mean |D_k r_k|: the
+// largest value below which EVERY weight draw of the sensitivity tables kept EPE < 1e-3 px against the oracle
+// = SN_AUTO_BUDGET_PX over the worst error per pixel of residual of the table (profiles/r06_auto_envelope_*.txt: 8 seeds x
+// head gain {1, 2, 4, 8}; single-scale 1280x720: 1.8e-4 .. 8.3e-4 px per px; hierarchical 1242x375: 1.1e-4 .. 2.9e-4 px per
+// px of the 2^k-weighted sum — a coarse level's error is upsampled with its map).  The self-check replaces this prior by the
+// model's own slope (sn_auto_limit_px).
+double sn_auto_envelope_px(int refine_levels) { return refine_levels > 1 ? kAutoEnvelopeMulti : kAutoEnvelopeSingle; }
+
+int sn_auto_init(sn_auto_state* s, int refine_levels) {
+  if (!s) return SN_ERR_ARG;
+  s->mode = SN_PREC_F16;
+  s->calm = 0;
+  s->envelope_px = sn_auto_envelope_px(refine_levels);
+  s->epe_per_px = 0.0;
+  s->running_px = -1.0;
+  s->switches = 0;
+  return SN_OK;
+}
+
+double sn_auto_limit_px(const sn_auto_state* s) {
+  if (!s) return 0.0;
+  if (!(s->epe_per_px > 0.0)) return s->envelope_px;        // nothing measured on this model yet: the class envelope
+  const double cap = SN_AUTO_ENVELOPE_CAP * s->envelope_px, own = SN_AUTO_BUDGET_PX / s->epe_per_px;
+  return own < cap ? own : cap;
+}
+
+int sn_auto_observe(sn_auto_state* s, double residual_px) {
+  if (!s) return SN_ERR_ARG;
+  if (!(residual_px >= 0.0)) residual_px = 1e30;       // NaN / negative: nothing the fp16 tower should be trusted with
+  s->running_px = s->running_px < 0.0 ? residual_px : 0.75 * s->running_px + 0.25 * residual_px;
+  const double lim = sn_auto_limit_px(s);
+  if (s->mode == SN_PREC_F16) {
+    if (residual_px > lim) {
+      s->mode = SN_PREC_F16X3;
+      s->calm = 0;
+      ++s->switches;
+    }
+  } else {
+    if (residual_px < SN_AUTO_REENTRY * lim) {
+      if (++s->calm >= SN_AUTO_CALM_CALLS) {
+        s->mode = SN_PREC_F16;
+        s->calm = 0;
+        ++s->switches;
+      }
+    } else {
+      s->calm = 0;
+    }
+  }
+  return s->mode;
+}
+
+int sn_get_refine_stats(sn_handle* h, sn_refine_stats* out) {
+  if (!h || !out) return SN_ERR_ARG;
+  int rc = check_device(h);
+  if (rc) return rc;
+  if ((rc = fold_pending(h, true))) return rc;
+  std::lock_guard<std::mutex> lk(h->mu);
+  const AutoCtl& a = h->actl;
+  memset(out, 0, sizeof *out);
+  out->levels = h->levels;
+  out->precision = h->precision;
+  out->precision_selected = h->precision == SN_PREC_AUTO ? a.st.mode : h->precision;
+  out->precision_last = a.last_mode;
+  out->calls = a.calls;
+  out->pairs = a.pairs;
+  out->switches = a.st.switches;
+  out->reruns = a.reruns;
+  for (int lv = 0; lv < kMaxLevels; ++lv) out->level_px[lv] = a.last_level[lv];
+  out->residual_px = a.last_res;
+  out->running_px = a.st.running_px < 0.0 ? 0.0 : a.st.running_px;
+  out->envelope_px = a.st.envelope_px;
+  out->limit_px = sn_auto_limit_px(&a.st);
+  out->selfcheck_epe_px = a.selfcheck_epe;
+  out->selfcheck_residual_px = a.selfcheck_res;
+  return SN_OK;
+}
 
 int sn_infer_batch(sn_handle* h, int n, const int8_t* in, int32_t* out_i32, float* out_disp, int mem,
                    void* stream) {
@@ -2166,16 +2494,14 @@ int sn_infer_batch(sn_handle* h, int n, const int8_t* in, int32_t* out_i32, floa
     draw = out_i32 ? h->ws.out_raw : nullptr;
     ddisp = out_disp ? h->ws.out_disp : nullptr;
   }
-  if ((rc = forward(h, h->ws, st, n, din, ddisp, draw, n == 1))) return rc;
-  if (mem == SN_MEM_HOST) {
-    if (out_i32) HIP_TRY(h, hipMemcpyAsync(out_i32, draw, (size_t)n * HW * 4, hipMemcpyDeviceToHost, st));
-    if (out_disp) HIP_TRY(h, hipMemcpyAsync(out_disp, ddisp, (size_t)n * HW * 4, hipMemcpyDeviceToHost, st));
-  }
-  if (mem == SN_MEM_HOST || !stream) {
-    HIP_TRY(h, hipStreamSynchronize(st));
-    if ((rc = collect_profile(h))) return rc;
-  }
-  return SN_OK;
+  auto post = [&]() -> int {
+    if (mem == SN_MEM_HOST) {
+      if (out_i32) HIP_TRY(h, hipMemcpyAsync(out_i32, draw, (size_t)n * HW * 4, hipMemcpyDeviceToHost, st));
+      if (out_disp) HIP_TRY(h, hipMemcpyAsync(out_disp, ddisp, (size_t)n * HW * 4, hipMemcpyDeviceToHost, st));
+    }
+    return SN_OK;
+  };
+  return run_forward(h, st, n, din, ddisp, draw, n == 1, mem == SN_MEM_HOST || !stream, post);
 }
 
 int sn_infer_i8(sn_handle* h, const int8_t* in, int32_t* out_i32, float* out_disp, int mem, void* stream) {
@@ -2249,17 +2575,15 @@ int sn_infer_sbs_nv12(sn_handle* h, const uint8_t* sbs, int w2, int h_px, int32_
     draw = out_i32 ? h->ws.out_raw : nullptr;
     ddisp = out_disp ? h->ws.out_disp : nullptr;
   }
-  if ((rc = forward(h, h->ws, st, 1, din, ddisp, draw, true))) return rc;
-  if (mem == SN_MEM_HOST) {
-    if (out_i32) HIP_TRY(h, hipMemcpyAsync(out_i32, draw, HW * 4, hipMemcpyDeviceToHost, st));
-    if (out_disp) HIP_TRY(h, hipMemcpyAsync(out_disp, ddisp, HW * 4, hipMemcpyDeviceToHost, st));
-    if (out_tensor) HIP_TRY(h, hipMemcpyAsync(out_tensor, din, HW * 6, hipMemcpyDeviceToHost, st));
-  }
-  if (mem == SN_MEM_HOST || !stream) {
-    HIP_TRY(h, hipStreamSynchronize(st));
-    if ((rc = collect_profile(h))) return rc;
-  }
-  return SN_OK;
+  auto post = [&]() -> int {
+    if (mem == SN_MEM_HOST) {
+      if (out_i32) HIP_TRY(h, hipMemcpyAsync(out_i32, draw, HW * 4, hipMemcpyDeviceToHost, st));
+      if (out_disp) HIP_TRY(h, hipMemcpyAsync(out_disp, ddisp, HW * 4, hipMemcpyDeviceToHost, st));
+      if (out_tensor) HIP_TRY(h, hipMemcpyAsync(out_tensor, din, HW * 6, hipMemcpyDeviceToHost, st));
+    }
+    return SN_OK;
+  };
+  return run_forward(h, st, 1, din, ddisp, draw, true, mem == SN_MEM_HOST || !stream, post);
 }
 
 // FeedImg's split + CvtNV12Data2Tensors for a batch of side-by-side frames (device or host buffers): n frames of
@@ -2306,7 +2630,7 @@ static int ensure_slots(sn_handle* h) {
     HIP_TRY(h, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
     HIP_TRY(h, hipEventCreate(&s.ev0));
     HIP_TRY(h, hipEventCreate(&s.ev1));
-    int rc = alloc_ws(h, &s.ws, 1, 1, 1);
+    int rc = alloc_ws(h, &s.ws, 1, 1, 1, 1);
     if (rc) return rc;
     HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&s.pin_in), 6 * HW, hipHostMallocDefault));
     HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&s.pin_raw), 4 * HW, hipHostMallocDefault));
@@ -2356,6 +2680,11 @@ static int submit_common(sn_handle* h, const void* in, int kind, int32_t* out_i3
   } guard{h, s};
   memcpy(s->pin_in, in, (kind == 1 ? 3 : 6) * HW);   // the caller may release its buffer as soon as we return
   const int mask = (out_i32 ? 1 : 0) | (out_disp ? 2 : 0);
+  // arithmetic of this request: an SN_PREC_AUTO handle's current one (sn_wait folds the request's statistic in and repeats
+  // a request that left the fp16 tower's envelope)
+  const int mode = h->precision == SN_PREC_AUTO ? h->actl.st.mode : h->precision;
+  const int mi = mode == SN_PREC_F16X3 ? 0 : 1;
+  s->mode_run = mode;
   auto enqueue = [&]() -> int {
     if (kind == 1) {
       HIP_TRY(h, hipMemcpyAsync(s->ws.nv12, s->pin_in, 3 * HW, hipMemcpyHostToDevice, s->stream));
@@ -2370,36 +2699,36 @@ static int submit_common(sn_handle* h, const void* in, int kind, int32_t* out_i3
     const bool prof = h->profiling;
     h->profiling = false;   // stage events belong to the synchronous path
     const int r = forward(h, s->ws, s->stream, 1, s->ws.in6, out_disp ? s->ws.out_disp : nullptr,
-                          out_i32 ? s->ws.out_raw : nullptr, false);
+                          out_i32 ? s->ws.out_raw : nullptr, false, mode);
     h->profiling = prof;
     if (r) return r;
     if (out_i32) HIP_TRY(h, hipMemcpyAsync(s->pin_raw, s->ws.out_raw, 4 * HW, hipMemcpyDeviceToHost, s->stream));
     if (out_disp) HIP_TRY(h, hipMemcpyAsync(s->pin_disp, s->ws.out_disp, 4 * HW, hipMemcpyDeviceToHost, s->stream));
     return SN_OK;
   };
-  if (h->use_graphs && !s->gexec[kind][mask] && s->uses[kind][mask] >= 1) {
+  if (h->use_graphs && !s->gexec[kind][mask][mi] && s->uses[kind][mask][mi] >= 1) {
     // capture on the second use (the first, un-captured run has done every one-time initialisation)
     hipGraph_t graph = nullptr;
     if (hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
       const int r = enqueue();
       const hipError_t e = hipStreamEndCapture(s->stream, &graph);
       if (r == SN_OK && e == hipSuccess && graph &&
-          hipGraphInstantiate(&s->gexec[kind][mask], graph, nullptr, nullptr, 0) != hipSuccess)
-        s->gexec[kind][mask] = nullptr;
+          hipGraphInstantiate(&s->gexec[kind][mask][mi], graph, nullptr, nullptr, 0) != hipSuccess)
+        s->gexec[kind][mask][mi] = nullptr;
       if (graph) hipGraphDestroy(graph);
     }
-    if (!s->gexec[kind][mask]) {
+    if (!s->gexec[kind][mask][mi]) {
       (void)hipGetLastError();
       h->use_graphs = false;          // capture unsupported here: keep issuing plain launches (same kernels)
     }
   }
   HIP_TRY(h, hipEventRecord(s->ev0, s->stream));
-  if (s->gexec[kind][mask]) {
-    HIP_TRY(h, hipGraphLaunch(s->gexec[kind][mask], s->stream));
+  if (s->gexec[kind][mask][mi]) {
+    HIP_TRY(h, hipGraphLaunch(s->gexec[kind][mask][mi], s->stream));
   } else {
     rc = enqueue();
     if (rc) return rc;
-    ++s->uses[kind][mask];
+    ++s->uses[kind][mask][mi];
   }
   HIP_TRY(h, hipEventRecord(s->ev1, s->stream));
   guard.armed = false;
@@ -2435,6 +2764,28 @@ int sn_wait(sn_handle* h, uint64_t ticket, float* infer_ms) {
   hipSetDevice(h->device);
   HIP_TRY(h, hipEventSynchronize(s->ev1));
   const size_t HW = (size_t)h->H * h->W;
+  {
+    // the request's refinement statistic; SN_PREC_AUTO: self-check on the first request, and a request that left the fp16
+    // tower's envelope is repeated in SN_PREC_F16X3 on its own stream before its maps are handed over
+    double lvl[kMaxLevels], res = 0.0;
+    read_stats(h, s->ws, 1, lvl, &res);
+    const bool is_auto = h->precision == SN_PREC_AUTO;
+    int rc = SN_OK;
+    if (is_auto && s->mode_run == SN_PREC_F16 && (rc = auto_selfcheck(h, s->ws, s->stream, s->ws.in6))) return rc;
+    count_call(h, 1);
+    const int next = fold_stats(h, lvl, res, 1, s->mode_run);
+    if (is_auto && s->mode_run == SN_PREC_F16 && next == SN_PREC_F16X3) {
+      if ((rc = forward(h, s->ws, s->stream, 1, s->ws.in6, s->user_disp ? s->ws.out_disp : nullptr,
+                        s->user_raw ? s->ws.out_raw : nullptr, false, SN_PREC_F16X3)))
+        return rc;
+      if (s->user_raw) HIP_TRY(h, hipMemcpyAsync(s->pin_raw, s->ws.out_raw, 4 * HW, hipMemcpyDeviceToHost, s->stream));
+      if (s->user_disp) HIP_TRY(h, hipMemcpyAsync(s->pin_disp, s->ws.out_disp, 4 * HW, hipMemcpyDeviceToHost, s->stream));
+      HIP_TRY(h, hipEventRecord(s->ev1, s->stream));
+      HIP_TRY(h, hipEventSynchronize(s->ev1));
+      read_stats(h, s->ws, 1, lvl, &res);
+      fold_stats(h, lvl, res, 1, SN_PREC_F16X3, false);
+    }
+  }
   if (s->user_raw) memcpy(s->user_raw, s->pin_raw, 4 * HW);
   if (s->user_disp) memcpy(s->user_disp, s->pin_disp, 4 * HW);
   if (infer_ms) {
@@ -2474,8 +2825,9 @@ int sn_get_stage_ms(sn_handle* h, float* ms, int count) {
 
 int sn_get_dominant_kernel(sn_handle* h, char* name, size_t cap, int* launches, double* flops, double* bytes) {
   if (!h) return SN_ERR_ARG;
-  const bool f16 = h->precision == SN_PREC_F16;
-  const double px = (double)h->Hp * h->Wp * h->ws.rb;
+  const int cur = h->precision == SN_PREC_AUTO ? h->actl.st.mode : h->precision;
+  const bool f16 = cur == SN_PREC_F16;
+  const double px = (double)h->Hp * h->Wp * chunk_pairs(h, h->ws, cur);
   if (f16 && h->fuse_mode == 4) {
     // the row-streaming fused residual block: SN_STAGE_DOMINANT times its launches of the first chunk one by one
     int n = 0;
@@ -2494,8 +2846,8 @@ int sn_get_dominant_kernel(sn_handle* h, char* name, size_t cap, int* launches, 
   }
   if (name && cap)
     snprintf(name, cap, "%s",
-             h->precision == SN_PREC_F16     ? "k_ref_conv_f16<DIL> (refinement 3x3 C->C, fp16 MFMA 32x32x16)"
-             : h->precision == SN_PREC_F16X3 ? "k_ref_conv_f16x3<DIL> (refinement 3x3 C->C, 3x fp16 MFMA on hi/lo split operands)"
+             cur == SN_PREC_F16     ? "k_ref_conv_f16<DIL> (refinement 3x3 C->C, fp16 MFMA 32x32x16)"
+             : cur == SN_PREC_F16X3 ? "k_ref_conv_f16x3<DIL> (refinement 3x3 C->C, 3x fp16 MFMA on hi/lo split operands)"
                                              : "k_ref_conv_f32<DIL> (refinement 3x3 C->C, weights-stationary, fp32 MFMA 32x32x2)");
   const int n_plain = kNRefRes, n_res = kNRefRes;      // per-layer forms: six launches without, six with a residual
   if (launches) *launches = n_plain + n_res;   // per refinement chunk
@@ -3072,8 +3424,8 @@ int sn_dbg_ref_tail_f16(sn_handle* h, int n, const float* in, int hk, int wk, co
   if (n <= 0 || hk <= 0 || wk <= 0 || h_out <= 0 || w_out <= 0 || h_out > hk || w_out > wk || (ups != 16 && ups != 2) ||
       hk % ups || wk % ups || (form != 0 && form != 1) || !(dnorm > 0.f))
     return SN_ERR_ARG;
-  if (h->precision != SN_PREC_F16) {
-    set_err(h, "sn_dbg_ref_tail_f16 needs an engine created with SN_PREC_F16");
+  if (h->precision != SN_PREC_F16 && h->precision != SN_PREC_AUTO) {
+    set_err(h, "sn_dbg_ref_tail_f16 needs an engine created with SN_PREC_F16 or SN_PREC_AUTO");
     return SN_ERR_ARG;
   }
   int rc = check_device(h);
@@ -3091,12 +3443,16 @@ int sn_dbg_ref_tail_f16(sn_handle* h, int n, const float* in, int hk, int wk, co
       }
   RefLayerF16 L1, L2;
   HeadLayer hd;
-  if ((rc = upload_ref_f16(h, HostLayer{w1, b1, kC, kC, 9}, &L1))) return rc;
+  // (tracked before the status is looked at: an upload that fails half-way has allocated its first buffer)
+  rc = upload_ref_f16(h, HostLayer{w1, b1, kC, kC, 9}, &L1);
   ds.track(L1.bias); ds.track(L1.wfrag);
-  if ((rc = upload_ref_f16(h, HostLayer{w2, b2, kC, kC, 9}, &L2))) return rc;
+  if (rc) return rc;
+  rc = upload_ref_f16(h, HostLayer{w2, b2, kC, kC, 9}, &L2);
   ds.track(L2.bias); ds.track(L2.wfrag);
-  if ((rc = upload_head(h, HostLayer{head_w, &head_b, 1, kC, 9}, &hd))) return rc;
+  if (rc) return rc;
+  rc = upload_head(h, HostLayer{head_w, &head_b, 1, kC, 9}, &hd);
   ds.track(hd.w);
+  if (rc) return rc;
   uint4 *da = nullptr, *db = nullptr, *da_raw = nullptr, *db_raw = nullptr;
   HIP_TRY(h, alloc_ref16(g, slots + ref_slack(g), &da_raw, &da));
   ds.track(da_raw);

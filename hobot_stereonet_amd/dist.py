@@ -7,6 +7,9 @@ as independent: one frame = one Run() (stereonet_infer/src/stereonet_node.cpp:14
 """
 from __future__ import annotations
 
+import os
+import threading
+import time
 from typing import Callable, List, Optional, Tuple
 
 import torch
@@ -56,8 +59,10 @@ class AsyncGather:
     That form exists so that the whole multi-rank path — real engine, real maps — can run where RCCL cannot, e.g. two
     ranks on ONE GPU in the tests; it is not a throughput path."""
 
-    def __init__(self, local: torch.Tensor, dst: int = 0, bufs: Optional[List[torch.Tensor]] = None):
-        """bufs: rank `dst`'s receive list (world tensors shaped like `local`), allocated ONCE by a caller that gathers
+    def __init__(self, local: torch.Tensor, dst: int = 0, bufs: Optional[List[torch.Tensor]] = None, group=None):
+        """group: the process group of the exchange (None = the default group; bench.py keeps a gloo default group as its
+        control plane and passes the RCCL group chosen by choose_gather).
+        bufs: rank `dst`'s receive list (world tensors shaped like `local`), allocated ONCE by a caller that gathers
         every step (alloc_root_buffers) — world x 236 MB at the metric's shard size is not something to allocate per
         step; None allocates a fresh list (one-shot callers).
 
@@ -68,9 +73,9 @@ class AsyncGather:
         Staged mode (gloo with device tensors) gathers HOST copies: device-resident `bufs` cannot receive them, so passing
         them raises instead of being dropped silently; host-resident `bufs` (pinned or not) are used as the receive list
         and wait() returns fresh device copies of them."""
-        world, rank = dist.get_world_size(), dist.get_rank()
+        world, rank = dist.get_world_size(group), dist.get_rank()
         self.device = local.device
-        self.staged = local.is_cuda and dist.get_backend() == "gloo"
+        self.staged = local.is_cuda and dist.get_backend(group) == "gloo"
         send = local.contiguous()
         if self.staged:
             send = send.cpu()                 # waits for the producing stream
@@ -83,17 +88,17 @@ class AsyncGather:
             self.bufs = bufs
         else:
             self.bufs = [torch.empty_like(send) for _ in range(world)]
-        self.work = dist.gather(send, self.bufs, dst=dst, async_op=True)
+        self.work = dist.gather(send, self.bufs, dst=dst, async_op=True, group=group)
 
     @staticmethod
-    def alloc_root_buffers(local: torch.Tensor, dst: int = 0) -> Optional[List[torch.Tensor]]:
+    def alloc_root_buffers(local: torch.Tensor, dst: int = 0, group=None) -> Optional[List[torch.Tensor]]:
         """The receive list of one gather on rank `dst` (None on the other ranks): on the shard's device, or in host
         memory when the gather will be staged (gloo with device tensors)."""
         if dist.get_rank() != dst:
             return None
-        staged = local.is_cuda and dist.get_backend() == "gloo"
+        staged = local.is_cuda and dist.get_backend(group) == "gloo"
         dev = torch.device("cpu") if staged else local.device
-        return [torch.empty(local.shape, dtype=local.dtype, device=dev) for _ in range(dist.get_world_size())]
+        return [torch.empty(local.shape, dtype=local.dtype, device=dev) for _ in range(dist.get_world_size(group))]
 
     def wait(self):
         if self.work is not None:
@@ -139,6 +144,9 @@ class PeerPullGather:
     so a rank's host runs at most one step ahead of its device and the pulls of step k-1 overlap the compute of step k."""
 
     def __init__(self, shape, dtype, device, dst: int = 0, sets: int = 2):
+        if sets < 2:
+            # with one set the root's begin(k) would release step k-1 before it has taken "ready k-1" or enqueued that pull
+            raise ValueError("PeerPullGather needs at least two buffer sets")
         self.world, self.rank, self.dst = dist.get_world_size(), dist.get_rank(), dst
         self.device = torch.device(device)
         self.cuda = self.device.type == "cuda"
@@ -146,20 +154,47 @@ class PeerPullGather:
         self.shape, self.dtype = tuple(int(d) for d in shape), dtype
         self.ctl = dist.new_group(backend="gloo")            # control plane: eight bytes per step and peer
         self._paths: List[str] = []
-        self.local = [self._alloc(s) for s in range(sets)]
-        handles = [self._export(s) for s in range(sets)]
-        table = [None] * self.world if self.rank == dst else None
-        dist.gather_object(handles, table, dst=dst, group=self.ctl)
         self.is_root = self.rank == dst
+        self.local = [self._alloc(s) for s in range(sets)]
+        # Only the PEERS export: an exported allocation is reference counted by torch's CUDA-IPC plumbing and every export
+        # expects one consumer; the root's own buffers are read first-hand, and a handle of them that nobody opens kept
+        # the root's allocation in torch's limbo until the "Producer process has been terminated before all shared CUDA
+        # tensors released" warning at exit (gpurun_out/ipc3.log, round 5).
+        # A rank that cannot export / open reports it instead of raising on its own: the constructor is collective, and a
+        # lone exception would leave the other ranks in the barrier below (choose_gather falls back on the error).
+        handles, err = None, ""
+        if not self.is_root:
+            try:
+                if _fault("ipc_error", self.rank):
+                    raise RuntimeError("injected failure (SN_BENCH_FAULT=ipc_error)")
+                handles = [self._export(s) for s in range(sets)]
+            except Exception as e:                           # noqa: BLE001 (reported to every rank below)
+                err = f"rank {self.rank} could not export its buffers: {e!r}"
+        table = [None] * self.world if self.is_root else None
+        dist.gather_object((handles, err), table, dst=dst, group=self.ctl)
         self.peer_views = None
         self.recv = None
         self.copy_stream = None
+        verdict = [""]
         if self.is_root:
-            self.peer_views = [[self._open(h) for h in hs] if r != dst else None for r, hs in enumerate(table)]
-            self.recv = [[torch.empty(self.shape, dtype=dtype, device=self.device) if r != dst else None
-                          for r in range(self.world)] for _ in range(sets)]
-            if self.cuda:
-                self.copy_stream = torch.cuda.Stream(device=self.device)
+            try:
+                bad = [e for r, (_, e) in enumerate(table) if r != dst and e]
+                if bad:
+                    raise RuntimeError("; ".join(bad))
+                if _fault("ipc_error", self.rank):
+                    raise RuntimeError("injected failure (SN_BENCH_FAULT=ipc_error)")
+                self.peer_views = [[self._open(h) for h in hs] if r != dst else None for r, (hs, _) in enumerate(table)]
+                self.recv = [[torch.empty(self.shape, dtype=dtype, device=self.device) if r != dst else None
+                              for r in range(self.world)] for _ in range(sets)]
+                if self.cuda:
+                    self.copy_stream = torch.cuda.Stream(device=self.device)
+            except Exception as e:                           # noqa: BLE001
+                verdict[0] = f"{e!r}"
+                self.peer_views = None
+        dist.broadcast_object_list(verdict, src=dst, group=self.ctl)
+        if verdict[0]:
+            self._teardown()
+            raise RuntimeError(f"peer-pull gather cannot be set up: {verdict[0]}")
         self.pull_ev = [torch.cuda.Event() if self.cuda else None for _ in range(sets)]
         self.step_ev = [torch.cuda.Event() if self.cuda else None for _ in range(sets)]
         self.k = 0                   # steps begun
@@ -301,8 +336,10 @@ class PeerPullGather:
         return [self.local[s] if r == self.dst else self.recv[s][r] for r in range(self.world)]
 
     def close(self) -> None:
+        """Teardown in the order the exported allocations need: (1) the root drops every view of the peers' buffers and
+        has torch release the opened IPC mappings, (2) barrier, (3) only then the producers let go of the exported
+        buffers, (4) barrier, control group destroyed."""
         import gc
-        import os
         self.peer_views = None
         self.recv = None
         gc.collect()                          # the IPC mappings go with the last reference to the opened tensors
@@ -310,9 +347,146 @@ class PeerPullGather:
             torch.cuda.synchronize(self.device)
             torch.cuda.ipc_collect()          # torch caches opened IPC allocations: release them before the producers exit
         dist.barrier(group=self.ctl)          # nobody unlinks / frees while a peer may still map it
+        self._teardown()
+
+    def _teardown(self) -> None:
+        import gc
+        self.local = None                     # the caller's own references (bench.py: raws) go first
+        gc.collect()
+        if self.cuda:
+            torch.cuda.synchronize(self.device)
+            torch.cuda.ipc_collect()          # producer side: blocks whose consumers are gone leave torch's limbo
         for p in self._paths:
             try:
                 os.unlink(p)
             except OSError:
                 pass
         self._paths = []
+        if self.ctl is not None:
+            dist.barrier(group=self.ctl)
+            dist.destroy_process_group(self.ctl)
+            self.ctl = None
+
+
+def _fault(name: str, rank: int) -> bool:
+    """SN_BENCH_FAULT=name[@rank][,name...]: fault injection for the gather set-up (tests, and a rehearsal of the first
+    real multi-GPU run): rccl_hang, rccl_error, ipc_error."""
+    for item in os.environ.get("SN_BENCH_FAULT", "").split(","):
+        item = item.strip()
+        if not item:
+            continue
+        n, _, r = item.partition("@")
+        if n == name and (not r or int(r) == rank):
+            return True
+    return False
+
+
+class GatherPlan:
+    """How the maps reach rank `dst` in this job, and how that was decided.
+        mode      "rccl" (AsyncGather on `group`, an RCCL process group), "ipc" (`pull`, a PeerPullGather) or "gloo"
+                  (AsyncGather on the default gloo group, staged through host memory)
+        attempts  one record per mode tried: {"mode", "ok", "seconds", "detail"}; the first ok one is in force
+        hung      a probe thread is still stuck in a collective: the process must leave through os._exit"""
+
+    def __init__(self, requested):
+        self.requested, self.mode, self.group, self.pull, self.attempts, self.hung = requested, None, None, None, [], False
+
+    @property
+    def fallback(self) -> bool:
+        return self.mode != self.requested
+
+    def label(self, world: int) -> str:
+        base = {"rccl": f"shard{world}+rccl-gather",
+                "ipc": f"shard{world}+ipc-peer-pull-gather (root pulls the peers' exported buffers, copy stream; control messages over gloo)",
+                "gloo": f"shard{world}+gloo-gather-via-host (functional check, not a scaling figure)"}[self.mode]
+        if self.fallback:
+            why = "; ".join(f"{a['mode']}: {a['detail']}" for a in self.attempts if not a["ok"])
+            base += f" [FALLBACK from {self.requested}: {why}]"
+        return base
+
+
+def _agree(ok: bool) -> bool:
+    """True only if every rank says so (control plane = the default gloo group, CPU tensors)."""
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(flag.item())
+
+
+def _probe_rccl(device, dst: int, timeout_s: float):
+    """Creates an RCCL group and runs ONE small gather on it in a helper thread, with a deadline: communicator creation
+    and the first collective are where a multi-GPU job hangs or fails (no 8-GPU node has been available to any round,
+    so the first real run must not be able to end without a line).  -> (group or None, detail, hung)"""
+    from datetime import timedelta
+    world, rank = dist.get_world_size(), dist.get_rank()
+    box = {"ok": False, "err": "", "group": None}
+
+    def run():
+        try:
+            if _fault("rccl_hang", rank):
+                time.sleep(10 ** 6)
+            if _fault("rccl_error", rank):
+                raise RuntimeError("injected failure (SN_BENCH_FAULT=rccl_error)")
+            t = torch.full((4,), rank + 1, dtype=torch.int32, device=device)
+            bufs = [torch.empty_like(t) for _ in range(world)] if rank == dst else None
+            dist.gather(t, bufs, dst=dst, group=box["group"])
+            if torch.device(device).type == "cuda":
+                torch.cuda.synchronize(device)
+            if rank == dst and any(int(b[0]) != r + 1 for r, b in enumerate(bufs)):
+                raise RuntimeError("the probe gather returned wrong values")
+            box["ok"] = True
+        except Exception as e:                               # noqa: BLE001
+            box["err"] = repr(e)[:300]
+
+    try:
+        # (a long collective timeout: torch's own watchdog must not tear the process down while the fallback runs)
+        box["group"] = dist.new_group(backend="nccl", timeout=timedelta(minutes=60))
+    except Exception as e:                                   # noqa: BLE001
+        if not _fault("rccl_hang", rank):                    # (an injected hang is played out below even where RCCL cannot start)
+            return None, f"communicator group: {repr(e)[:300]}", False
+    th = threading.Thread(target=run, daemon=True, name="sn-rccl-probe")
+    th.start()
+    th.join(timeout_s)
+    if th.is_alive():
+        return None, f"no answer from the first gather within {timeout_s:.0f} s", True
+    if not box["ok"]:
+        return None, box["err"] or "failed", False
+    return box["group"], "ok", False
+
+
+def choose_gather(requested: str, device, shape, dtype, dst: int = 0, timeout_s: float = 60.0) -> GatherPlan:
+    """Sets up the job's one exchange (gather of the maps to `dst`), falling back instead of dying: rccl -> ipc -> gloo.
+    Collective: every rank calls it with the same arguments; the DEFAULT process group must be gloo (control plane).  Every
+    mode is tried under a deadline and accepted only if ALL ranks succeeded; the plan records what was tried and why it was
+    left (bench.py prints it in config.parallelism and `gather`)."""
+    if dist.get_backend() != "gloo":
+        raise RuntimeError("choose_gather wants a gloo default process group as its control plane")
+    order = {"rccl": ["rccl", "ipc", "gloo"], "ipc": ["ipc", "gloo"], "gloo": ["gloo"]}[requested]
+    plan = GatherPlan(requested)
+    for mode in order:
+        t0 = time.perf_counter()
+        ok, detail = False, ""
+        if mode == "rccl":
+            group, detail, hung = _probe_rccl(device, dst, timeout_s)
+            plan.hung = plan.hung or hung
+            ok = group is not None
+            if _agree(ok):
+                plan.group = group
+            elif ok:
+                ok, detail = False, "another rank's probe failed"
+        elif mode == "ipc":
+            try:
+                plan.pull = PeerPullGather(shape, dtype, device, dst=dst)
+                ok, detail = True, "ok"
+            except Exception as e:                           # noqa: BLE001 (PeerPullGather fails on every rank together)
+                plan.pull, detail = None, repr(e)[:300]
+            if not _agree(ok) and ok:
+                ok, detail = False, "another rank could not set it up"
+                plan.pull.close()
+                plan.pull = None
+        else:
+            ok, detail = _agree(True), "ok"
+        plan.attempts.append({"mode": mode, "ok": ok, "seconds": round(time.perf_counter() - t0, 3), "detail": detail})
+        if ok:
+            plan.mode = mode
+            return plan
+    raise RuntimeError("no gather mode could be set up")

@@ -3,7 +3,7 @@
 D1) needed to score the output against dataset ground truth.
 
     python -m hobot_stereonet_amd.filelist --model m.snw --left left.list --right right.list \
-        [--gt gt.list] [--out out_dir] [--precision f16|f16x3|fp32]
+        [--gt gt.list] [--out out_dir] [--precision auto|f16|f16x3|fp32]
 
 Per frame i (same order as the reference): read left[i] / right[i] (8-bit colour image) -> BGR -> NV12
 (`images.bgr_to_nv12`) -> side-by-side frame -> `sn_infer_sbs_nv12` (split + pre-processing + network on the
@@ -125,11 +125,11 @@ def main(argv=None) -> int:
     ap.add_argument("--right", required=True)
     ap.add_argument("--gt", default=None, help="optional list of ground-truth disparities (.pfm or 16-bit .png)")
     ap.add_argument("--out", default=None)
-    ap.add_argument("--precision", choices=["f16", "f16x3", "fp32"], default="f16")
+    ap.add_argument("--precision", choices=["auto", "f16", "f16x3", "fp32"], default="auto")
     ap.add_argument("--device", type=int, default=-1)
     args = ap.parse_args(argv)
     from . import api
-    prec = {"f16": api.PREC_F16, "f16x3": api.PREC_F16X3, "fp32": api.PREC_FP32}[args.precision]
+    prec = {"auto": api.PREC_AUTO, "f16": api.PREC_F16, "f16x3": api.PREC_F16X3, "fp32": api.PREC_FP32}[args.precision]
     try:
         read_pair_lists(args.left, args.right)          # fail on the lists before touching the GPU
         with api.StereoNetHIP(args.model, device=args.device, precision=prec) as eng:

@@ -45,10 +45,11 @@ extern "C" {
 
 typedef struct sn_handle sn_handle;
 
-/* Version of this binary interface.  2 = the SN_PREC_* numbering below (0 means "default" = SN_PREC_F16 and exact fp32 is
- * 3); version 1 (round 1) had 0 = exact fp32.  A caller built against an older header compares SN_ABI_VERSION with
- * sn_abi_version() at start-up instead of silently running in another arithmetic. */
-#define SN_ABI_VERSION 2
+/* Version of this binary interface.  3 = SN_PREC_AUTO exists and is what 0 ("default") selects, sn_io_info ends in
+ * precision_selected, sn_get_refine_stats / sn_auto_* exist; 2 = the SN_PREC_* numbering below with 0 = SN_PREC_F16 and
+ * exact fp32 = 3; version 1 (round 1) had 0 = exact fp32.  A caller built against an older header compares
+ * SN_ABI_VERSION with sn_abi_version() at start-up instead of silently running in another arithmetic. */
+#define SN_ABI_VERSION 3
 int sn_abi_version(void);
 
 enum {
@@ -66,18 +67,31 @@ enum { SN_MEM_HOST = 0, SN_MEM_DEVICE = 1 };
 
 /* Arithmetic of the convolution contractions.  All variants accumulate in fp32. */
 enum {
-  SN_PREC_DEFAULT = 0,   /* a zero-initialised or NULL sn_config selects SN_PREC_F16              */
+  SN_PREC_DEFAULT = 0,   /* a zero-initialised or NULL sn_config selects SN_PREC_AUTO             */
   SN_PREC_F16X3 = 1,     /* refinement tower on fp16 MFMA with hi/lo operand split (3 MFMAs per   */
                          /* product, ~2^-22 relative): fp32-class accuracy at 3/16 of the fp32    */
                          /* MFMA cost; activations stored as two fp16 tensors                     */
   SN_PREC_F16 = 2,       /* refinement tower on plain fp16 MFMA operands (3x3 weights rounded per  */
                          /* kernel so that every kernel's tap sum survives: no coherent offset);  */
-                         /* low-resolution branch on 22-bit split fp16 operands (the default, and */
-                         /* what bench.py measures).  Envelope: EPE vs the fp32 oracle < 1e-3 px   */
-                         /* while the refinement adds up to ~2-3 px on average (8 weight draws,   */
-                         /* profiles/r05_epe_sensitivity_*.txt); the error then grows linearly    */
-                         /* with the residual: larger ones belong to SN_PREC_F16X3                */
-  SN_PREC_FP32 = 3       /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere                  */
+                         /* low-resolution branch on 22-bit split fp16 operands.  Its error is     */
+                         /* proportional to what the refinement adds to the map: over 8 weight    */
+                         /* draws (profiles/r05_epe_sensitivity_*.txt) EPE vs the fp32 oracle is    */
+                         /* 1.8e-4 .. 8.3e-4 px per pixel of mean |D r|, i.e. < 1e-3 px is only    */
+                         /* GUARANTEED up to ~1.1 px of mean residual at 1280x720 (typically up   */
+                         /* to ~2 px); a hierarchical model holds at head gain 1 only.  Forcing    */
+                         /* this mode is the caller's statement that the model is inside that.    */
+  SN_PREC_FP32 = 3,      /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere                   */
+  SN_PREC_AUTO = 4       /* the default: SN_PREC_F16 while the model stays inside the fp16 tower's */
+                         /* envelope, SN_PREC_F16X3 otherwise.  Every head kernel sums |D r| (the  */
+                         /* refinement statistic, sn_get_refine_stats); the first call of a handle */
+                         /* also runs one pair in both arithmetics and measures their distance.    */
+                         /* A call whose statistic (or self-check) predicts EPE > 1e-3 px is       */
+                         /* REPEATED in SN_PREC_F16X3 before it returns, and the handle stays      */
+                         /* there until the statistic has been back inside 0.8 of the envelope    */
+                         /* for 8 calls.  Calls that only enqueue work (device buffers + a caller */
+                         /* stream) cannot be repeated: the first such call of a handle blocks    */
+                         /* for the self-check, later ones act on the statistic of the call        */
+                         /* before (sn_auto_* below is the state machine, pure functions).         */
 };
 
 typedef struct sn_config {
@@ -86,7 +100,7 @@ typedef struct sn_config {
   int width;         /* 0 = take from the model file header                                      */
   int height;        /* 0 = take from the model file header                                      */
   int dmax;          /* max disparity D (multiple of 16, <= 256); 0 = from the model file        */
-  int precision;     /* SN_PREC_*; 0 = SN_PREC_F16                                                */
+  int precision;     /* SN_PREC_*; 0 = SN_PREC_AUTO                                               */
   int task_num;      /* async slots for sn_submit; <=0 -> 4 (stereonet_node.cpp:144)              */
   int refine_chunk;  /* pairs per refinement-tower launch; <=0 -> sized by work per launch, about    */
                      /* 5.5 Mpx (6 at 1280x720, 8 at 1248x384, max 8); the per-layer forms           */
@@ -108,6 +122,8 @@ typedef struct sn_io_info {
   int tower_streams;      /* tower chunks in flight (1 or 2)                   */
   int refine_levels;      /* 1 = single-scale refinement; 4 = hierarchical (towers at 1/8, 1/4, 1/2, 1), as the
                            * model file says (weights.py: header word 72) */
+  int precision_selected; /* arithmetic the NEXT call runs in: = precision unless that is SN_PREC_AUTO
+                           * (then SN_PREC_F16 or SN_PREC_F16X3) */
 } sn_io_info;
 
 /* DnnNode::Init + Model introspection ------------------------------------------------------- */
@@ -117,6 +133,54 @@ int sn_get_io_info(const sn_handle *h, sn_io_info *info);
 const char *sn_strerror(int code);
 const char *sn_last_error(const sn_handle *h);   /* detail of the last failure on this handle; h = NULL: of the
                                                   * last failed sn_create on the calling thread */
+
+/* Refinement statistic and SN_PREC_AUTO --------------------------------------------------------------------------
+ * The reference loads an opaque model_file and only checks that it exists (stereonet_node.cpp:131-136); whether the
+ * fp16 tower keeps north_star's 1e-3 px on it depends on how far its refinement moves the map.  Every head kernel
+ * therefore accumulates the sum of |D_k r_k| over the pixels it writes (level k of the refinement, in level-k pixels;
+ * one 64-bit fixed-point atomic per wave, outputs bit-unchanged), all precision modes. */
+typedef struct sn_refine_stats {
+  int levels;                       /* refinement levels of the model (1 or 4)                                        */
+  int precision;                    /* as configured (SN_PREC_*)                                                      */
+  int precision_selected;           /* arithmetic the next call runs in (differs from `precision` under SN_PREC_AUTO)  */
+  int precision_last;               /* arithmetic the most recent call's maps were computed in                        */
+  uint64_t calls, pairs;            /* completed calls / stereo pairs since sn_create (every entry point)             */
+  uint64_t switches;                /* SN_PREC_AUTO: changes of arithmetic                                            */
+  uint64_t reruns;                  /* SN_PREC_AUTO: calls repeated in SN_PREC_F16X3 before they returned              */
+  double level_px[4];               /* last call: mean |D_k r_k| of level k (0 = full resolution), level-k pixels      */
+  double residual_px;               /* last call: sum_k 2^k level_px[k] = full-resolution pixels the refinement adds   */
+  double running_px;                /* exponential mean of residual_px over the calls (weight 1/4)                    */
+  double envelope_px;               /* SN_PREC_F16 is trusted while residual_px stays below this (shape class)         */
+  double limit_px;                  /* the threshold in force (sn_auto_limit_px)                                      */
+  double selfcheck_epe_px;          /* mean |F16 - F16X3| of the self-check pair, < 0 = not measured                   */
+  double selfcheck_residual_px;     /* residual_px of that pair                                                       */
+} sn_refine_stats;
+int sn_get_refine_stats(sn_handle *h, sn_refine_stats *out);
+
+/* SN_PREC_AUTO's decision as pure functions (no GPU; tests/test_auto_precision.py).  sn_auto_observe folds the statistic of
+ * one finished call in and returns the arithmetic of the next one; a caller that ran the call in SN_PREC_F16 and gets
+ * SN_PREC_F16X3 back repeats the call.
+ *   limit: envelope_px (the shape class's envelope = the budget over the WORST error-per-pixel of the measured weight
+ *          draws) until the self-check has measured THIS model's error per pixel of residual (epe_per_px); then
+ *          min(SN_AUTO_ENVELOPE_CAP * envelope_px, SN_AUTO_BUDGET_PX / epe_per_px).
+ *   F16 -> F16X3: residual > limit (at once).  F16X3 -> F16: SN_AUTO_CALM_CALLS consecutive calls with residual <
+ *   SN_AUTO_REENTRY * limit. */
+#define SN_AUTO_BUDGET_PX 0.85e-3   /* of north_star's 1e-3 px: the rest is SN_PREC_F16X3's own distance to the oracle */
+#define SN_AUTO_ENVELOPE_CAP 4.0    /* a measured slope may widen the class envelope by at most this factor            */
+#define SN_AUTO_REENTRY 0.8
+#define SN_AUTO_CALM_CALLS 8
+typedef struct sn_auto_state {
+  int mode;             /* SN_PREC_F16 or SN_PREC_F16X3: arithmetic of the next call                              */
+  int calm;             /* consecutive SN_PREC_F16X3 calls whose residual sat inside the re-entry band            */
+  double envelope_px;   /* measured envelope of the shape class (sn_auto_envelope_px)                             */
+  double epe_per_px;    /* self-check: mean |F16 - F16X3| per pixel of residual; 0 = not measured                 */
+  double running_px;    /* exponential mean of the residual, < 0 before the first call                            */
+  uint64_t switches;
+} sn_auto_state;
+double sn_auto_envelope_px(int refine_levels);          /* 1: single-scale; 4: hierarchical                        */
+int sn_auto_init(sn_auto_state *s, int refine_levels);
+double sn_auto_limit_px(const sn_auto_state *s);
+int sn_auto_observe(sn_auto_state *s, double residual_px);   /* returns the new s->mode                            */
 
 /* DnnNode::Run, synchronous form (stereonet_node.cpp:968) ----------------------------------- */
 /* out_i32 and out_disp may each be NULL (but not both). */

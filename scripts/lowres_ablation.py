@@ -20,6 +20,9 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 os.environ["SN_AGG_DMA"] = "0"          # plain split-slot layouts throughout (bit-identical to the zero-bordered ones), so
 os.environ["SN_DOWN_DMA"] = "0"         # that every row of the table runs the same kernels
+os.environ["SN_DOWN01"] = "0"           # down-convs 0 and 1 as their own layers: folded (the default since round 5) there is no
+                                        # down1 input tensor / weight set for the "down1" rows to ablate
+os.environ["SN_PRECISION"] = "f16"      # the table is about the fp16 mode's layers (the library default is SN_PREC_AUTO)
 import oracle_py  # noqa: E402
 from hobot_stereonet_amd import api, build as snbuild, synth, weights  # noqa: E402
 

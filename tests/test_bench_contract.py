@@ -49,7 +49,50 @@ def test_self_launch_plumbing_two_ranks_gloo():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
-    assert lines[0] == {"plumbing": "ok", "n_gpus": 2, "world_size_seen": 2, "self_launched": True}
+    d = lines[0]
+    assert (d["plumbing"], d["n_gpus"], d["world_size_seen"], d["self_launched"]) == ("ok", 2, 2, True)
+    # no RCCL on this box: the job must say so and run on, not die (dist.choose_gather: rccl -> ipc -> gloo)
+    assert d["gather"]["requested"] == "rccl" and d["gather"]["mode"] == "ipc" and d["gather"]["fallback"] is True
+    assert "FALLBACK from rccl" in d["parallelism"] and d["gather"]["attempts"][0]["ok"] is False
+    assert [p["rank"] for p in d["per_rank"]] == [0, 1]
+    assert all(p["ms_per_step"] > 0 and p["gather_wait_ms_per_step"] >= 0 for p in d["per_rank"])
+
+
+def _plumbing(extra, env_extra, ranks=2, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, BENCH, "--gpus", str(ranks), "--batch", "3", "--selftest-plumbing"] + extra,
+                       capture_output=True, text=True, cwd=ROOT, timeout=timeout, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    return lines[0]
+
+
+def test_a_hung_communicator_ends_in_a_labelled_fallback_not_in_silence():
+    """if RCCL init or the first gather hangs, the run must still yield a line.  Rank 1's probe is made
+    to hang (SN_BENCH_FAULT=rccl_hang@1); the watchdog (2 s here) expires, ALL ranks agree to leave RCCL, the job runs on
+    the ipc gather, says so, and exits cleanly although a thread is still stuck."""
+    d = _plumbing([], {"SN_BENCH_FAULT": "rccl_hang@1", "SN_BENCH_WATCHDOG_S": "2"})
+    assert d["plumbing"] == "ok"
+    assert d["gather"]["mode"] == "ipc" and d["gather"]["fallback"] is True and "FALLBACK from rccl" in d["parallelism"]
+
+
+def test_fallback_chain_reaches_the_host_gather():
+    d = _plumbing([], {"SN_BENCH_FAULT": "ipc_error@1"}, ranks=3)
+    assert d["plumbing"] == "ok" and d["n_gpus"] == 3
+    assert [a["mode"] for a in d["gather"]["attempts"]] == ["rccl", "ipc", "gloo"]
+    assert [a["ok"] for a in d["gather"]["attempts"]] == [False, False, True]
+    assert "injected failure" in d["gather"]["attempts"][1]["detail"]
+    assert d["gather"]["mode"] == "gloo" and "gloo-gather-via-host" in d["parallelism"] and "FALLBACK" in d["parallelism"]
+
+
+def test_requested_modes_are_not_labelled_as_fallbacks():
+    d = _plumbing(["--gather", "ipc"], {})
+    assert d["gather"] == {"requested": "ipc", "mode": "ipc", "fallback": False, "attempts": d["gather"]["attempts"]}
+    assert "FALLBACK" not in d["parallelism"] and "ipc-peer-pull" in d["parallelism"]
+    d = _plumbing(["--dist-backend", "gloo"], {})
+    assert d["gather"]["mode"] == "gloo" and d["gather"]["fallback"] is False and "FALLBACK" not in d["parallelism"]
 
 
 def test_launcher_world_size_mismatch_is_refused():

@@ -58,10 +58,52 @@ def test_two_ranks_on_one_gpu_peer_pull_gather():
 
 
 @pytest.mark.gpu
-def test_shared_gpu_needs_gloo():
-    r, lines = _run(["--gpus", "2", "--device-map", "0,0", "--batch", "2", "--steps", "1"])
-    assert r.returncode != 0 and not lines
-    assert "gloo" in r.stderr
+def test_rccl_refusing_the_devices_ends_in_a_labelled_ipc_fallback():
+    """Two ranks on ONE GPU with the default --dist-backend nccl: RCCL refuses duplicate devices — a REAL communicator
+    failure on this box.  The job must not die without a line: all ranks agree to leave RCCL, the maps
+    travel by the ipc gather, the line says so, carries every rank's clocks, and still verifies bit for bit."""
+    r, lines = _run(["--gpus", "2", "--device-map", "0,0", "--batch", "4", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                     "--no-end-to-end", "--no-long"], env={"SN_BENCH_WATCHDOG_S": "45"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1
+    d = lines[0]
+    g = d["gather"]
+    assert g["requested"] == "rccl" and g["mode"] == "ipc" and g["fallback"] is True and g["attempts"][0]["ok"] is False
+    assert "FALLBACK from rccl" in d["config"]["parallelism"] and "ipc-peer-pull" in d["config"]["parallelism"]
+    assert d["verified"] is True and "gathered maps of ranks 1..1" in d["verification"]
+    pr = d["per_rank"]
+    assert [p["rank"] for p in pr] == [0, 1]
+    for p in pr:
+        assert 0 < p["engine_ms_per_step"] <= p["ms_per_step"] + 1e-6
+        assert p["gather_wait_ms_per_step"] >= 0 and p["gather_issue_ms_per_step"] >= 0
+    assert d["root_extra_ms_per_step_over_median_rank"] is not None
+    assert d["refine_stats"]["same_on_all_ranks"] is True and d["config"]["precision_selected"] == "f16"
+
+
+@pytest.mark.gpu
+def test_a_hung_rccl_probe_with_the_real_engine():
+    """The watchdog with the real engine: rank 1's RCCL probe hangs (injected), the deadline (5 s) expires, the job runs on
+    the ipc gather and exits although a thread is still stuck in the probe."""
+    r, lines = _run(["--gpus", "2", "--device-map", "0,0", "--batch", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                     "--no-end-to-end", "--no-long"], env={"SN_BENCH_FAULT": "rccl_hang@1", "SN_BENCH_WATCHDOG_S": "5"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = lines[0]
+    assert d["gather"]["mode"] == "ipc" and d["gather"]["fallback"] is True and d["verified"] is True
+
+
+@pytest.mark.gpu
+def test_three_ranks_ipc_gather_shuts_down_cleanly():
+    """Teardown order of the IPC exports (round 5's ipc3.log ended with torch's "Producer process has been terminated before
+    all shared CUDA tensors released"): the root drops its views and releases the opened mappings, barrier, only then the
+    producers let go; the root itself exports nothing.  Three ranks on one GPU, no warning."""
+    r, lines = _run(["--gpus", "3", "--dist-backend", "gloo", "--device-map", "0,0,0", "--gather", "ipc", "--batch", "2",
+                     "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-end-to-end", "--no-long"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = lines[0]
+    assert d["n_gpus"] == 3 and d["verified"] is True and "gathered maps of ranks 1..2" in d["verification"]
+    assert d["gather"]["mode"] == "ipc" and d["gather"]["fallback"] is False
+    assert "Producer process has been terminated" not in r.stderr, r.stderr[-3000:]
+    assert "CudaIPCTypes" not in r.stderr, r.stderr[-3000:]
 
 
 @pytest.mark.gpu

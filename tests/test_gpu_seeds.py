@@ -28,7 +28,7 @@ def _epe(path, prec, x, od):
     return float(err.mean()), float(err.max())
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 5])
+@pytest.mark.parametrize("seed", [1, 2, 3, 5, 6, 7])      # 6 and 7: the two worst draws of profiles/r05_epe_sensitivity_*.txt
 @pytest.mark.parametrize("shape", sorted(SHAPES))
 def test_other_weight_seeds_stay_inside_the_bounds(oracle, tmp_path, shape, seed):
     w, h, d, levels = SHAPES[shape]
@@ -59,7 +59,9 @@ def test_margin_of_the_default_weights(oracle, tmp_path, shape):
 @pytest.mark.parametrize("shape", sorted(SHAPES))
 def test_large_residuals_need_and_get_the_split_mode(oracle, tmp_path, shape):
     """Head gain 8 (the refinement moves the map by several pixels on average): outside the fp16 tower's envelope by
-    construction — its error is ~5e-4 of the residual — and inside SN_PREC_F16X3's and SN_PREC_FP32's."""
+    construction — its error is 1.8e-4 .. 8.3e-4 px per pixel of residual — and inside SN_PREC_F16X3's and SN_PREC_FP32's.
+    A forced SN_PREC_F16 is over the bound there (that is why it is not the default); the default, SN_PREC_AUTO, must notice
+    and deliver the split mode's maps (tests/test_gpu_auto.py runs the whole seed x gain grid)."""
     w, h, d, levels = SHAPES[shape]
     blob = weights.synthetic(1, levels, head_gain=8.0)
     x = synth.model_input_i8(w, h, d, 501)
@@ -70,9 +72,16 @@ def test_large_residuals_need_and_get_the_split_mode(oracle, tmp_path, shape):
     e32, _ = _epe(path, api.PREC_FP32, x, od)
     e16, _ = _epe(path, api.PREC_F16, x, od)
     print(f"{shape} head gain 8: refinement {refine_px:.2f} px mean; EPE F16 {e16:.3e}, F16X3 {ex3:.3e}, FP32 {e32:.3e}")
+    with api.StereoNetHIP(path) as eng:               # default precision
+        da, _ = eng.infer(x)
+        st = eng.refine_stats()
+    ea = float(np.abs(da - od).mean())
+    print(f"{shape} head gain 8: default precision ran {st['precision_last']} (residual statistic {st['residual_px']:.2f} px, "
+          f"limit {st['limit_px']:.2f} px), EPE {ea:.3e}")
     assert refine_px > 2.0
     assert ex3 < X3_TOL and e32 < X3_TOL
-    assert e16 < 2e-3 * max(1.0, refine_px)          # grows with the residual, stays proportional to it
+    assert e16 > F16_TOL                               # the fp16 tower alone does NOT hold the bound here
+    assert st["precision_last"] == "f16x3" and ea < X3_TOL
 
 
 @pytest.mark.parametrize("shape,seed", [("c2_single", 6), ("c5_multi", 3)])
