@@ -215,11 +215,33 @@ struct UpScale {
 // (|dmax * acc| and not |d - up|: `up` is itself a product (map value x factor) and `up + dmax * acc` contracts into ONE fma
 // with whichever product has fewer uses; a second use of `up` flipped that choice and the last bit of d — seen as a
 // difference against the round-5 library wherever dmax is not a power of two, profiles/r06_ab_outputs.txt)
+// Where the sums meet: atomics on ONE address are resolved one after the other at about 10 ns each on this part (measured:
+// the fp32 head with 4368 per-wave atomics per 1280x720 map ran 82.7 us, 41.3 us without them; profiles/r06_stat_atomics.txt),
+// so a statistic word is kStatSlots partial sums in separate 128-byte lines (slot = workgroup index mod kStatSlots; the host
+// adds them up — still integers, still order-independent), and the kernels that can meet in LDS first commit once per
+// workgroup (refine_stat_commit_block).
 constexpr float kStatScale = 1048576.0f;
+constexpr int kStatSlots = 16, kStatLine = 16;              // partial sums per word; 64-bit words per 128-byte line
+constexpr int kStatWordStride = kStatSlots * kStatLine;     // 64-bit words between two statistic words (levels)
 __device__ __forceinline__ void refine_stat_commit(unsigned long long* stat, float lane_sum) {
 #pragma unroll
   for (int off = 32; off; off >>= 1) lane_sum += __shfl_xor(lane_sum, off);
-  if (stat != nullptr && (threadIdx.x & 63) == 0) atomicAdd(stat, (unsigned long long)(lane_sum * kStatScale + 0.5f));
+  if (stat != nullptr && (threadIdx.x & 63) == 0)
+    atomicAdd(stat + (blockIdx.x % kStatSlots) * kStatLine, (unsigned long long)(lane_sum * kStatScale + 0.5f));
+}
+// every thread of a (<= 512-thread) workgroup calls this: one atomic per workgroup
+__device__ __forceinline__ void refine_stat_commit_block(unsigned long long* stat, float lane_sum) {
+  __shared__ float s_stat[8];
+#pragma unroll
+  for (int off = 32; off; off >>= 1) lane_sum += __shfl_xor(lane_sum, off);
+  if ((threadIdx.x & 63) == 0) s_stat[threadIdx.x >> 6] = lane_sum;
+  __syncthreads();
+  if (stat != nullptr && threadIdx.x == 0) {
+    float sum = 0.f;
+    for (unsigned w = 0; w < (blockDim.x + 63) / 64; ++w) sum += s_stat[w];
+    const unsigned wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    atomicAdd(stat + (wg % kStatSlots) * kStatLine, (unsigned long long)(sum * kStatScale + 0.5f));
+  }
 }
 
 // bilinear upsample, align_corners=False (half-pixel centres, edge clamp), values x factor
@@ -1219,7 +1241,7 @@ __global__ __launch_bounds__(256) void k_head_final(const float* __restrict__ xi
   if (out_disp) out_disp[o] = d;
   if (out_raw) out_raw[o] = (int32_t)__float2int_rn(d * inv_q);
   }
-  refine_stat_commit(stat, moved);
+  refine_stat_commit_block(stat, moved);
 }
 
 
@@ -2225,7 +2247,95 @@ __global__ __launch_bounds__(256) void k_head_final_f16(const uint4* __restrict_
     if (out_disp) out_disp[o] = d;
     if (out_raw) out_raw[o] = (int32_t)__float2int_rn(d * inv_q);
   }
-  refine_stat_commit(stat, moved);
+  refine_stat_commit_block(stat, moved);
+}
+
+// K8 in SN_PREC_FP32 on the matrix core: the same taps-as-M contraction on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32):
+//     P[tap][pixel] = sum_c w[c][tap] * x[c][pixel]            sixteen 32x32x2 MFMAs per 32 pixels (K = 2 channels each)
+// x is the plain fp32 NCHW tensor (no border: out-of-image pixels of the P window are zero operands); lane (j, kh) of K-step
+// kk reads channel 2 kk + kh of pixel j — 128-byte runs per half-wave, every element ONCE per P window instead of nine
+// times through L1 (k_head_final: 288 loads + 288 fma per pixel, 81 us per 1280x720 map; BASELINE configs[1]'s single
+// pair spends 2.6 % of its time there).  Products and sums are exact fp32 fmas; only the summation order differs from
+// k_head_final (channels first, then the nine taps).
+template <int TH>
+__global__ __launch_bounds__(256) void k_head_final_mfma32(const float* __restrict__ xin,     // [n][32][Hp][Wp]
+                                                           const float* __restrict__ w,       // [32][9]
+                                                           float bias, const float* __restrict__ disp_low, int hl, int wl,
+                                                           int Hp, int Wp, int H, int W, float dmax, float inv_q,
+                                                           float* __restrict__ out_disp, int32_t* __restrict__ out_raw,
+                                                           int tiles_x, int tiles_y, UpScale ups,
+                                                           unsigned long long* __restrict__ stat) {   // nullable: sum |D r|
+  using T = HeadTile<TH>;
+  static_assert(T::NSEG % 4 == 0, "whole segments per wave");
+  extern __shared__ __attribute__((aligned(16))) float s_p[];           // [9][RP][CP]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, kh = lane >> 5;
+  int t = blockIdx.x;
+  const int tx = t % tiles_x;
+  t /= tiles_x;
+  const int ty = t % tiles_y, n = t / tiles_y;
+  const int y0 = ty * T::TH, x0 = tx * T::TWO;
+  const size_t plane = (size_t)Hp * Wp;
+  const float* src = xin + ((size_t)n * kC + kh) * plane;
+
+  // A operands: row i = tap (rows 9.. are zero), K-step kk <-> channels 2 kk, 2 kk + 1
+  float a[16];
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) a[kk] = j < 9 ? w[(2 * kk + kh) * 9 + j] : 0.f;
+  constexpr int HALF = T::SPW > 4 ? (T::SPW + 1) / 2 : T::SPW;         // segments whose loads are in flight together
+#pragma unroll
+  for (int s0 = 0; s0 < T::SPW; s0 += HALF) {
+    float b[HALF][16];
+#pragma unroll
+    for (int s = 0; s < HALF; ++s) {
+      const int seg = wave * T::SPW + s0 + s;
+      const int yy = y0 - 1 + (seg >> 1), xx = x0 - 1 + (seg & 1) * 32 + j;
+      const bool ok = s0 + s < T::SPW && (unsigned)yy < (unsigned)Hp && (unsigned)xx < (unsigned)Wp;
+      const float* p = src + (size_t)(ok ? yy : 0) * Wp + (ok ? xx : 0);
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const float v = p[(size_t)(2 * kk) * plane];
+        b[s][kk] = ok ? v : 0.f;
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < HALF; ++s) {
+      if (s0 + s >= T::SPW) break;
+      const int seg = wave * T::SPW + s0 + s;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b[s][kk], acc, 0, 0, 0);
+      // accumulator row (r & 3) + 8 (r >> 2) + 4 kh: lanes kh = 0 hold taps 0..3 (r 0..3) and 8 (r 4), kh = 1 taps 4..7
+      float* dst = s_p + (seg >> 1) * T::CP + (seg & 1) * 32 + j;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst[(4 * kh + r) * T::PLANE] = acc[r];
+      if (kh == 0) dst[8 * T::PLANE] = acc[4];
+    }
+  }
+  __syncthreads();
+  const float* dl = disp_low + (size_t)n * hl * wl;
+  float moved = 0.f;
+  for (int p = tid; p < T::TH * T::TWO; p += 256) {
+    const int oy = p / T::TWO, ox = p - oy * T::TWO;
+    const int y = y0 + oy, x = x0 + ox;
+    if (y >= H || x >= W) continue;
+    float acc = bias;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) acc += s_p[(ky * 3 + kx) * T::PLANE + (oy + ky) * T::CP + ox + kx];
+    const float up = upsample_map(dl, hl, wl, y, x, ups);
+    float d = up + dmax * acc;
+    moved += fabsf(dmax * acc);
+    d = d > 0.f ? d : 0.f;
+    const size_t o = ((size_t)n * H + y) * W + x;
+    if (out_disp) out_disp[o] = d;
+    if (out_raw) out_raw[o] = (int32_t)__float2int_rn(d * inv_q);
+  }
+  refine_stat_commit_block(stat, moved);
 }
 
 }  // namespace sn

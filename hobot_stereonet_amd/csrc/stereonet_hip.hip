@@ -100,6 +100,7 @@ struct HeadLayer {          // C -> 1 layers (VALU kernels)
 
 constexpr int kMaxLevels = 4, kMultiLevels = 4;              // hierarchical refinement: 1/8, 1/4, 1/2, 1
 constexpr int kStatWords = 8;                                // refinement statistic: [level 0..3] sum |D r|, [4] self-check sum |a - b|
+constexpr size_t kStatU64 = (size_t)kStatWords * kStatWordStride;   // each word = kStatSlots partial sums in separate 128-byte lines
 constexpr int kTileCtrStride = 8 * 16;                       // uints per tower launch (one 64-B line per XCD)
 constexpr size_t kTileCtrBytes = (size_t)2 * 6 * kTileCtrStride * sizeof(unsigned);   // 2 * kNRefRes launches
 
@@ -792,23 +793,24 @@ hipError_t conv3x3_d(hipStream_t st, const ConvLayer& L, const float* in, int ni
 }
 
 // Tower layers of SN_PREC_FP32 (plain fp32 NCHW, 32 -> 32, 3x3 dilated): the weights-stationary kernel of sn_tower_f32.hpp.
-template <int DIL, int CPH>
+template <int DIL, int CPH, int NW = 8>
 hipError_t launch_ref_conv_f32(hipStream_t st, const ConvLayer& L, const float* in, int nimg, int H, int W, float* out,
                                const float* res, bool lrelu, int num_cu) {
-  using T = F32Tile<DIL, CPH>;
-  auto kern = res ? k_ref_conv_f32<DIL, CPH, true> : k_ref_conv_f32<DIL, CPH, false>;
+  using T = F32Tile<DIL, CPH, 64, NW>;
+  auto kern = res ? k_ref_conv_f32<DIL, CPH, true, NW> : k_ref_conv_f32<DIL, CPH, false, NW>;
   if (T::LDS_BYTES > 64 * 1024 - 1024) {
     hipError_t e = ensure_lds_attr(kern, T::LDS_BYTES);
     if (e != hipSuccess) return e;
   }
   const int total = ((W + T::TW - 1) / T::TW) * ((H + T::TH - 1) / T::TH) * nimg;
-  // persistent: two workgroups per CU, tiles strided over them; the grid is trimmed so that every workgroup gets the
-  // same number of tiles (1280x720, one pair: 1800 tiles = 450 workgroups x 4 instead of 512 x 3.5 -> 4 rounds)
-  const int cap = 2 * num_cu;
-  const int rounds = (total + cap - 1) / cap;
-  int grid = (total + rounds - 1) / rounds;
+  // persistent: ONE workgroup per CU (it double-buffers its own staging, sn_tower_f32.hpp), each walks a contiguous share of
+  // the launch's HALF tiles (1280x720, one pair = 3600 halves on 256 CUs = 14.06 per workgroup instead of 8 whole tiles for
+  // 7.03 tiles of work)
+  int grid = 2 * total < num_cu ? 2 * total : num_cu;
+  static const int grid_env = getenv("SN_F32_GRID") ? atoi(getenv("SN_F32_GRID")) : 0;          // probe: workgroups per launch
+  if (grid_env > 0) grid = grid_env < 2 * total ? grid_env : 2 * total;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), T::LDS_BYTES, st, in, out, res, L.wpk, L.bias, nimg, H, W, lrelu ? 1 : 0);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), T::LDS_BYTES, st, in, out, res, L.wpk, L.bias, nimg, H, W, lrelu ? 1 : 0);
   return hipGetLastError();
 }
 
@@ -826,8 +828,9 @@ hipError_t conv3x3(hipStream_t st, const ConvLayer& L, const float* in, int nimg
     switch (dil) {
       case 1: return launch_ref_conv_f32<1, 8>(st, L, in, nimg, H, W, out, res, lrelu, tower_cu);
       case 2: return launch_ref_conv_f32<2, 8>(st, L, in, nimg, H, W, out, res, lrelu, tower_cu);
-      case 4: return launch_ref_conv_f32<4, 8>(st, L, in, nimg, H, W, out, res, lrelu, tower_cu);
-      case 8: return launch_ref_conv_f32<8, 4>(st, L, in, nimg, H, W, out, res, lrelu, tower_cu);
+      case 4: return launch_ref_conv_f32<4, 4, 16>(st, L, in, nimg, H, W, out, res, lrelu, tower_cu);
+      // dilation 4 / 8: sixteen rows per tile (1024 threads) — 16 / 24 halo rows per 8 would be 2 - 3x the staging of the tile itself
+      case 8: return launch_ref_conv_f32<8, 4, 16>(st, L, in, nimg, H, W, out, res, lrelu, tower_cu);
       default: return hipErrorInvalidValue;
     }
   }
@@ -1310,10 +1313,10 @@ int alloc_ws(sn_handle* h, Workspace* ws, int nb, int rb, int ns, int rb_x3 = 0)
   HIP_TRY(h, dalloc(&ws->out_disp, (size_t)nb * HW));
   HIP_TRY(h, dalloc(&ws->out_raw, (size_t)nb * HW));
   HIP_TRY(h, dalloc(&ws->nv12, (size_t)HW * 3));
-  HIP_TRY(h, dalloc(&ws->stats, kStatWords));
-  HIP_TRY(h, memset_now(ws->stats, 0, kStatWords * sizeof(unsigned long long)));
-  HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&ws->stats_host), kStatWords * sizeof(unsigned long long), hipHostMallocDefault));
-  memset(ws->stats_host, 0, kStatWords * sizeof(unsigned long long));
+  HIP_TRY(h, dalloc(&ws->stats, kStatU64));
+  HIP_TRY(h, memset_now(ws->stats, 0, kStatU64 * sizeof(unsigned long long)));
+  HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&ws->stats_host), kStatU64 * sizeof(unsigned long long), hipHostMallocDefault));
+  memset(ws->stats_host, 0, kStatU64 * sizeof(unsigned long long));
   return SN_OK;
 }
 
@@ -1563,9 +1566,26 @@ int refine_level(sn_handle* h, Workspace& ws, hipStream_t st, const Tower& T, fl
       HIP_TRY(h, conv3x3(st, T.rres[i][1], rt, c, Hk, Wk, kRefDil[i], rx, rx, true, ncu));
     }
     if (pe) HIP_TRY(h, hipEventRecord(h->ev[5], st));
-    dim3 grid((W + 63) / 64, (H + 3) / 4, c);
-    hipLaunchKernelGGL(k_head_final, grid, dim3(256), 0, st, rx, T.rout.w, T.rout.bias, src, sh, sw, Hk, Wk, H, W, dnorm,
-                       inv_q, od, orw, ups, stat);
+    // head on the fp32 MFMA with the nine taps as M (k_head_final_mfma32); SN_HEAD_MFMA32=0 keeps the per-pixel kernel (A/B)
+    static const bool head_mfma = !(getenv("SN_HEAD_MFMA32") != nullptr && atoi(getenv("SN_HEAD_MFMA32")) == 0);
+    if (head_mfma) {
+      static const int th_env = getenv("SN_HEAD_TH") ? atoi(getenv("SN_HEAD_TH")) : 14;          // probe
+      static const bool nostat = getenv("SN_HEAD_NOSTAT") != nullptr;                              // probe
+      auto go = [&](auto thc) {
+        constexpr int TH = decltype(thc)::value;
+        using HT = HeadTile<TH>;
+        const int tiles_x = (W + HT::TWO - 1) / HT::TWO, tiles_y = (H + TH - 1) / TH;
+        hipLaunchKernelGGL(k_head_final_mfma32<TH>, dim3((unsigned)(tiles_x * tiles_y * c)), dim3(256), HT::LDS_BYTES, st, rx,
+                           T.rout.w, T.rout.bias, src, sh, sw, Hk, Wk, H, W, dnorm, inv_q, od, orw, tiles_x, tiles_y, ups,
+                           nostat ? nullptr : stat);
+      };
+      if (th_env == 6) go(std::integral_constant<int, 6>{});
+      else go(std::integral_constant<int, 14>{});
+    } else {
+      dim3 grid((W + 63) / 64, (H + 3) / 4, c);
+      hipLaunchKernelGGL(k_head_final, grid, dim3(256), 0, st, rx, T.rout.w, T.rout.bias, src, sh, sw, Hk, Wk, H, W, dnorm,
+                         inv_q, od, orw, ups, stat);
+    }
   } else {
     // fp16 tower: ref.in writes the NCHW8c fp16 tensor, the 12 C->C convs run on v_mfma_f32_32x32x16_f16, the head
     // reads fp16 and finishes in fp32
@@ -1671,7 +1691,7 @@ int refine_coarse(sn_handle* h, Workspace& ws, hipStream_t st, int p0, int m, co
       rc = refine_level(h, ws, st, T, ws.ref_lv[lv][0], ws.ref_lv[lv][1], ws.ref16_lv[lv][0], ws.ref16_lv[lv][1],
                                   src + (size_t)q * sh * sw, sh, sw, UpScale{0.5f, 2.0f}, ws.pyr[lv] + (size_t)q * 3 * HWk, true,
                                   T.Hk, T.Wk, dnorm, ws.lvl_disp[lv] + (size_t)q * HWk, nullptr, ctr, c, ws.rbk[lv], false, mode,
-                                  ws.stats + lv);
+                                  ws.stats + (size_t)lv * kStatWordStride);
       if (rc) return rc;
     }
     src = ws.lvl_disp[lv];
@@ -1730,9 +1750,10 @@ int forward(sn_handle* h, Workspace& ws, hipStream_t st, int n, const int8_t* in
   int rc;
   int ctr_block = 0;          // tile-queue blocks are handed out in launch order (alloc_ws sized the pool)
   if (ws.tile_ctr) HIP_TRY(h, hipMemsetAsync(ws.tile_ctr, 0, kTileCtrBytes * ws.n_chunks, st));
-  HIP_TRY(h, hipMemsetAsync(ws.stats, 0, kMaxLevels * sizeof(unsigned long long), st));
+  HIP_TRY(h, hipMemsetAsync(ws.stats, 0, kMaxLevels * kStatWordStride * sizeof(unsigned long long), st));
   auto finish = [&]() -> int {
-    HIP_TRY(h, hipMemcpyAsync(ws.stats_host, ws.stats, kStatWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipMemcpyAsync(ws.stats_host, ws.stats, (size_t)h->levels * kStatWordStride * sizeof(unsigned long long),
+                              hipMemcpyDeviceToHost, st));        // the levels this model has (2 KB each)
     return SN_OK;
   };
   if (!piped) {
@@ -1824,18 +1845,23 @@ __global__ __launch_bounds__(256) void k_abs_diff_sum(const float* __restrict__ 
                                                       unsigned long long* __restrict__ out) {
   float sum = 0.f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) sum += fabsf(a[i] - b[i]);
-  refine_stat_commit(out, sum);
+  refine_stat_commit_block(out, sum);
 }
 
 // mean |D_k r_k| per level from a workspace's pinned statistic of an n-pair call (valid once the stream that ran forward()
 // has been synchronised): level 0 writes the H x W output maps, a coarse level its whole padded map
+inline unsigned long long stat_word(const Workspace& ws, int word) {      // the word's partial sums (refine_stat_commit)
+  unsigned long long sum = 0;
+  for (int s = 0; s < kStatSlots; ++s) sum += ws.stats_host[(size_t)word * kStatWordStride + (size_t)s * kStatLine];
+  return sum;
+}
 void read_stats(const sn_handle* h, const Workspace& ws, int n, double* level_px, double* residual_px) {
   double res = 0.0;
   for (int lv = 0; lv < kMaxLevels; ++lv) {
     level_px[lv] = 0.0;
     if (lv >= h->levels || n <= 0) continue;
     const double px = lv == 0 ? (double)h->H * h->W : (double)h->tw[lv].Hk * h->tw[lv].Wk;
-    level_px[lv] = (double)ws.stats_host[lv] / (double)kStatScale / (px * n);
+    level_px[lv] = (double)stat_word(ws, lv) / (double)kStatScale / (px * n);
     res += level_px[lv] * (double)(1 << lv);
   }
   *residual_px = res;
@@ -1887,14 +1913,14 @@ int auto_selfcheck(sn_handle* h, Workspace& ws, hipStream_t st, const int8_t* in
   h->profiling = prof;
   if (rc) return rc;
   const size_t HW = (size_t)h->H * h->W;
-  HIP_TRY(h, hipMemsetAsync(ws.stats + 4, 0, sizeof(unsigned long long), st));
-  hipLaunchKernelGGL(k_abs_diff_sum, dim3(512), dim3(256), 0, st, h->chk[0], h->chk[1], HW, ws.stats + 4);
+  HIP_TRY(h, hipMemsetAsync(ws.stats + 4 * kStatWordStride, 0, kStatWordStride * sizeof(unsigned long long), st));
+  hipLaunchKernelGGL(k_abs_diff_sum, dim3(512), dim3(256), 0, st, h->chk[0], h->chk[1], HW, ws.stats + 4 * kStatWordStride);
   HIP_TRY(h, hipGetLastError());
-  HIP_TRY(h, hipMemcpyAsync(ws.stats_host, ws.stats, kStatWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  HIP_TRY(h, hipMemcpyAsync(ws.stats_host, ws.stats, kStatU64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   HIP_TRY(h, hipStreamSynchronize(st));
   double lvl[kMaxLevels], res = 0.0;
   read_stats(h, ws, 1, lvl, &res);
-  const double epe = (double)ws.stats_host[4] / (double)kStatScale / (double)HW;
+  const double epe = (double)stat_word(ws, 4) / (double)kStatScale / (double)HW;
   std::lock_guard<std::mutex> lk(h->mu);
   AutoCtl& a = h->actl;
   a.selfcheck_epe = epe;
