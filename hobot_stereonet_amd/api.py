@@ -124,6 +124,7 @@ def load_library(path: Optional[str] = None):
     lib.sn_dbg_ref_conv_f16.argtypes = [vp, fp, ip, ip, fp, fp, ip, ip, fp, fp]
     lib.sn_dbg_ref_conv_f16x3.argtypes = [vp, fp, ip, ip, fp, fp, ip, ip, fp, fp]
     lib.sn_dbg_ref_block_f16.argtypes = [vp, fp, ip, ip, fp, fp, fp, fp, ip, fp]
+    lib.sn_dbg_ref_block_f16x3.argtypes = [vp, fp, ip, ip, fp, fp, fp, fp, ip, ip, fp]
     lib.sn_dbg_ref_tail_f16.argtypes = [vp, ip, fp, ip, ip, fp, fp, fp, fp, fp, C.c_float, fp, ip, C.c_float, ip, ip, ip, fp, i32p]
     lib.sn_dbg_read.argtypes = [vp, C.c_char_p, fp, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.sn_dbg_copy_limited.argtypes = [vp, vp, C.c_size_t, ip, vp]
@@ -139,7 +140,7 @@ def load_library(path: Optional[str] = None):
                  "sn_infer_sbs_nv12", "sn_preprocess_sbs_nv12_batch", "sn_submit", "sn_submit_nv12", "sn_wait", "sn_synchronize", "sn_set_profiling",
                  "sn_get_stage_ms", "sn_get_dominant_kernel", "sn_mgpu_shard", "sn_mgpu_create", "sn_mgpu_destroy",
                  "sn_mgpu_get_info", "sn_mgpu_get_handle", "sn_mgpu_infer_batch", "sn_mgpu_infer_batch_device",
-                 "sn_mgpu_submit_device", "sn_mgpu_wait", "sn_mgpu_ring_init", "sn_mgpu_ring_submit", "sn_mgpu_ring_wait", "sn_dbg_conv2d", "sn_dbg_down0", "sn_dbg_compose_down01", "sn_dbg_round_kernels_f16", "sn_dbg_down01", "sn_dbg_refin", "sn_dbg_conv3d", "sn_dbg_ref_conv_f16", "sn_dbg_ref_conv_f16x3", "sn_dbg_ref_block_f16", "sn_dbg_ref_tail_f16", "sn_dbg_read", "sn_dbg_copy_limited", "sn_depth_from_raw", "sn_get_refine_stats", "sn_auto_init", "sn_auto_observe"):
+                 "sn_mgpu_submit_device", "sn_mgpu_wait", "sn_mgpu_ring_init", "sn_mgpu_ring_submit", "sn_mgpu_ring_wait", "sn_dbg_conv2d", "sn_dbg_down0", "sn_dbg_compose_down01", "sn_dbg_round_kernels_f16", "sn_dbg_down01", "sn_dbg_refin", "sn_dbg_conv3d", "sn_dbg_ref_conv_f16", "sn_dbg_ref_conv_f16x3", "sn_dbg_ref_block_f16", "sn_dbg_ref_block_f16x3", "sn_dbg_ref_tail_f16", "sn_dbg_read", "sn_dbg_copy_limited", "sn_depth_from_raw", "sn_get_refine_stats", "sn_auto_init", "sn_auto_observe"):
         getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
@@ -464,6 +465,16 @@ class StereoNetHIP:
         self._check(self._lib.sn_dbg_ref_block_f16(self._h, a[0].ctypes.data, h, w, a[1].ctypes.data, a[2].ctypes.data,
                                                    a[3].ctypes.data, a[4].ctypes.data, dil, out.ctypes.data),
                     "sn_dbg_ref_block_f16")
+        return out
+
+    def dbg_ref_block_f16x3(self, x, w1, b1, w2, b2, dil=1, streamed=False):
+        """the same block on split operands (SN_PREC_F16X3): two k_ref_conv_f16x3 launches, or the row-streaming fused kernel"""
+        a = [np.ascontiguousarray(v, np.float32) for v in (x, w1, b1, w2, b2)]
+        _, h, w = a[0].shape
+        out = np.empty((32, h, w), np.float32)
+        self._check(self._lib.sn_dbg_ref_block_f16x3(self._h, a[0].ctypes.data, h, w, a[1].ctypes.data, a[2].ctypes.data,
+                                                     a[3].ctypes.data, a[4].ctypes.data, dil, int(streamed), out.ctypes.data),
+                    "sn_dbg_ref_block_f16x3")
         return out
 
     def dbg_ref_tail_f16(self, x, w1, b1, w2, b2, head_w, head_b, low, ups, dnorm, h_out, w_out, form):

@@ -1013,19 +1013,20 @@ int upload_ref_f16x3(sn_handle* h, const HostLayer& l, RefLayerF16* out) {
   return SN_OK;
 }
 
-template <int DIL, int TW, int NBUF>
+template <int DIL, int TW, int NBUF, int WPC = 1>
 hipError_t launch_ref_f16x3(hipStream_t st, const RefLayerF16& L, const RefGeom& g, int num_cu, const uint4* in,
                             uint4* out, const uint4* res, size_t lo_slots, int nimg, bool lrelu) {
   using T = RefTile2<DIL, TW>;
   constexpr int lds_bytes = NBUF * 2 * T::BUF * 16;
-  auto kern = res ? k_ref_conv_f16x3<DIL, TW, NBUF, true> : k_ref_conv_f16x3<DIL, TW, NBUF, false>;
+  static_assert(WPC * lds_bytes <= 160 * 1024, "workgroups per CU");
+  auto kern = res ? k_ref_conv_f16x3<DIL, TW, NBUF, true, WPC> : k_ref_conv_f16x3<DIL, TW, NBUF, false, WPC>;
   hipError_t e = ensure_lds_attr(kern, lds_bytes);
   if (e != hipSuccess) return e;
   RefGeom gt = g;
   gt.tiles_x = (g.W + TW - 1) / TW;
   const int total = gt.tiles_x * gt.tiles_y * nimg;
   const int band = (total + 7) / 8;
-  int cap = num_cu / 8;                      // one workgroup per CU
+  int cap = num_cu / 8 * WPC;                // WPC workgroups per CU
   if (cap < 1) cap = 1;
   const int rounds = (band + cap - 1) / cap;
   const int nlb = (band + rounds - 1) / rounds;
@@ -1200,6 +1201,52 @@ hipError_t ref_block_f16(hipStream_t st, const RefLayerF16& L1, const RefLayerF1
   RefGeom g2 = g;
   if (alt) g2.rev ^= 1;                  // the second conv walks the tiles the other way round (refine_level)
   return ref_conv_f16(st, L2, g2, num_cu, dil, *oth, *cur, *cur, nimg, true, tile_ctr + kTileCtrStride);   // in-place residual
+}
+
+// Fused residual block on split operands, row-streaming form (sn_stream_block_x3.hpp): every dilation.  x and y are
+// different hi tensors, the lo tensors sit lo_slots behind them.  SN_X3_STREAM=0 keeps two k_ref_conv_f16x3 launches (A/B).
+inline bool stream_x3_supports(int dil) {
+  static const bool on = !(getenv("SN_X3_STREAM") != nullptr && atoi(getenv("SN_X3_STREAM")) == 0);
+  return on && (dil == 1 || dil == 2 || dil == 4 || dil == 8);
+}
+template <int DIL>
+hipError_t launch_ref_block_stream_x3(hipStream_t st, const RefLayerF16& L1, const RefLayerF16& L2, const RefGeom& g, int num_cu,
+                                      const uint4* x, uint4* y, size_t lo_slots, int nimg) {
+  using T = StreamTileX3<DIL>;
+  static_assert(T::ROWS_ABOVE <= kStreamRowsAbove && T::ROWS_BELOW <= kStreamRowsBelow, "inside the zero rows the tensors are allocated with");
+  auto kern = k_ref_block_stream_x3<T::DIL, T::TW, T::R, T::NXS, T::NWR>;
+  hipError_t e = ensure_lds_attr(kern, T::LDS_BYTES);
+  if (e != hipSuccess) return e;
+  StreamSched sc;
+  sc.nstrips = (g.W + T::OW - 1) / T::OW;
+  sc.hsub = (g.H + DIL - 1) / DIL;
+  sc.total_rows = nimg * DIL * sc.nstrips * sc.hsub;
+  int nwg = num_cu;
+  if (nwg > sc.total_rows) nwg = sc.total_rows;
+  if (nwg < 1) nwg = 1;
+  sc.rows_per_wg = (sc.total_rows + nwg - 1) / nwg;
+  const int grid = (sc.total_rows + sc.rows_per_wg - 1) / sc.rows_per_wg;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * T::NWR), T::LDS_BYTES, st, x, y, lo_slots * 16, L1.wfrag, L1.bias, L2.wfrag,
+                     L2.bias, g, sc);
+  return hipGetLastError();
+}
+// One residual block of the split tower on `*cur` (input and, on return, output); `*oth` is scratch.
+hipError_t ref_block_f16x3(hipStream_t st, const RefLayerF16& L1, const RefLayerF16& L2, const RefGeom& g, int num_cu, int dil,
+                           uint4** cur, uint4** oth, size_t lo_slots, int nimg, bool stream = true) {
+  if (stream && stream_x3_supports(dil)) {
+    hipError_t e = hipErrorInvalidValue;
+    if (dil == 1) e = launch_ref_block_stream_x3<1>(st, L1, L2, g, num_cu, *cur, *oth, lo_slots, nimg);
+    else if (dil == 2) e = launch_ref_block_stream_x3<2>(st, L1, L2, g, num_cu, *cur, *oth, lo_slots, nimg);
+    else if (dil == 4) e = launch_ref_block_stream_x3<4>(st, L1, L2, g, num_cu, *cur, *oth, lo_slots, nimg);
+    else e = launch_ref_block_stream_x3<8>(st, L1, L2, g, num_cu, *cur, *oth, lo_slots, nimg);
+    uint4* t = *cur;
+    *cur = *oth;
+    *oth = t;
+    return e;
+  }
+  hipError_t e = ref_conv_f16x3(st, L1, g, num_cu, dil, *cur, *oth, nullptr, lo_slots, nimg, true);
+  if (e != hipSuccess) return e;
+  return ref_conv_f16x3(st, L2, g, num_cu, dil, *oth, *cur, *cur, lo_slots, nimg, true);      // in-place residual
 }
 
 // ---- workspace -----------------------------------------------------------------------------------
@@ -1614,8 +1661,10 @@ int refine_level(sn_handle* h, Workspace& ws, hipStream_t st, const Tower& T, fl
     const bool tail = !x3 && last_streamed && h->tail_fuse && kRefDil[kNRefRes - 1] == 1 && ups.rs <= 0.5f;
     for (int i = 0; i < kNRefRes; ++i) {
       if (x3) {
-        HIP_TRY(h, ref_conv_f16x3(st, T.rres16x3[i][0], g, ncu, kRefDil[i], x16, t16, nullptr, lo_slots, c, true));
-        HIP_TRY(h, ref_conv_f16x3(st, T.rres16x3[i][1], g, ncu, kRefDil[i], t16, x16, x16, lo_slots, c, true));
+        const bool dom = pe && stream_x3_supports(kRefDil[i]) && h->dom_pairs < 6;
+        if (dom) HIP_TRY(h, hipEventRecord(h->ev_dom[2 * h->dom_pairs], st));
+        HIP_TRY(h, ref_block_f16x3(st, T.rres16x3[i][0], T.rres16x3[i][1], g, ncu, kRefDil[i], &x16, &t16, lo_slots, c));
+        if (dom) HIP_TRY(h, hipEventRecord(h->ev_dom[2 * h->dom_pairs++ + 1], st));
       } else if (tail && i == kNRefRes - 1) {
         if (pe) HIP_TRY(h, hipEventRecord(h->ev[5], st));          // the plain tower launches end here
         StreamHeadArgs ha{T.rout.w, src, od, orw, T.rout.bias, dnorm, inv_q, sh, sw, H, W, ups, stat};
@@ -2151,7 +2200,13 @@ int sn_create_prio(const char* model_file, const sn_config* cfg, int stream_prio
   {
     // the Infinity-Cache sizing of the per-layer forms, for the split tensors of SN_PREC_F16X3 (what an AUTO handle falls back to)
     const double tensor_mb = 4.0 * h->tw[0].rg.Hs * h->tw[0].rg.Ws * 16.0 / 1048576.0 * 2.0;
-    const int r = (int)(256.0 / (2.0 * tensor_mb * h->tower_streams) + 0.5);
+    int r = (int)(256.0 / (2.0 * tensor_mb * h->tower_streams) + 0.5);
+    // with the split blocks streamed too (sn_stream_block_x3.hpp) the chunk no longer has to live in the Infinity Cache:
+    // the fp16 rule below (1280x720: one pair 1067, four 1099-1134, six 1137-1139, eight 1142 pairs/s, profiles/r06_x3_stream_ab.txt)
+    if (stream_x3_supports(8)) {
+      const int by_px = (int)(5.5e6 / ((double)h->Hp * h->Wp) + 0.5);
+      if (by_px > r) r = by_px;
+    }
     h->refine_chunk_x3 = r < 1 ? 1 : (r > 8 ? 8 : r);
   }
   if (h->refine_chunk <= 0) {
@@ -2167,7 +2222,7 @@ int sn_create_prio(const char* model_file, const sn_config* cfg, int stream_prio
     // the Infinity Cache, and fuller launches amortise the restart rows and the launch itself: ~5.5 Mpx per launch
     // (1280x720: 6 pairs; round 3: 4 pairs 2583 -> 2653 pairs/s; round 5, three interleaved runs: 4 pairs 3064-3068,
     // 6 pairs 3074-3081, 8 pairs 3071-3078, profiles/r05_schedule_sweep.txt).
-    if (want_f16 && fuse_env() == 4 && stream_block_supports(8)) {
+    if ((want_f16 && fuse_env() == 4 && stream_block_supports(8)) || (c.precision == SN_PREC_F16X3 && stream_x3_supports(8))) {
       const int by_px = (int)(5.5e6 / ((double)h->Hp * h->Wp) + 0.5);
       if (by_px > rc_auto) rc_auto = by_px;
     }
@@ -2870,6 +2925,20 @@ int sn_get_dominant_kernel(sn_handle* h, char* name, size_t cap, int* launches, 
       return SN_OK;
     }
   }
+  if (cur == SN_PREC_F16X3) {
+    int n = 0;
+    for (int i = 0; i < kNRefRes; ++i)
+      if (stream_x3_supports(kRefDil[i])) ++n;
+    if (n > 0) {     // (SN_X3_STREAM=0: the per-layer description below applies)
+      if (name && cap)
+        snprintf(name, cap, "%s", "k_ref_block_stream_x3<DIL> (fused residual block: two 3x3 C->C convs + residual, 3 fp16 MFMAs 32x32x16 "
+                                  "per product on hi/lo split operands; the FLOPs counted are the model's, not the three products')");
+      if (launches) *launches = n;
+      if (flops) *flops = 2.0 * (2.0 * px * kC * kC * 9);           // two convolutions per launch (algorithmic)
+      if (bytes) *bytes = px * kC * 4.0 * 2.0;                       // x (hi + lo) read once + y written once; t never leaves LDS
+      return SN_OK;
+    }
+  }
   if (name && cap)
     snprintf(name, cap, "%s",
              cur == SN_PREC_F16     ? "k_ref_conv_f16<DIL> (refinement 3x3 C->C, fp16 MFMA 32x32x16)"
@@ -3379,6 +3448,61 @@ int sn_dbg_ref_conv_f16x3(sn_handle* h, const float* in, int h_px, int w, const 
           for (int e = 0; e < 8; ++e)
             if ((float)hout[part * lo_slots * 8 + (((size_t)c * g.Hs + y) * g.Ws + x) * 8 + e] != 0.f) {
               set_err(h, "f16x3 conv wrote into the zero border");
+              return SN_ERR_DEVICE;
+            }
+        }
+  return SN_OK;
+}
+
+int sn_dbg_ref_block_f16x3(sn_handle* h, const float* in, int h_px, int w, const float* w1, const float* b1, const float* w2,
+                           const float* b2, int dil, int form, float* out) {
+  DevScope ds;      // frees every tracked device buffer on every return path
+  if (!h || !in || !w1 || !b1 || !w2 || !b2 || !out || h_px <= 0 || w <= 0) return SN_ERR_ARG;
+  if (dil != 1 && dil != 2 && dil != 4 && dil != 8) return SN_ERR_ARG;
+  if (form != 0 && form != 1) return SN_ERR_ARG;            // 0 = two k_ref_conv_f16x3 launches, 1 = the streamed block
+  if (form == 1 && !stream_x3_supports(dil)) return SN_ERR_ARG;
+  int rc = check_device(h);
+  if (rc) return rc;
+  const RefGeom g = make_ref_geom(h_px, w);
+  const size_t lo_slots = ref16_slots(g, 1) + ref_slack(g), slots = 2 * lo_slots;      // [hi | slack | lo | slack]
+  auto idx = [&](int c, int y, int x) { return ((((size_t)(c >> 3)) * g.Hs + y + kRefPad) * g.Ws + x + kRefPad) * 8 + (c & 7); };
+  std::vector<_Float16> hin(slots * 8, (_Float16)0.f);
+  for (int c = 0; c < kC; ++c)
+    for (int y = 0; y < h_px; ++y)
+      for (int x = 0; x < w; ++x) {
+        const float v = in[((size_t)c * h_px + y) * w + x];
+        const _Float16 hi = (_Float16)v;
+        hin[idx(c, y, x)] = hi;
+        hin[lo_slots * 8 + idx(c, y, x)] = (_Float16)((v - (float)hi) * kSplitScale);
+      }
+  RefLayerF16 L1, L2;
+  if ((rc = upload_ref_f16x3(h, HostLayer{w1, b1, kC, kC, 9}, &L1))) return rc;
+  ds.track(L1.bias); ds.track(L1.wfrag);
+  if ((rc = upload_ref_f16x3(h, HostLayer{w2, b2, kC, kC, 9}, &L2))) return rc;
+  ds.track(L2.bias); ds.track(L2.wfrag);
+  uint4 *da = nullptr, *db = nullptr, *da_raw = nullptr, *db_raw = nullptr;
+  HIP_TRY(h, alloc_ref16(g, slots, &da_raw, &da));
+  ds.track(da_raw);
+  HIP_TRY(h, alloc_ref16(g, slots, &db_raw, &db));
+  ds.track(db_raw);
+  HIP_TRY(h, hipMemcpy(da, hin.data(), slots * 16, hipMemcpyHostToDevice));
+  uint4 *cur = da, *oth = db;
+  HIP_TRY(h, ref_block_f16x3(h->stream, L1, L2, g, h->num_cu, dil, &cur, &oth, lo_slots, 1, form == 1));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  std::vector<_Float16> hout(slots * 8);
+  HIP_TRY(h, hipMemcpy(hout.data(), cur, slots * 16, hipMemcpyDeviceToHost));
+  for (int c = 0; c < kC; ++c)
+    for (int y = 0; y < h_px; ++y)
+      for (int x = 0; x < w; ++x)
+        out[((size_t)c * h_px + y) * w + x] = (float)hout[idx(c, y, x)] + (float)hout[lo_slots * 8 + idx(c, y, x)] * kSplitInv;
+  for (int part = 0; part < 2; ++part)       // both zero borders must have survived
+    for (int c = 0; c < 4; ++c)
+      for (int y = 0; y < g.Hs; ++y)
+        for (int x = 0; x < g.Ws; ++x) {
+          if (y >= kRefPad && y < kRefPad + h_px && x >= kRefPad && x < kRefPad + w) continue;
+          for (int e = 0; e < 8; ++e)
+            if ((float)hout[part * lo_slots * 8 + (((size_t)c * g.Hs + y) * g.Ws + x) * 8 + e] != 0.f) {
+              set_err(h, "f16x3 residual block wrote into the zero border");
               return SN_ERR_DEVICE;
             }
         }

@@ -334,6 +334,10 @@ int sn_dbg_ref_conv_f16x3(sn_handle *h, const float *in, int h_px, int w, const 
  * kernel the pipeline runs by default (every dilation). */
 int sn_dbg_ref_block_f16(sn_handle *h, const float *in, int h_px, int w, const float *w1, const float *b1,
                          const float *w2, const float *b2, int dil, float *out);
+/* the same block on split operands (SN_PREC_F16X3): form 0 = two k_ref_conv_f16x3 launches, 1 = the row-streaming fused kernel
+ * (sn_stream_block_x3.hpp) — bit-identical to form 0 */
+int sn_dbg_ref_block_f16x3(sn_handle *h, const float *in, int h_px, int w, const float *w1, const float *b1,
+                           const float *w2, const float *b2, int dil, int form, float *out);
 /* The LAST residual block of the fp16 tower followed by the refinement head (conv 3x3 32 -> 1, disp = relu(up + D r), wire
  * quantisation) on n images: fp32 host tensors in [n][32][hk][wk] (the level's padded activation, rounded to fp16 by the hook),
  * low [n][hk / ups][wk / ups] (the map the level starts from; ups = 16: soft-argmin map, 2: the level below), head_w [32][9].
