@@ -1653,8 +1653,8 @@ __global__ __launch_bounds__(256, MINW) void k_ref_conv_f16_v2(const uint4* __re
 // the fp32-MFMA cost.  Tensors are two NCHW8c fp16 tensors (hi at `in`, lo at `in + lo_slots`), so the HBM
 // traffic equals an fp32 tensor.  One workgroup per CU (LDS holds hi and lo tiles), NBUF-deep DMA ring.
 // ------------------------------------------------------------------------------------------
-template <int DIL, int TW, int NBUF, bool RES, int WPC = 1>
-__global__ __launch_bounds__(256, WPC) void k_ref_conv_f16x3(const uint4* __restrict__ in, uint4* out, const uint4* res,
+template <int DIL, int TW, int NBUF, bool RES>
+__global__ __launch_bounds__(256, 1) void k_ref_conv_f16x3(const uint4* __restrict__ in, uint4* out, const uint4* res,
                                                            size_t lo_slots,                 // hi -> lo tensor offset
                                                            const uint4* __restrict__ wfrag, // [hi 18][lo 18] x 64 slots
                                                            const float* __restrict__ bias, RefGeom g, int nimg, int lrelu) {

@@ -1013,20 +1013,20 @@ int upload_ref_f16x3(sn_handle* h, const HostLayer& l, RefLayerF16* out) {
   return SN_OK;
 }
 
-template <int DIL, int TW, int NBUF, int WPC = 1>
+template <int DIL, int TW, int NBUF>
 hipError_t launch_ref_f16x3(hipStream_t st, const RefLayerF16& L, const RefGeom& g, int num_cu, const uint4* in,
                             uint4* out, const uint4* res, size_t lo_slots, int nimg, bool lrelu) {
   using T = RefTile2<DIL, TW>;
   constexpr int lds_bytes = NBUF * 2 * T::BUF * 16;
-  static_assert(WPC * lds_bytes <= 160 * 1024, "workgroups per CU");
-  auto kern = res ? k_ref_conv_f16x3<DIL, TW, NBUF, true, WPC> : k_ref_conv_f16x3<DIL, TW, NBUF, false, WPC>;
+  auto kern = res ? k_ref_conv_f16x3<DIL, TW, NBUF, true> : k_ref_conv_f16x3<DIL, TW, NBUF, false>;
   hipError_t e = ensure_lds_attr(kern, lds_bytes);
   if (e != hipSuccess) return e;
   RefGeom gt = g;
   gt.tiles_x = (g.W + TW - 1) / TW;
   const int total = gt.tiles_x * gt.tiles_y * nimg;
   const int band = (total + 7) / 8;
-  int cap = num_cu / 8 * WPC;                // WPC workgroups per CU
+  int cap = num_cu / 8;                      // one workgroup per CU (two on 8 x 32 tiles measured -6 %: the kernel is
+                                             // memory bound and spills at 256 registers, profiles/r06_x3_wpc_ab.txt)
   if (cap < 1) cap = 1;
   const int rounds = (band + cap - 1) / cap;
   const int nlb = (band + rounds - 1) / rounds;
@@ -1616,18 +1616,11 @@ int refine_level(sn_handle* h, Workspace& ws, hipStream_t st, const Tower& T, fl
     // head on the fp32 MFMA with the nine taps as M (k_head_final_mfma32); SN_HEAD_MFMA32=0 keeps the per-pixel kernel (A/B)
     static const bool head_mfma = !(getenv("SN_HEAD_MFMA32") != nullptr && atoi(getenv("SN_HEAD_MFMA32")) == 0);
     if (head_mfma) {
-      static const int th_env = getenv("SN_HEAD_TH") ? atoi(getenv("SN_HEAD_TH")) : 14;          // probe
-      static const bool nostat = getenv("SN_HEAD_NOSTAT") != nullptr;                              // probe
-      auto go = [&](auto thc) {
-        constexpr int TH = decltype(thc)::value;
-        using HT = HeadTile<TH>;
-        const int tiles_x = (W + HT::TWO - 1) / HT::TWO, tiles_y = (H + TH - 1) / TH;
-        hipLaunchKernelGGL(k_head_final_mfma32<TH>, dim3((unsigned)(tiles_x * tiles_y * c)), dim3(256), HT::LDS_BYTES, st, rx,
-                           T.rout.w, T.rout.bias, src, sh, sw, Hk, Wk, H, W, dnorm, inv_q, od, orw, tiles_x, tiles_y, ups,
-                           nostat ? nullptr : stat);
-      };
-      if (th_env == 6) go(std::integral_constant<int, 6>{});
-      else go(std::integral_constant<int, 14>{});
+      constexpr int TH = 14;               // 16-row P window: 32 segments, 8 per wave (TH = 6 measured the same 41 us without the statistic)
+      using HT = HeadTile<TH>;
+      const int tiles_x = (W + HT::TWO - 1) / HT::TWO, tiles_y = (H + TH - 1) / TH;
+      hipLaunchKernelGGL(k_head_final_mfma32<TH>, dim3((unsigned)(tiles_x * tiles_y * c)), dim3(256), HT::LDS_BYTES, st, rx,
+                         T.rout.w, T.rout.bias, src, sh, sw, Hk, Wk, H, W, dnorm, inv_q, od, orw, tiles_x, tiles_y, ups, stat);
     } else {
       dim3 grid((W + 63) / 64, (H + 3) / 4, c);
       hipLaunchKernelGGL(k_head_final, grid, dim3(256), 0, st, rx, T.rout.w, T.rout.bias, src, sh, sw, Hk, Wk, H, W, dnorm,
