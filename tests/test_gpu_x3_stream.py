@@ -39,3 +39,43 @@ def test_streamed_split_block_is_the_two_launches(eng, oracle, h, w, dil):
     if h * w <= 130 * 300:
         ref = _block(oracle, x, w1, b1, w2, b2, dil)
         assert np.abs(one - ref).max() / np.abs(ref).max() < 2e-5
+
+
+_SCRIPT = """
+import sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from hobot_stereonet_amd import api, synth
+w, h, d, n = (int(v) for v in sys.argv[4:8])
+xs = np.stack([synth.model_input_i8(w, h, d, 90 + i) for i in range(n)])
+with api.StereoNetHIP(sys.argv[2], max_batch=n, precision=api.PREC_F16X3) as eng:
+    disp, raw = eng.infer(xs)
+np.savez(sys.argv[3], disp=disp, raw=raw)
+"""
+
+
+@pytest.mark.parametrize("w,h,d,n,multi", [(200, 120, 64, 3, False), (416, 128, 64, 2, True), (1280, 720, 192, 1, False)])
+def test_split_mode_end_to_end_is_unchanged_by_the_streamed_blocks(model_factory, oracle, weights_blob, weights_multi, tmp_path,
+                                                                  w, h, d, n, multi):
+    """SN_PREC_F16X3 through the pipeline with the streamed blocks (default) and with SN_X3_STREAM=0 (two launches per block):
+    the same maps bit for bit, single-scale and hierarchical, and inside the split mode's bound against the oracle."""
+    import os
+    import subprocess
+    import sys
+    from hobot_stereonet_amd import synth
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    model = model_factory(w, h, d, multi)
+    script = tmp_path / "run.py"
+    script.write_text(_SCRIPT)
+    outs = {}
+    for tag, e in (("stream", {}), ("layers", {"SN_X3_STREAM": "0"})):
+        out = str(tmp_path / f"{tag}.npz")
+        r = subprocess.run([sys.executable, str(script), root, model, out, str(w), str(h), str(d), str(n)],
+                           env=dict(os.environ, **e), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = np.load(out)
+    assert np.array_equal(outs["stream"]["raw"], outs["layers"]["raw"])
+    assert np.array_equal(outs["stream"]["disp"], outs["layers"]["disp"])
+    blob = weights_multi if multi else weights_blob
+    odisp, _, _ = oracle.forward(blob, synth.model_input_i8(w, h, d, 90), d)
+    assert np.abs(outs["stream"]["disp"].reshape(n, h, w)[0] - odisp).mean() < 2e-4
