@@ -370,11 +370,15 @@ __global__ __launch_bounds__(256, 1) void k_down01_f16(const int8_t* __restrict_
 
 // ------------------------------------------------------------------------------------------
 // The eight border classes: first / last row and column of the quarter-resolution map (1.7 % of it at 1280 x 720).  One
-// wave per run of up to 32 pixels of one class; A fragments streamed from L2 (80 KB per class), B fragments gathered
-// from the int8 image with per-byte bounds tests.  Same K order and the same two MFMAs per K-step as the inner kernel.
+// WORKGROUP of three waves per run of up to 32 pixels of one class, wave c takes input channel c (13 of the 39 K-steps); A
+// fragments streamed from L2 (80 KB per class), B fragments gathered from the int8 image with per-byte bounds tests, the
+// same two MFMAs per K-step as the inner kernel; the three partial sums meet in LDS, channel 0 + channel 1 + channel 2.
+// (Rounds 5: one wave per run walked the three channels one after the other — three dependent request phases, and in the
+// column classes every lane of a load touches its own image row: 29 us for a single pair, 1.7x the inner kernel that does
+// 60x the work; profiles/r06_f16_b1_kernel_summary.txt.)
 // ------------------------------------------------------------------------------------------
 template <bool W4>      // W % 4 == 0 (as k_down01_f16): straight-line unconditional loads; otherwise the checked byte-wise form
-__global__ __launch_bounds__(256) void k_down01_border(const int8_t* __restrict__ in6, int H, int W,
+__global__ __launch_bounds__(192) void k_down01_border(const int8_t* __restrict__ in6, int H, int W,
                                                        const uint4* __restrict__ wfrag,   // [9][39][hi|lo][64]
                                                        const float* __restrict__ bias,    // [9][32]
                                                        uint4* __restrict__ out, int Ho, int Wo, int nimg, int oPH, int oPW,
@@ -382,9 +386,11 @@ __global__ __launch_bounds__(256) void k_down01_border(const int8_t* __restrict_
   using T = Down01;
   const int lane = threadIdx.x & 63, j = lane & 31, g = lane >> 5;
   const int nT = (Wo - 2 + 31) / 32, nL = (Ho - 2 + 31) / 32, per_img = 4 + 2 * nT + 2 * nL;
-  const int wid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
-  if (wid >= per_img * (nimg >> 1)) return;        // a wave takes its run of pixels in BOTH eyes of a pair (nimg = 2 pairs):
-  const int n = wid / per_img;                     // each A fragment it fetches from L2 then serves two MFMAs per weight half
+  __shared__ float s_part[2][64][64];              // partial sums of waves 1, 2: [wave - 1][eye, accumulator, register][lane]
+  const int wid = (int)blockIdx.x;                 // one run per workgroup
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // = input channel of this wave
+  // the run of pixels is taken in BOTH eyes of a pair (nimg = 2 pairs): each A fragment fetched from L2 then serves two
+  const int n = wid / per_img;                     // MFMAs per weight half
   int ch = wid - n * per_img;
   int cls, oy, ox;
   bool valid = true;
@@ -418,7 +424,7 @@ __global__ __launch_bounds__(256) void k_down01_border(const int8_t* __restrict_
   f32x16 acc0[2], acc1[2];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    acc0[0][r] = acc0[1][r] = bias[cls * kC + (r & 3) + 8 * (r >> 2) + 4 * g];
+    acc0[0][r] = acc0[1][r] = wave == 0 ? bias[cls * kC + (r & 3) + 8 * (r >> 2) + 4 * g] : 0.f;
     acc1[0][r] = acc1[1][r] = 0.f;
   }
   const int xw = 4 * ox - 8 + 8 * g;
@@ -446,8 +452,8 @@ __global__ __launch_bounds__(256) void k_down01_border(const int8_t* __restrict_
     }
     return v;
   };
-#pragma unroll 1
-  for (int c = 0; c < 3; ++c) {
+  {
+    const int c = wave;
     uint32_t v0[2][T::KW], v1[2][T::KW];
     uint4 fa[T::KW], fb[T::KW];
     unsigned keep0 = 0, keep1 = 0;                 // (the same for both eyes: same pixel, same window)
@@ -482,6 +488,24 @@ __global__ __launch_bounds__(256) void k_down01_border(const int8_t* __restrict_
         acc1[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8*>(&fb[u]), x, acc1[e], 0, 0, 0);
       }
   }
+  if (wave > 0) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s_part[wave - 1][(e * 2 + 0) * 16 + r][lane] = acc0[e][r];
+        s_part[wave - 1][(e * 2 + 1) * 16 + r][lane] = acc1[e][r];
+      }
+  }
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc0[e][r] = (acc0[e][r] + s_part[0][(e * 2 + 0) * 16 + r][lane]) + s_part[1][(e * 2 + 0) * 16 + r][lane];
+      acc1[e][r] = (acc1[e][r] + s_part[0][(e * 2 + 1) * 16 + r][lane]) + s_part[1][(e * 2 + 1) * 16 + r][lane];
+    }
   if (valid) {
     const size_t plane_b = (size_t)oPH * oPW * 16;
 #pragma unroll

@@ -480,10 +480,10 @@ hipError_t launch_down01(hipStream_t st, const Down01W& L, const int8_t* in6, in
                        og.PH, og.PW, og.py, og.px);
   const int per_img = 4 + 2 * ((Wo - 2 + 31) / 32) + 2 * ((Ho - 2 + 31) / 32);
   if (w4)
-    hipLaunchKernelGGL(k_down01_border<true>, dim3((per_img * (nimg / 2) + 3) / 4), dim3(256), 0, st, in6, H, W, L.wfrag, L.bias, out,
+    hipLaunchKernelGGL(k_down01_border<true>, dim3(per_img * (nimg / 2)), dim3(192), 0, st, in6, H, W, L.wfrag, L.bias, out,
                        Ho, Wo, nimg, og.PH, og.PW, og.py, og.px);
   else
-    hipLaunchKernelGGL(k_down01_border<false>, dim3((per_img * (nimg / 2) + 3) / 4), dim3(256), 0, st, in6, H, W, L.wfrag, L.bias, out,
+    hipLaunchKernelGGL(k_down01_border<false>, dim3(per_img * (nimg / 2)), dim3(192), 0, st, in6, H, W, L.wfrag, L.bias, out,
                        Ho, Wo, nimg, og.PH, og.PW, og.py, og.px);
   return hipGetLastError();
 }
