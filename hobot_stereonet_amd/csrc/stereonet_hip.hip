@@ -1791,7 +1791,14 @@ int forward(sn_handle* h, Workspace& ws, hipStream_t st, int n, const int8_t* in
   const bool piped = !prof && (&ws == &h->ws) && h->overlap && n > rb;
   int rc;
   int ctr_block = 0;          // tile-queue blocks are handed out in launch order (alloc_ws sized the pool)
-  if (ws.tile_ctr) HIP_TRY(h, hipMemsetAsync(ws.tile_ctr, 0, kTileCtrBytes * ws.n_chunks, st));
+  // the tile queues belong to the per-layer fp16 kernel (k_ref_conv_f16_v2): with every block of this call streamed (the
+  // default) or on split operands nobody reads them, and the fill is a 4 us launch of its own in front of a single pair
+  bool need_queues = ws.tile_ctr != nullptr && mode == SN_PREC_F16;
+  if (need_queues && h->fuse_mode == 4) {
+    need_queues = false;
+    for (int i = 0; i < kNRefRes; ++i) need_queues = need_queues || !stream_block_supports(kRefDil[i]);
+  }
+  if (need_queues) HIP_TRY(h, hipMemsetAsync(ws.tile_ctr, 0, kTileCtrBytes * ws.n_chunks, st));
   HIP_TRY(h, hipMemsetAsync(ws.stats, 0, kMaxLevels * kStatWordStride * sizeof(unsigned long long), st));
   auto finish = [&]() -> int {
     HIP_TRY(h, hipMemcpyAsync(ws.stats_host, ws.stats, (size_t)h->levels * kStatWordStride * sizeof(unsigned long long),
