@@ -5,6 +5,8 @@
 #    command (rocprofv3 serialises the dispatches, so these are per-kernel times, not the overlapped pipeline), separate
 #    --pmc passes: FETCH_SIZE / WRITE_SIZE (scripts/pmc_traffic.py) and SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE
 #    (scripts/mfma_busy.py), SQ_LDS_BANK_CONFLICT + SQ_LDS_IDX_ACTIVE (scripts/lds_conflicts.py); PAIRS_PER_LAUNCH = the --refine-chunk of the PMC passes: 4, two chunks per 8-pair batch, comparable across rounds), bench lines of the other precision modes / configs / the stream mode, the MALL probe.
+# (the --pmc passes force --precision f16: an AUTO handle's first call also runs ONE pair in both arithmetics, whose one-pair
+# launches would be averaged into the per-launch figures)
 # Copy what should be judged into profiles/ afterwards (gpurun_out/ is scratch).
 set -u
 TAG=${1:-r02x}
@@ -21,10 +23,10 @@ SN_NO_OVERLAP=1 $T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/
 python $ROOT/scripts/kstats.py $(find $OUT/${TAG}_prof_ser -name "*kernel_stats.csv" | head -1) 30 > $OUT/${TAG}_kernel_summary_serialised.txt
 rm -rf $OUT/${TAG}_prof_ser
 for c in FETCH_SIZE WRITE_SIZE; do
-  $T rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${TAG}_pmc_$c -- python $ROOT/bench.py --steps 2 --warmup 1 --batch 8 --refine-chunk 4 --no-cpu-baseline --no-end-to-end --no-verify --no-long > $OUT/${TAG}_pmc_$c.log 2>&1
+  $T rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${TAG}_pmc_$c -- python $ROOT/bench.py --steps 2 --warmup 1 --batch 8 --refine-chunk 4 --precision f16 --no-cpu-baseline --no-end-to-end --no-verify --no-long > $OUT/${TAG}_pmc_$c.log 2>&1
 done
-$T rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_pmc_mfma -- python $ROOT/bench.py --steps 2 --warmup 1 --batch 8 --refine-chunk 4 --no-cpu-baseline --no-end-to-end --no-verify --no-long > $OUT/${TAG}_pmc_mfma.log 2>&1
-$T rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/${TAG}_pmc_lds -- python $ROOT/bench.py --steps 2 --warmup 1 --batch 8 --refine-chunk 4 --no-cpu-baseline --no-end-to-end --no-verify --no-long > $OUT/${TAG}_pmc_lds.log 2>&1
+$T rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_pmc_mfma -- python $ROOT/bench.py --steps 2 --warmup 1 --batch 8 --refine-chunk 4 --precision f16 --no-cpu-baseline --no-end-to-end --no-verify --no-long > $OUT/${TAG}_pmc_mfma.log 2>&1
+$T rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/${TAG}_pmc_lds -- python $ROOT/bench.py --steps 2 --warmup 1 --batch 8 --refine-chunk 4 --precision f16 --no-cpu-baseline --no-end-to-end --no-verify --no-long > $OUT/${TAG}_pmc_lds.log 2>&1
 cd $ROOT
 python scripts/lds_conflicts.py $(find $OUT/${TAG}_pmc_lds -name "*counter_collection.csv" | head -1) $OUT/${TAG}_lds_conflicts.json > $OUT/${TAG}_lds_conflicts.txt 2>&1
 python scripts/pmc_traffic.py $(find $OUT/${TAG}_pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1) \
