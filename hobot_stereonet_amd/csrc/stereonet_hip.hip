@@ -107,6 +107,7 @@ constexpr size_t kTileCtrBytes = (size_t)2 * 6 * kTileCtrStride * sizeof(unsigne
 struct Workspace {          // activations for up to `nb` pairs
   int nb = 0, rb = 0, pb = 0;   // batch capacity, pairs per tower launch, pairs per low-res piece
   int rb_x3 = 0;                // SN_PREC_AUTO: pairs per tower launch while the handle runs in SN_PREC_F16X3 (same buffers)
+  int tower_cu = 0;             // > 0: workgroups of a streamed tower launch (an async slot that shares the GPU, submit_common)
   int rbk_x3[4] = {};           // ... and per coarse level
   // refinement statistic: one 64-bit fixed-point sum of |D r| per level (refine_stat_commit) + the self-check's sum at [4];
   // copied to the pinned twin at the end of every forward()
@@ -166,8 +167,8 @@ struct Slot {                // async request slot (sn_submit / sn_wait)
   // given mask is captured, later ones replay it (the ~45 launches of a single-pair forward are launch-bound)
   // the first index is the input kind: 0 = int8 model tensor (sn_submit), 1 = side-by-side NV12 frame (sn_submit_nv12)
   // the last index is the arithmetic the request runs in (0 = SN_PREC_F16X3, 1 = anything else): SN_PREC_AUTO may change it
-  hipGraphExec_t gexec[2][4][2] = {};
-  int uses[2][4][2] = {};
+  hipGraphExec_t gexec[2][4][4] = {};       // [input kind][output mask][arithmetic x (alone | sharing the GPU)]
+  int uses[2][4][4] = {};
   int mode_run = 0;          // arithmetic of the request in flight (SN_PREC_*)
 };
 
@@ -1596,6 +1597,7 @@ int refine_level(sn_handle* h, Workspace& ws, hipStream_t st, const Tower& T, fl
                  float dnorm, float* od, int32_t* orw, unsigned* chunk_ctr, int c, int cap, bool pe, int mode,
                  unsigned long long* stat) {
   const int ncu = h->num_cu;
+  const int tcu = ws.tower_cu > 0 ? ws.tower_cu : ncu;      // workgroups of the streamed tower launches
   const int Hk = T.Hk, Wk = T.Wk;
   // The wire factor is the reference's literal 16 * 12 for EVERY dmax (parser.cpp:86, stereonet_node.cpp:288,
   // publisher_member_function.py:75): the unmodified consumers recover pixels whatever D the model was built for.
@@ -1656,16 +1658,16 @@ int refine_level(sn_handle* h, Workspace& ws, hipStream_t st, const Tower& T, fl
       if (x3) {
         const bool dom = pe && stream_x3_supports(kRefDil[i]) && h->dom_pairs < 6;
         if (dom) HIP_TRY(h, hipEventRecord(h->ev_dom[2 * h->dom_pairs], st));
-        HIP_TRY(h, ref_block_f16x3(st, T.rres16x3[i][0], T.rres16x3[i][1], g, ncu, kRefDil[i], &x16, &t16, lo_slots, c));
+        HIP_TRY(h, ref_block_f16x3(st, T.rres16x3[i][0], T.rres16x3[i][1], g, tcu, kRefDil[i], &x16, &t16, lo_slots, c));
         if (dom) HIP_TRY(h, hipEventRecord(h->ev_dom[2 * h->dom_pairs++ + 1], st));
       } else if (tail && i == kNRefRes - 1) {
         if (pe) HIP_TRY(h, hipEventRecord(h->ev[5], st));          // the plain tower launches end here
         StreamHeadArgs ha{T.rout.w, src, od, orw, T.rout.bias, dnorm, inv_q, sh, sw, H, W, ups, stat};
-        HIP_TRY(h, ref_block_stream_tail(st, T.rres16[i][0], T.rres16[i][1], g, ncu, x16, c, h->dump, ha));
+        HIP_TRY(h, ref_block_stream_tail(st, T.rres16[i][0], T.rres16[i][1], g, tcu, x16, c, h->dump, ha));
       } else {
         const bool dom = pe && h->fuse_mode == 4 && stream_block_supports(kRefDil[i]) && h->dom_pairs < 6;
         if (dom) HIP_TRY(h, hipEventRecord(h->ev_dom[2 * h->dom_pairs], st));
-        HIP_TRY(h, ref_block_f16(st, T.rres16[i][0], T.rres16[i][1], g, ncu, kRefDil[i], &x16, &t16, c,
+        HIP_TRY(h, ref_block_f16(st, T.rres16[i][0], T.rres16[i][1], g, tcu, kRefDil[i], &x16, &t16, c,
                                  chunk_ctr + 2 * i * kTileCtrStride, h->fuse_mode, h->dump, rev_env != 0));
         if (dom) HIP_TRY(h, hipEventRecord(h->ev_dom[2 * h->dom_pairs++ + 1], st));
       }
@@ -2764,7 +2766,18 @@ static int submit_common(sn_handle* h, const void* in, int kind, int32_t* out_i3
   // arithmetic of this request: an SN_PREC_AUTO handle's current one (sn_wait folds the request's statistic in and repeats
   // a request that left the fp16 tower's envelope)
   const int mode = h->precision == SN_PREC_AUTO ? h->actl.st.mode : h->precision;
-  const int mi = mode == SN_PREC_F16X3 ? 0 : 1;
+  // A streamed tower launch is one 160 KB-LDS workgroup per CU: while it runs nothing of another request fits the chip, so
+  // requests in flight together simply queue (four in flight: the sum of their kernel times).  A request submitted while
+  // others are in flight therefore leaves an eighth of the CUs to them: their low-resolution launches (tens of workgroups,
+  // latency bound) run beside its tower — 2015-2030 -> 2135 pairs/s with four in flight (profiles/r06_async_wgs.txt), at
+  // +14 % tower time for that request; a request that finds the GPU idle keeps every CU (latency of a lone frame unchanged).
+  int others = 0;
+  for (auto& c : h->slots)
+    if (&c != s && c.ticket != 0) ++others;
+  static const bool share_env = !(getenv("SN_ASYNC_SHARE") != nullptr && atoi(getenv("SN_ASYNC_SHARE")) == 0);
+  const int shared = (others > 0 && share_env) ? 1 : 0;
+  s->ws.tower_cu = shared ? h->num_cu * 7 / 8 : 0;
+  const int mi = (mode == SN_PREC_F16X3 ? 0 : 2) + shared;
   s->mode_run = mode;
   auto enqueue = [&]() -> int {
     if (kind == 1) {
