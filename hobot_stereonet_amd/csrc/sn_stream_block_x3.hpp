@@ -14,11 +14,12 @@
 //
 // Differences from the fp16 kernel (read that file first: rings, slots, units, iterators and the counted waits are the same):
 //   * x ring and t ring exist twice (hi part, lo part PART slots behind it); a step is R = 2 rows so that both fit 160 KB;
-//   * TWO waves per role, ONE wave per SIMD (256 threads, up to 512 registers each): a wave holds its conv's 36 weight
-//     fragments (hi + lo) and two accumulators per segment, two segments (one row of the step).  With three MFMAs per
-//     product a wave's matrix work per step is 216 MFMAs = 6.9 k cycles against ~1.5 - 2 k cycles of DMA issue / epilogue,
-//     so the role pairing per SIMD that the fp16 kernel needs (36 MFMAs per product-row) is not needed here — and the
-//     registers of 144 weight values + 64 accumulators + two fragment batches do not fit 256;
+//   * waves per role NWR = 4 (default): two waves per SIMD, one of each role, as in the fp16 kernel — one role's epilogue and
+//     DMA issue sit beside the other's MFMAs.  A wave holds its conv's 36 weight fragments (hi + lo, 144 registers), two
+//     accumulators and ONE batch of fragments (the SIMD's other wave covers the reads): 236 VGPRs, no scratch.  The first form
+//     (NWR = 2, one wave per SIMD with 512 registers, double-buffered hand-scheduled fragment batches; SN_X3_NWR=2) measured
+//     1110-1118 pairs/s where this one runs 1229-1235; NWR = 4 WITH the double-buffered batches (256 VGPRs + 20 bytes of
+//     scratch) 1164-1176 (profiles/r06_x3_nwr_ab.txt);
 //   * the epilogues are k_ref_conv_f16x3's, expression for expression (v = acc0 + acc1 / 2048 [+ xh + xl / 2048], LeakyReLU,
 //     hi = fp16(v), lo = fp16((v - hi) 2048)): the streamed block is bit-identical to the two launches
 //     (tests/test_gpu_x3_stream.py through sn_dbg_ref_block_f16x3).
@@ -63,11 +64,12 @@ __device__ __forceinline__ float x3_acc(float a0, float a1) { return a0 + a1 * k
 // k_ref_conv_f16x3's order per accumulator.  rp[ky] = LDS pointer into the HI part (lane part included), the lo part sits
 // PART slots behind; COLW = slots per channel block row.  Fragments of one tap row of one k-half (3 kx x SPW segments, hi
 // and lo) are fetched one batch ahead of the MFMAs that consume them.
-template <int DIL, int COLW, int SPW, int PART>
+template <int DIL, int COLW, int SPW, int PART, bool DB = true>
 __device__ __forceinline__ void stream_conv108(const uint4* const (&rp)[3], const half8 (&wh)[18], const half8 (&wl)[18],
                                                const f32x16& bv, f32x16 (&a0)[SPW], f32x16 (&a1)[SPW]) {
   constexpr int NB = 3 * SPW;            // (kx, segment) pairs per batch
-  half8 bh[2][NB], bl[2][NB];
+  constexpr int NBUF = DB ? 2 : 1;       // DB = false (two waves per SIMD): the other wave covers the fragment reads
+  half8 bh[NBUF][NB], bl[NBUF][NB];
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   auto fetch = [&](int batch, half8 (&dh)[NB], half8 (&dl)[NB]) {
     const int kk = batch / 3, ky = batch - kk * 3;
@@ -80,17 +82,21 @@ __device__ __forceinline__ void stream_conv108(const uint4* const (&rp)[3], cons
         dl[kx * SPW + s] = *reinterpret_cast<const half8*>(p + PART);
       }
   };
-  fetch(0, bh[0], bl[0]);
+  if (DB) fetch(0, bh[0], bl[0]);
 #pragma unroll
   for (int batch = 0; batch < 6; ++batch) {
-    if (batch + 1 < 6) fetch(batch + 1, bh[(batch + 1) & 1], bl[(batch + 1) & 1]);
+    if (DB) {
+      if (batch + 1 < 6) fetch(batch + 1, bh[(batch + 1) & (NBUF - 1)], bl[(batch + 1) & (NBUF - 1)]);
+    } else {
+      fetch(batch, bh[0], bl[0]);
+    }
     const int kk = batch / 3, ky = batch - kk * 3;
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
       for (int s = 0; s < SPW; ++s) {
         const int w = (ky * 3 + kx) * 2 + kk;
-        const half8 xh = bh[batch & 1][kx * SPW + s], xl = bl[batch & 1][kx * SPW + s];
+        const half8 xh = bh[batch & (NBUF - 1)][kx * SPW + s], xl = bl[batch & (NBUF - 1)][kx * SPW + s];
         if (batch == 0 && kx == 0) {
           a0[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[w], xh, bv, 0, 0, 0);
           a1[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[w], xh, zero, 0, 0, 0);
@@ -101,20 +107,22 @@ __device__ __forceinline__ void stream_conv108(const uint4* const (&rp)[3], cons
         a1[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[w], xl, a1[s], 0, 0, 0);
       }
   }
-  // issue order for the machine scheduler: the first batch's fragments up front, then two reads per three MFMAs
-  // (0x100 = DS read, 0x008 = MFMA)
-  __builtin_amdgcn_sched_group_barrier(0x100, 2 * NB + 2, 0);
+  if (DB) {
+    // issue order for the machine scheduler: the first batch's fragments up front, then two reads per three MFMAs
+    // (0x100 = DS read, 0x008 = MFMA)
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * NB + 2, 0);
 #pragma unroll
-  for (int i = 0; i < 18 * SPW; ++i) {
-    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    for (int i = 0; i < 18 * SPW; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    }
   }
 }
 
 // xin / yout: the hi tensors; the lo tensors sit lo_bytes behind them.  wfrag1 / wfrag2: [hi 18][lo 18] x 64 slots
 // (upload_ref_f16x3).
 template <int DIL, int TW, int R, int NXS, int NWR>
-__global__ __launch_bounds__(128 * NWR, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_ref_block_stream_x3(
+__global__ __launch_bounds__(128 * NWR, NWR / 2) __attribute__((amdgpu_waves_per_eu(NWR / 2, NWR / 2))) void k_ref_block_stream_x3(
     const uint4* __restrict__ xin, uint4* __restrict__ yout, size_t lo_bytes, const uint4* __restrict__ wfrag1,
     const float* __restrict__ bias1, const uint4* __restrict__ wfrag2, const float* __restrict__ bias2, RefGeom g, StreamSched sc) {
   using T = StreamTileX3<DIL, TW, R, NXS, NWR>;
@@ -250,7 +258,7 @@ __global__ __launch_bounds__(128 * NWR, 1) __attribute__((amdgpu_waves_per_eu(1,
         }
         const f32x16 bv = *reinterpret_cast<const f32x16*>(s_bias + gh * 16);
         f32x16 a0[T::SPW], a1[T::SPW];
-        stream_conv108<DIL, T::XW, T::SPW, T::XRING>(xp, wfh, wfl, bv, a0, a1);
+        stream_conv108<DIL, T::XW, T::SPW, T::XRING, (NWR <= 2)>(xp, wfh, wfl, bv, a0, a1);
         // epilogue: t = lrelu(acc0 + acc1 / 2048) as an fp16 hi / lo pair, zero outside the image (conv2's zero padding)
         const int trow = (c1.v0 - 1 + R * (c1.j - 1) + rowW) * DIL + c1_py;           // image row of this wave's t row
         const bool row_ok = trow >= 0 && trow < g.H;
@@ -401,7 +409,7 @@ __global__ __launch_bounds__(128 * NWR, 1) __attribute__((amdgpu_waves_per_eu(1,
           tp[ky] = tring + (rr < 0 ? gt2 : gt1) * T::TGP + (rr & (R - 1)) * T::TROW + lane_t;
         }
         const f32x16 bv = *reinterpret_cast<const f32x16*>(s_bias + (2 + gh) * 16);
-        stream_conv108<DIL, T::TW, T::SPW, T::TRING>(tp, wfh, wfl, bv, a0, a1);
+        stream_conv108<DIL, T::TW, T::SPW, T::TRING, (NWR <= 2)>(tp, wfh, wfl, bv, a0, a1);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       block_barrier();

@@ -1210,10 +1210,10 @@ inline bool stream_x3_supports(int dil) {
   static const bool on = !(getenv("SN_X3_STREAM") != nullptr && atoi(getenv("SN_X3_STREAM")) == 0);
   return on && (dil == 1 || dil == 2 || dil == 4 || dil == 8);
 }
-template <int DIL>
+template <int DIL, int NWR = 2>
 hipError_t launch_ref_block_stream_x3(hipStream_t st, const RefLayerF16& L1, const RefLayerF16& L2, const RefGeom& g, int num_cu,
                                       const uint4* x, uint4* y, size_t lo_slots, int nimg) {
-  using T = StreamTileX3<DIL>;
+  using T = StreamTileX3<DIL, 64, 2, 5, NWR>;
   static_assert(T::ROWS_ABOVE <= kStreamRowsAbove && T::ROWS_BELOW <= kStreamRowsBelow, "inside the zero rows the tensors are allocated with");
   auto kern = k_ref_block_stream_x3<T::DIL, T::TW, T::R, T::NXS, T::NWR>;
   hipError_t e = ensure_lds_attr(kern, T::LDS_BYTES);
@@ -1236,7 +1236,15 @@ hipError_t ref_block_f16x3(hipStream_t st, const RefLayerF16& L1, const RefLayer
                            uint4** cur, uint4** oth, size_t lo_slots, int nimg, bool stream = true) {
   if (stream && stream_x3_supports(dil)) {
     hipError_t e = hipErrorInvalidValue;
-    if (dil == 1) e = launch_ref_block_stream_x3<1>(st, L1, L2, g, num_cu, *cur, *oth, lo_slots, nimg);
+    // waves per role: 4 (default) = two waves per SIMD, one of each role, so that one role's epilogue / DMA issue sits beside the
+    // other's MFMAs (256 registers per wave: 20 bytes of scratch at dilation 1 / 2); SN_X3_NWR=2 = one wave per SIMD (A/B)
+    static const int nwr = getenv("SN_X3_NWR") ? atoi(getenv("SN_X3_NWR")) : 4;
+    if (nwr == 4) {
+      if (dil == 1) e = launch_ref_block_stream_x3<1, 4>(st, L1, L2, g, num_cu, *cur, *oth, lo_slots, nimg);
+      else if (dil == 2) e = launch_ref_block_stream_x3<2, 4>(st, L1, L2, g, num_cu, *cur, *oth, lo_slots, nimg);
+      else if (dil == 4) e = launch_ref_block_stream_x3<4, 4>(st, L1, L2, g, num_cu, *cur, *oth, lo_slots, nimg);
+      else e = launch_ref_block_stream_x3<8, 4>(st, L1, L2, g, num_cu, *cur, *oth, lo_slots, nimg);
+    } else if (dil == 1) e = launch_ref_block_stream_x3<1>(st, L1, L2, g, num_cu, *cur, *oth, lo_slots, nimg);
     else if (dil == 2) e = launch_ref_block_stream_x3<2>(st, L1, L2, g, num_cu, *cur, *oth, lo_slots, nimg);
     else if (dil == 4) e = launch_ref_block_stream_x3<4>(st, L1, L2, g, num_cu, *cur, *oth, lo_slots, nimg);
     else e = launch_ref_block_stream_x3<8>(st, L1, L2, g, num_cu, *cur, *oth, lo_slots, nimg);
