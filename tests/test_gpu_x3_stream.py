@@ -68,7 +68,7 @@ def test_split_mode_end_to_end_is_unchanged_by_the_streamed_blocks(model_factory
     script = tmp_path / "run.py"
     script.write_text(_SCRIPT)
     outs = {}
-    for tag, e in (("stream", {}), ("layers", {"SN_X3_STREAM": "0"})):
+    for tag, e in (("stream", {}), ("layers", {"SN_X3_STREAM": "0"}), ("nwr2", {"SN_X3_NWR": "2"})):
         out = str(tmp_path / f"{tag}.npz")
         r = subprocess.run([sys.executable, str(script), root, model, out, str(w), str(h), str(d), str(n)],
                            env=dict(os.environ, **e), capture_output=True, text=True, timeout=600)
@@ -76,6 +76,7 @@ def test_split_mode_end_to_end_is_unchanged_by_the_streamed_blocks(model_factory
         outs[tag] = np.load(out)
     assert np.array_equal(outs["stream"]["raw"], outs["layers"]["raw"])
     assert np.array_equal(outs["stream"]["disp"], outs["layers"]["disp"])
+    assert np.array_equal(outs["stream"]["raw"], outs["nwr2"]["raw"])          # one wave per SIMD (SN_X3_NWR=2): the same bits
     blob = weights_multi if multi else weights_blob
     odisp, _, _ = oracle.forward(blob, synth.model_input_i8(w, h, d, 90), d)
     assert np.abs(outs["stream"]["disp"].reshape(n, h, w)[0] - odisp).mean() < 2e-4
